@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X hot path (BASELINE.json metric).
+
+Metric: field-ops/sec of the MLE fold (one sumcheck-round restriction, `partial_evaluate(0, [r])`,
+polynomial/src/multilinear/evaluation_form.rs:40-80) on a 2^24-element BN254-Fr table, 3 field ops per pair
+(1 mul + 2 sub, evaluation_form.rs:68).  A "step" is one fold of one 2^24 table per GPU: read 512 MiB, write 256 MiB
+(algorithmic bytes 48 * 2^24 = 805,306,368 B).  Inputs are synthetic (device-generated, resident in HBM
+before the timed region).  At N > 1 every rank folds its own 2^24-element shard of a 2^(24+log2 N)-variable table
+(suffix shard): the fold has no exchange step, so there is no data-path collective ("weak" scaling).
+The sumcheck prover wall-clock (second half of the metric) is reported in `extra`.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; N > 1 is launched by torch.distributed.run, one rank per
+GPU.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_VARS = 24
+ALG_BYTES_PER_FOLD = 48 * (1 << N_VARS)
+FIELD_OPS_PER_FOLD = 3 * (1 << (N_VARS - 1))
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(field):
+    """Reference-faithful CPU restatement (oracle, 1 thread) of the same fold on a bounded sample."""
+    import numpy as np
+
+    from oracle import binding as orc
+
+    n = 21   # 2^21 elements = 64 MiB: same streaming pattern, bounded run time
+    tab = orc.fill_random(field, 0x5EED0000 + 24, 1 << n)
+    r = orc.fill_random(field, 0xC4A11, 1)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        out = orc.mle_partial_evaluate(field, n, tab, 0, r)
+        reps += 1
+        if time.perf_counter() - t0 > 10.0:
+            break
+    dt = time.perf_counter() - t0
+    ops = 3 * (1 << (n - 1)) * reps
+    return {
+        "value": ops / dt,
+        "unit": "field-ops/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{reps} folds of a 2^{n}-element BN254-Fr table (clone + fold + copy as evaluation_form.rs:49-79), "
+                  f"{dt:.1f} s, single thread (the reference is single-threaded)",
+    }, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+
+    import zk_amd
+
+    field = zk_amd.BN254_FR
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx = zk_amd.Context(field, local_rank)
+    # rank g holds one 2^24-element shard of the global table (shard = index mod world).  The synthetic
+    # table is i.i.d. uniform, so each shard simply draws its own index range of the generator stream.
+    table = zk_amd.MultiLinearPolynomial.random(ctx, N_VARS, 0x5EED0000 + 24, first_index=rank << N_VARS)
+    out = zk_amd.MultiLinearPolynomial.alloc(ctx, N_VARS - 1)
+    tr = zk_amd.Transcript()
+    tr.append(b"zk_amd bench challenge")
+    r = tr.sample_field_element(field)       # a uniform challenge (not 0/1: generic path)
+    ctx.synchronize()
+
+    for _ in range(args.warmup):
+        table.fold_into(r, out)
+    ctx.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    # the K timed steps are bracketed by HIP events on the launch stream inside zk_bench_fold
+    kernel_ms = table.bench_fold(r, out, args.steps)
+    ctx.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_ops = FIELD_OPS_PER_FOLD * args.steps * world
+    achieved_gbps = ALG_BYTES_PER_FOLD / (kernel_ms * 1e-3) / 1e9
+    result = {
+        "metric": "field-ops/sec (MLE fold, 2^24 evals, BN254 Fr)",
+        "value": total_ops / dt,
+        "unit": "field-ops/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u256 (8 x u32 Montgomery limbs, integer)",
+        "data": "synthetic",
+        "config": {"workload": "mle_fold_msb 2^24 BN254-Fr elements per GPU (partial_evaluate(0,[r]))",
+                   "n_vars": N_VARS, "field": "bn254_fr", "shard": "index mod n_gpus (no collective in the fold)"},
+        "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "zk::k_fold", "kernel_ms": kernel_ms, "algorithmic_bytes": ALG_BYTES_PER_FOLD},
+    }
+
+    if rank == 0 and not args.no_extra:
+        extra = {}
+        try:
+            # second half of the metric: sumcheck prover wall-clock (prove_partial semantics), k=2, D=2
+            for n in (20, 24):
+                A = zk_amd.MultiLinearPolynomial.random(ctx, n, 0x5EED0000 + n, 0)
+                B = zk_amd.MultiLinearPolynomial.random(ctx, n, 0x5EED0000 + n, 1 << n)
+                pp = zk_amd.ProductPoly.new([A, B])
+                s = pp.round_sums(1)
+                from oracle import binding as orc  # checker only: claimed sum = S0 + S1 (field add)
+
+                claimed = orc.add(field, s[0], s[1])
+                prover = zk_amd.SumcheckProver(2)
+                prover.prove_partial(pp, claimed)   # warm
+                ts = []
+                for _ in range(5):
+                    ctx.synchronize()
+                    t1 = time.perf_counter()
+                    prover.prove_partial(pp, claimed)
+                    ts.append(time.perf_counter() - t1)
+                extra[f"sumcheck_prove_partial_ms_n{n}_k2_d2"] = sorted(ts)[len(ts) // 2] * 1e3
+                A.free(); B.free()
+            extra["modmul_per_s_register_resident"] = ctx.bench_modmul(2000)
+            extra["copy_gbps_1GiB"] = ctx.bench_copy(1 << 30, 10)
+        except Exception as e:  # extras never invalidate the headline line
+            extra["error"] = repr(e)
+        result["extra"] = extra
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base, _ = cpu_baseline(field)
+        result["cpu_baseline"] = base
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

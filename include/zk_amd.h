@@ -1,0 +1,196 @@
+/*
+ * zk_amd.h -- C ABI of libzk_amd.so: the MI355X (gfx950) implementation of the iammadab/zk sumcheck /
+ * MLE-fold / NTT hot path.
+ *
+ * The reference has no FFI: its boundary for this path is the public Rust API of the
+ * `polynomial`, `sumcheck`, `transcript` and `fft` crates.  Each entry point below names the reference item it
+ * replaces (file:line relative to the reference checkout); bindings/rust/ shows the shim that maps the
+ * reference's type and method names onto these calls, INTEGRATION.md shows how a maintainer wires it in.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.  Every call returns int32_t: 0 = ok, negative =
+ *    zk_status.  zk_strerror() returns the reference's own `Err(&'static str)` text where one exists.
+ *    No exception or panic crosses the boundary: misuse the reference panics on returns ZK_ERR_PANIC_*.
+ *  - Field elements cross as `const uint64_t*`: ark-ff 0.5.0 `Fp<MontBackend<_,4>>` in memory -- 4 little-endian
+ *    u64 limbs, Montgomery form (R = 2^256), fully reduced.  A `Vec<F>` is passed as-is, no conversion.
+ *  - Device memory lives behind opaque handles (zk_mle).  The `*_host` calls are the value-semantics
+ *    convenience forms (upload, compute, download) matching the reference's Vec-in / Vec-out signatures.
+ *  - A zk_ctx owns one device, one HIP stream and its scratch; it is not thread-safe, distinct contexts are
+ *    independent.  All work is stream-ordered; calls that return host data synchronise that stream.
+ *  - There is NO CPU fallback: without a usable gfx950 device zk_ctx_create fails with ZK_ERR_NO_DEVICE.
+ */
+#ifndef ZK_AMD_H
+#define ZK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZK_AMD_ABI_VERSION 1
+
+typedef enum zk_field {
+    ZK_FIELD_BN254_FR = 0,     /* north-star field (not a dependency of the reference: SURVEY D2) */
+    ZK_FIELD_BLS12_381_FR = 1, /* field of the reference's polynomial/sumcheck tests */
+    ZK_FIELD_BLS12_377_FR = 2  /* field of the reference's fft test */
+} zk_field;
+
+typedef enum zk_status {
+    ZK_OK = 0,
+    ZK_ERR_EVAL_LEN = -1,       /* "evaluation vec len should equal 2^n_vars"            evaluation_form.rs:20 */
+    ZK_ERR_EVAL_ARITY = -2,     /* "evaluate must assign to all variables"               evaluation_form.rs:85 */
+    ZK_ERR_EMPTY_PRODUCT = -3,  /* "cannot create product polynomial from empty ..."     product_poly.rs:16    */
+    ZK_ERR_ARITY_MISMATCH = -4, /* "... don't share the same number of variables"        product_poly.rs:25    */
+    ZK_ERR_PANIC_INDEX = -5,    /* reference panics: integer underflow in index_pair / slice (evaluation_form.rs:55,75) */
+    ZK_ERR_FFT_NOT_POW2 = -6,   /* reference panics: "values must be a power of 2"       fft/src/lib.rs:29     */
+    ZK_ERR_FFT_NO_ROOT = -7,    /* reference panics: get_root_of_unity(..).unwrap()      fft/src/lib.rs:6,14   */
+    ZK_ERR_VERIFY_ROUNDS = -8,  /* "invalid proof: require 1 round poly for each variable in poly" verifier.rs:18 */
+    ZK_ERR_VERIFY_SUM = -9,     /* "verifier check failed: claimed_sum != p(0) + p(1)"   verifier.rs:64        */
+    ZK_ERR_BAD_ARG = -20,
+    ZK_ERR_BAD_FIELD = -21,
+    ZK_ERR_NO_DEVICE = -22,     /* no gfx950 device / HIP runtime failure at context creation */
+    ZK_ERR_HIP = -23,           /* a HIP call failed; zk_last_hip_error() has the text */
+    ZK_ERR_ALLOC = -24,
+    ZK_ERR_UNSUPPORTED = -25,
+    ZK_ERR_CONTEXT_MISMATCH = -26
+} zk_status;
+
+typedef struct zk_ctx zk_ctx;               /* one device + stream + scratch */
+typedef struct zk_mle zk_mle;               /* device-resident table of 2^n_vars elements */
+typedef struct zk_transcript zk_transcript; /* host-side Keccak-256 Fiat-Shamir sponge */
+
+/* ---- library ---------------------------------------------------------------------------------------- */
+int32_t zk_abi_version(void);
+const char *zk_strerror(int32_t status);
+const char *zk_last_hip_error(void);
+int32_t zk_device_count(int32_t *out_count);
+
+/* ---- context ---------------------------------------------------------------------------------------- */
+int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out_ctx);
+int32_t zk_ctx_destroy(zk_ctx *ctx);
+int32_t zk_ctx_synchronize(zk_ctx *ctx);
+/* run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own; NULL restores it */
+int32_t zk_ctx_set_stream(zk_ctx *ctx, void *hip_stream);
+int32_t zk_ctx_field(const zk_ctx *ctx, int32_t *out_field);
+/* modulus as 4 LE limbs; two-adicity s of p-1 */
+int32_t zk_field_modulus(int32_t field, uint64_t out_p[4]);
+int32_t zk_field_two_adicity(int32_t field, int32_t *out_s);
+/* host-side element helpers for callers without ark-ff (tests, Python): F::from(u64), into_bigint, from_be_bytes_mod_order */
+int32_t zk_fe_from_u64(int32_t field, uint64_t v, uint64_t out[4]);
+int32_t zk_fe_from_canonical(int32_t field, const uint64_t limbs[4], uint64_t out[4]);
+int32_t zk_fe_to_canonical(int32_t field, const uint64_t a[4], uint64_t out_limbs[4]);
+int32_t zk_fe_from_be_bytes_mod_order(int32_t field, const uint8_t *bytes, size_t len, uint64_t out[4]);
+
+/* ---- MultiLinearPolynomial  (polynomial/src/multilinear/evaluation_form.rs) ------------------------------- */
+/* ::new(n_vars, evaluations) :15-27 -- len != 2^n_vars -> ZK_ERR_EVAL_LEN.  Copies host -> device. */
+int32_t zk_mle_upload(zk_ctx *ctx, uint64_t n_vars, const uint64_t *evals, uint64_t len, zk_mle **out);
+/* uninitialised table (for outputs) / synthetic table (bench inputs: SURVEY 8d generator, element i of stream `seed`) */
+int32_t zk_mle_alloc(zk_ctx *ctx, uint64_t n_vars, zk_mle **out);
+int32_t zk_mle_fill_random(zk_ctx *ctx, zk_mle *t, uint64_t seed, uint64_t first_index);
+int32_t zk_mle_clone(zk_ctx *ctx, const zk_mle *t, zk_mle **out);                    /* #[derive(Clone)] :4 */
+int32_t zk_mle_free(zk_ctx *ctx, zk_mle *t);
+int32_t zk_mle_n_vars(const zk_mle *t, uint64_t *out_n_vars);                         /* ::n_vars :30 */
+int32_t zk_mle_download(zk_ctx *ctx, const zk_mle *t, uint64_t *out_evals);           /* ::evaluation_slice :92 */
+int32_t zk_mle_device_ptr(const zk_mle *t, void **out_ptr);                           /* raw device pointer (interop) */
+/* ::partial_evaluate(initial_var, assignments) :40-80 -> new table of n_vars - n_assign variables */
+int32_t zk_mle_partial_evaluate(zk_ctx *ctx, const zk_mle *t, uint64_t initial_var,
+                                const uint64_t *assignments, uint64_t n_assign, zk_mle **out);
+/* the sumcheck fold: partial_evaluate(0, [r]) written into a preallocated (n_vars-1)-variable table (no allocation) */
+int32_t zk_mle_fold_into(zk_ctx *ctx, const zk_mle *t, const uint64_t r[4], zk_mle *out);
+/* ::evaluate(assignments) :83-89 -- n_point != n_vars -> ZK_ERR_EVAL_ARITY */
+int32_t zk_mle_evaluate(zk_ctx *ctx, const zk_mle *t, const uint64_t *point, uint64_t n_point, uint64_t out[4]);
+/* ::to_bytes :97-103 -- 32-byte big-endian canonical integers, concatenated (32 << n_vars bytes) */
+int32_t zk_mle_to_bytes(zk_ctx *ctx, const zk_mle *t, uint8_t *out_bytes);
+/* value-semantics forms of the two calls above the reference's own tests use */
+int32_t zk_mle_partial_evaluate_host(zk_ctx *ctx, uint64_t n_vars, const uint64_t *evals, uint64_t len,
+                                     uint64_t initial_var, const uint64_t *assignments, uint64_t n_assign,
+                                     uint64_t *out_evals /* 2^(n_vars-n_assign) elements */);
+
+/* ---- ProductPoly  (polynomial/src/product_poly.rs) ---------------------------------------------------------- */
+/* ::new :14-32 -- k == 0 -> ZK_ERR_EMPTY_PRODUCT, unequal arity -> ZK_ERR_ARITY_MISMATCH.  Validation only:
+ * a product is passed to the calls below as an array of k table handles. */
+int32_t zk_product_check(const zk_mle *const *factors, uint64_t k);
+/* ::prod_reduce :66-74 -> new table, element-wise product of the k factors */
+int32_t zk_prod_reduce(zk_ctx *ctx, const zk_mle *const *factors, uint64_t k, zk_mle **out);
+/* ::evaluate :36-44 */
+int32_t zk_product_evaluate(zk_ctx *ctx, const zk_mle *const *factors, uint64_t k, const uint64_t *point,
+                            uint64_t n_point, uint64_t out[4]);
+/* one prover round's polynomial in evaluation form (sumcheck/src/prover.rs:49-56):
+ * out[t] = sum_x prod_f P_f(t, x), t = 0..max_var_degree -- (max_var_degree+1) elements */
+int32_t zk_round_sums(zk_ctx *ctx, const zk_mle *const *factors, uint64_t k, uint32_t max_var_degree,
+                      uint64_t *out_sums);
+
+/* ---- Transcript  (transcript/src/lib.rs) -- host side ------------------------------------------------------- */
+int32_t zk_transcript_new(zk_transcript **out);                                        /* ::new :10-14 */
+int32_t zk_transcript_free(zk_transcript *t);
+int32_t zk_transcript_append(zk_transcript *t, const uint8_t *data, size_t len);       /* ::append :16-18 */
+int32_t zk_transcript_sample_field_element(zk_transcript *t, int32_t field, uint64_t out[4]); /* :27-30 */
+int32_t zk_transcript_sample_challenge(zk_transcript *t, uint8_t out[32]);             /* :20-25 (private in the reference) */
+int32_t zk_keccak256(const uint8_t *data, size_t len, uint8_t out[32]);
+
+/* ---- SumcheckProver<MAX_VAR_DEGREE, F>  (sumcheck/src/prover.rs) ---------------------------------------------- */
+/* ::prove :15-20 (absorb_table != 0: the whole table is serialised and absorbed first) and ::prove_partial :24-30
+ * (absorb_table == 0).  The factor tables are consumed as scratch only if `consume` != 0 (the reference takes the
+ * polynomial by value); otherwise they are left intact.
+ * out_round_polys: n_vars * (max_var_degree+1) elements (SumcheckProof.round_polys, row-major);
+ * out_challenges: n_vars elements (the Vec<F> prove_partial returns). */
+int32_t zk_sumcheck_prove(zk_ctx *ctx, zk_mle *const *factors, uint64_t k, uint32_t max_var_degree,
+                          const uint64_t sum[4], int32_t absorb_table, int32_t consume,
+                          uint64_t *out_round_polys, uint64_t *out_challenges);
+/* value-semantics form: k host tables of 2^n_vars elements each */
+int32_t zk_sumcheck_prove_host(zk_ctx *ctx, const uint64_t *const *tables, uint64_t k, uint64_t n_vars,
+                               uint32_t max_var_degree, const uint64_t sum[4], int32_t absorb_table,
+                               uint64_t *out_round_polys, uint64_t *out_challenges);
+
+/* Stepwise form of the same loop for a table sharded across devices: every rank holds the shard
+ * {idx : idx mod world == rank} as an (n_vars - log2 world)-variable table and calls these in lockstep; the
+ * caller sums `out_limbs` across ranks between the two calls (one all-reduce of (D+1)*16 uint64 lanes).
+ *   begin : local round sums as lazily reduced lanes: per element 16 lanes, lane i holds a 16-bit digit-sum
+ *           (radix 2^16) so that up to 2^47 ranks can be added lane-wise without overflow.  Device buffer.
+ *   finish: carry-propagate + reduce the summed lanes mod p, absorb, squeeze the challenge, fold every factor.
+ * zk_sumcheck_shard_begin folds with the previous challenge first when round > 0 (fused kernel). */
+typedef struct zk_shard_prover zk_shard_prover;
+int32_t zk_shard_prover_create(zk_ctx *ctx, zk_mle *const *factors, uint64_t k, uint32_t max_var_degree,
+                               const uint64_t sum[4], zk_shard_prover **out);
+int32_t zk_shard_prover_destroy(zk_shard_prover *sp);
+int32_t zk_shard_prover_lanes_ptr(zk_shard_prover *sp, void **out_device_ptr, uint64_t *out_n_lanes);
+int32_t zk_shard_prover_round_begin(zk_shard_prover *sp);
+int32_t zk_shard_prover_round_finish(zk_shard_prover *sp, uint64_t *out_round_poly, uint64_t out_challenge[4]);
+/* after the local rounds: the (single-element) folded factors, for the cross-rank tail */
+int32_t zk_shard_prover_remaining(zk_shard_prover *sp, uint64_t *out_n_vars_left);
+
+/* ---- SumcheckVerifier  (sumcheck/src/verifier.rs) -- host-side protocol logic; oracle check on device ------------ */
+/* ::verify_partial :38-41 -> SubClaim{sum, challenges} */
+int32_t zk_sumcheck_verify_partial(int32_t field, uint64_t n_rounds, uint32_t max_var_degree,
+                                   const uint64_t sum[4], const uint64_t *round_polys,
+                                   uint64_t out_subclaim_sum[4], uint64_t *out_challenges);
+/* ::verify :15-33 -> *out_ok = 1 for Ok(true), 0 for Ok(false); Err -> negative status */
+int32_t zk_sumcheck_verify(zk_ctx *ctx, const zk_mle *const *factors, uint64_t k, uint64_t n_round_polys,
+                           uint32_t max_var_degree, const uint64_t sum[4], const uint64_t *round_polys,
+                           int32_t *out_ok);
+
+/* ---- fft crate  (fft/src/lib.rs) ------------------------------------------------------------------------------ */
+/* fft :4-8 / ifft :11-19 on a device vector of 2^log_n elements (zk_mle doubles as the vector handle);
+ * natural order in, natural order out, omega = F::get_root_of_unity(n). */
+int32_t zk_ntt(zk_ctx *ctx, const zk_mle *in, int32_t inverse, zk_mle *out);
+/* value-semantics forms: fft(Vec<F>) -> Vec<F>; n == 0 or n > 2^two_adicity -> ZK_ERR_FFT_NO_ROOT,
+ * n not a power of two -> ZK_ERR_FFT_NO_ROOT (get_root_of_unity returns None first, fft/src/lib.rs:6) */
+int32_t zk_fft_host(zk_ctx *ctx, const uint64_t *in, uint64_t n, uint64_t *out);
+int32_t zk_ifft_host(zk_ctx *ctx, const uint64_t *in, uint64_t n, uint64_t *out);
+/* fft_internal(values, omega) :21-46 with a caller-chosen omega: n not a power of two -> ZK_ERR_FFT_NOT_POW2 */
+int32_t zk_fft_internal_host(zk_ctx *ctx, const uint64_t *in, uint64_t n, const uint64_t omega[4], uint64_t *out);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------ */
+/* time `reps` launches of the MSB fold of `t` into `out` with HIP events on the context's stream; average ms/launch */
+int32_t zk_bench_fold(zk_ctx *ctx, const zk_mle *t, const uint64_t r[4], zk_mle *out, int32_t reps, double *out_ms);
+/* register-resident modular-multiply throughput (no memory traffic): variant 0 = fe_mul chain. Returns modmul/s */
+int32_t zk_bench_modmul(zk_ctx *ctx, int32_t variant, int32_t iters, double *out_modmul_per_s);
+/* plain 16-B/lane streaming copy of `bytes` bytes: achieved GB/s (calibrates the HBM ceiling on this device) */
+int32_t zk_bench_copy(zk_ctx *ctx, uint64_t bytes, int32_t reps, double *out_gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZK_AMD_H */

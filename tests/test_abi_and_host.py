@@ -1,0 +1,115 @@
+"""CPU-side checks of libzk_amd.so: it loads, exports every symbol include/zk_amd.h declares, fails loudly without
+a GPU, and its HOST logic (field helpers, Keccak-256 transcript, verifier) agrees with the oracle.  No kernel runs.
+"""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+import zk_amd
+from oracle import binding as orc
+from zk_amd import _lib
+
+FIELDS = [zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR]
+
+
+def test_library_exports_every_declared_symbol():
+    names = _lib.declared_symbols()
+    assert len(names) >= 50
+    missing = [n for n in names if not hasattr(_lib.lib, n)]
+    assert missing == []
+    assert _lib.lib.zk_abi_version() == 1
+
+
+def test_every_declared_symbol_has_a_python_signature():
+    untyped = [n for n in _lib.declared_symbols()
+               if n not in _lib._sig and n not in ("zk_abi_version", "zk_strerror", "zk_last_hip_error")]
+    assert untyped == []
+
+
+def test_strerror_reproduces_reference_messages():
+    s = lambda code: _lib.lib.zk_strerror(code).decode()
+    assert s(-1) == "evaluation vec len should equal 2^n_vars"                      # evaluation_form.rs:20
+    assert s(-2) == "evaluate must assign to all variables"                         # evaluation_form.rs:85
+    assert s(-3) == "cannot create product polynomial from empty polynomials"       # product_poly.rs:16
+    assert s(-4).endswith("don't share the same number of variables")               # product_poly.rs:25
+    assert s(-6) == "values must be a power of 2"                                   # fft/src/lib.rs:29
+    assert s(-8) == "invalid proof: require 1 round poly for each variable in poly" # verifier.rs:18
+    assert s(-9) == "verifier check failed: claimed_sum != p(0) + p(1)"             # verifier.rs:64
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(zk_amd.ZkError) as e:
+        zk_amd.Context(zk_amd.BN254_FR, 0)
+    assert e.value.code == -22 and "no CPU fallback" in str(e.value)
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_host_field_helpers_match_oracle(field):
+    p = orc.modulus(field)
+    assert zk_amd.modulus(field) == p
+    assert zk_amd.two_adicity(field) == orc.two_adicity(field)
+    rng = random.Random(field)
+    for v in [0, 1, 2, p - 1, (1 << 255) % p] + [rng.randrange(p) for _ in range(20)]:
+        a = zk_amd.fe_from_int(field, v)
+        assert np.array_equal(a, orc.from_int(field, v))
+        assert zk_amd.fe_to_int(field, a) == v
+    for n in (0, 1, 31, 32, 33, 64):
+        b = bytes(rng.randrange(256) for _ in range(n))
+        out = np.zeros(4, dtype=np.uint64)
+        _lib.check(_lib.lib.zk_fe_from_be_bytes_mod_order(field, b, n, out.ctypes.data_as(_lib.u64p)))
+        assert np.array_equal(out, orc.from_be_bytes_mod_order(field, b))
+    # not-reduced canonical input is rejected, not silently wrapped
+    limbs = np.array([(p >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    out = np.zeros(4, dtype=np.uint64)
+    assert _lib.lib.zk_fe_from_canonical(field, limbs.ctypes.data_as(_lib.u64p), out.ctypes.data_as(_lib.u64p)) == -20
+    assert _lib.lib.zk_field_modulus(7, out.ctypes.data_as(_lib.u64p)) == -21
+
+
+def test_keccak_and_transcript_match_oracle():
+    assert zk_amd.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    assert zk_amd.keccak256(b"abc").hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+    rng = random.Random(5)
+    for n in (1, 135, 136, 137, 272, 273, 5000):
+        msg = bytes(rng.randrange(256) for _ in range(n))
+        assert zk_amd.keccak256(msg) == orc.keccak256(msg)
+    t, o = zk_amd.Transcript(), orc.Transcript()
+    for chunk in (b"", b"abc", bytes(range(200)), b"\x00" * 136, bytes(300)):
+        t.append(chunk)
+        o.append(chunk)
+        assert t.sample_challenge() == o.sample_challenge()
+    for field in FIELDS:
+        assert np.array_equal(t.sample_field_element(field), o.sample_field_element(field))
+    assert np.array_equal(t.sample_n_field_elements(FIELDS[0], 3),
+                          np.stack([o.sample_field_element(FIELDS[0]) for _ in range(3)]))
+
+
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("k,D,n_vars", [(1, 1, 3), (2, 2, 4), (3, 3, 3), (2, 4, 2)])
+def test_verify_partial_matches_oracle(field, k, D, n_vars):
+    """verifier.rs:38-78 host logic on proofs produced by the ORACLE prover (no GPU involved)."""
+    tabs = [orc.fill_random(field, 100 + f, 1 << n_vars) for f in range(k)]
+    claimed = np.zeros(4, dtype=np.uint64)
+    for e in orc.prod_reduce(field, n_vars, tabs):
+        claimed = orc.add(field, claimed, e)
+    rp, ch = orc.sumcheck_prove(field, n_vars, tabs, D, claimed, absorb_table=False)
+    sub = zk_amd.SumcheckVerifier.verify_partial(field, zk_amd.SumcheckProof(claimed, rp))
+    osub, och = orc.sumcheck_verify_partial(field, D, claimed, rp)
+    assert np.array_equal(sub.sum, osub) and np.array_equal(sub.challenges, och) and np.array_equal(och, ch)
+    # a wrong claimed sum is rejected with the reference's message
+    bad = orc.add(field, claimed, orc.from_int(field, 1))
+    rp2, _ = orc.sumcheck_prove(field, n_vars, tabs, D, bad, absorb_table=False)
+    with pytest.raises(zk_amd.ZkError, match="claimed_sum != p\\(0\\) \\+ p\\(1\\)"):
+        zk_amd.SumcheckVerifier.verify_partial(field, zk_amd.SumcheckProof(bad, rp2))
+
+
+def test_argument_validation_without_gpu():
+    # ProductPoly::new on an empty list (product_poly.rs:15-17) needs no device
+    arr = (ctypes.c_void_p * 1)()
+    assert _lib.lib.zk_product_check(ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p)), 0) == -3
+    assert _lib.lib.zk_ctx_create(9, 0, ctypes.byref(ctypes.c_void_p())) == -21

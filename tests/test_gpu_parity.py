@@ -1,0 +1,337 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit, on the same seeded inputs.
+
+Layout follows the reference's own tests (evaluation_form.rs:106-203, product_poly.rs:91-197,
+sumcheck/src/lib.rs:31-123, fft/src/lib.rs:63-83) and then widens to random tables, every fold position, edge
+values, all three fields and the (k, D) grid.  Run with -m gpu on the MI355X box.
+"""
+import random
+
+import numpy as np
+import pytest
+
+import zk_amd
+from oracle import binding as orc
+from zk_amd import MultiLinearPolynomial as MLE
+from zk_amd import ProductPoly, SumcheckProof, SumcheckProver, SumcheckVerifier, ZkError
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = [zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR]
+_ctx = {}
+
+
+def ctx_for(field):
+    if field not in _ctx:
+        _ctx[field] = zk_amd.Context(field, 0)
+    return _ctx[field]
+
+
+def F(field, vals):
+    return zk_amd.fe_from_ints(field, vals)
+
+
+def ints(field, arr):
+    p = zk_amd.modulus(field)
+    return [v if v <= p // 2 else v - p for v in zk_amd.fe_to_ints(field, arr)]
+
+
+def sum_elems(field, arr):
+    acc = np.zeros(4, dtype=np.uint64)
+    for e in np.asarray(arr).reshape(-1, 4):
+        acc = orc.add(field, acc, e)
+    return acc
+
+
+# ------------------------------------------------------------------ reference KATs through the GPU path
+@pytest.mark.parametrize("field", FIELDS)
+def test_ref_new_and_partial_evaluate_kats(field):
+    c = ctx_for(field)
+    with pytest.raises(ZkError, match="evaluation vec len should equal 2\\^n_vars"):   # evaluation_form.rs:112-119
+        MLE.new(c, 2, F(field, [3, 1, 2]))
+    with pytest.raises(ZkError, match="evaluation vec len should equal 2\\^n_vars"):
+        MLE.new(c, 2, F(field, [3, 1]))
+    MLE.new(c, 1, F(field, [3, 1]))
+    t = MLE.new(c, 2, F(field, [3, 1, 2, 5]))
+    assert ints(field, t.partial_evaluate(0, F(field, [5])).evaluation_slice()) == [-2, 21]   # :128-137
+    assert ints(field, t.partial_evaluate(0, F(field, [0])).evaluation_slice()) == [3, 1]     # :139-146
+    assert ints(field, t.partial_evaluate(0, F(field, [1])).evaluation_slice()) == [2, 5]
+    p = MLE.new(c, 3, F(field, [0, 0, 0, 3, 0, 0, 2, 5]))                                     # 2ab + 3bc
+    assert ints(field, p.partial_evaluate(1, F(field, [2, 3])).evaluation_slice()) == [18, 22]  # :149-171
+    assert ints(field, p.evaluate(F(field, [2, 3, 4]))) == [48]                               # :181-202
+    with pytest.raises(ZkError, match="evaluate must assign to all variables"):
+        p.evaluate(F(field, [2, 3]))
+    assert p.partial_evaluate(0, F(field, [])).evaluation_slice().shape == (8, 4)
+    for bad in [(3, [1]), (0, [1, 2, 3, 4]), (2, [1, 2])]:                                    # reference panics
+        with pytest.raises(ZkError, match="reference panics"):
+            p.partial_evaluate(bad[0], F(field, bad[1]))
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_ref_product_poly_kats(field):
+    c = ctx_for(field)
+    a, b = MLE.new(c, 2, F(field, [2, 8, 10, 14])), MLE.new(c, 2, F(field, [2, 8, 10, 22]))
+    with pytest.raises(ZkError, match="share the same number of variables"):                  # product_poly.rs:98-111
+        ProductPoly.new([a, MLE.new(c, 1, F(field, [3, 1]))])
+    with pytest.raises(ZkError, match="empty polynomials"):
+        ProductPoly.new([])
+    pp = ProductPoly.new([a, b])
+    assert ints(field, pp.prod_reduce()) == [4, 64, 100, 308]                                 # :179-196
+    pe = pp.partial_evaluate(1, F(field, [10]))                                               # :154-176
+    assert ints(field, pe.polynomials[0].evaluation_slice()) == [62, 50]
+    assert ints(field, pe.polynomials[1].evaluation_slice()) == [62, 130]
+    three = ProductPoly.new([a, b, MLE.new(c, 2, F(field, [3, 1, 2, 5]))])                    # :124-151
+    pt = F(field, [1, 10])
+    want = 1
+    for q in three.polynomials:
+        want = want * zk_amd.fe_to_int(field, q.evaluate(pt)) % zk_amd.modulus(field)
+    assert zk_amd.fe_to_int(field, three.evaluate(pt)) == want
+    with pytest.raises(ZkError, match="evaluate must assign to all variables"):
+        three.evaluate(F(field, [1]))
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_ref_sumcheck_kats(field):
+    c = ctx_for(field)
+    p = ProductPoly.new([MLE.new(c, 3, F(field, [0, 0, 0, 3, 0, 0, 2, 5]))])
+    proof = SumcheckProver(1).prove(p, zk_amd.fe_from_int(field, 10))                          # sumcheck/src/lib.rs:53-62
+    assert ints(field, proof.round_polys[0]) == [3, 7]
+    assert SumcheckVerifier.verify(p, proof) is True
+    q = ProductPoly.new([MLE.new(c, 2, F(field, [3, 3, 5, 5])), MLE.new(c, 2, F(field, [0, 0, 0, 1]))])
+    proof2 = SumcheckProver(2).prove(q, zk_amd.fe_from_int(field, 5))                          # :64-100
+    assert ints(field, proof2.round_polys[0]) == [0, 5, 14]
+    assert SumcheckVerifier.verify(q, proof2) is True
+    proof3, ch = SumcheckProver(1).prove_partial(p, zk_amd.fe_from_int(field, 10))             # :102-112
+    sub = SumcheckVerifier.verify_partial(field, proof3)
+    assert np.array_equal(sub.challenges, ch)
+    assert np.array_equal(p.evaluate(sub.challenges), sub.sum)
+    bad = SumcheckProver(1).prove(p, zk_amd.fe_from_int(field, 12))                            # :114-122
+    with pytest.raises(ZkError, match="claimed_sum != p\\(0\\) \\+ p\\(1\\)"):
+        SumcheckVerifier.verify(p, bad)
+    with pytest.raises(ZkError, match="require 1 round poly"):
+        SumcheckVerifier.verify(p, SumcheckProof(proof.sum, proof.round_polys[:2]))
+
+
+@pytest.mark.parametrize("field", [zk_amd.BLS12_377_FR, zk_amd.BN254_FR, zk_amd.BLS12_381_FR])
+def test_ref_fft_roundtrip_kat(field):
+    c = ctx_for(field)
+    a = F(field, [0, 2, 34, 3434])                                                             # fft/src/lib.rs:78-82
+    assert np.array_equal(zk_amd.ifft(c, zk_amd.fft(c, a)), a)
+
+
+# ------------------------------------------------------------------ fold vs oracle
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("n_vars", [1, 2, 3, 6, 9])
+def test_fold_every_position_and_length(field, n_vars):
+    c = ctx_for(field)
+    p = zk_amd.modulus(field)
+    tab = orc.fill_random(field, 1000 + n_vars, 1 << n_vars)
+    t = MLE.new(c, n_vars, tab)
+    rng = random.Random(n_vars * 7 + field)
+    for initial_var in range(n_vars):
+        for n_assign in range(0, n_vars - initial_var + 1):
+            asg = F(field, [rng.choice([0, 1, p - 1, rng.randrange(p)]) for _ in range(n_assign)])
+            got = t.partial_evaluate(initial_var, asg).evaluation_slice()
+            assert np.array_equal(got, orc.mle_partial_evaluate(field, n_vars, tab, initial_var, asg))
+    assert np.array_equal(t.evaluation_slice(), tab)   # input untouched
+
+
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("n_vars", [12, 16])
+def test_msb_fold_evaluate_to_bytes_random(field, n_vars):
+    c = ctx_for(field)
+    tab = orc.fill_random(field, 2000 + n_vars, 1 << n_vars)
+    t = MLE.new(c, n_vars, tab)
+    r = orc.fill_random(field, 99, 1)
+    assert np.array_equal(t.partial_evaluate(0, r).evaluation_slice(), orc.mle_partial_evaluate(field, n_vars, tab, 0, r))
+    out = MLE.alloc(c, n_vars - 1)
+    assert np.array_equal(t.fold_into(r[0], out).evaluation_slice(), orc.mle_partial_evaluate(field, n_vars, tab, 0, r))
+    pt = orc.fill_random(field, 98, n_vars)
+    assert np.array_equal(t.evaluate(pt), orc.mle_evaluate(field, n_vars, tab, pt))
+    assert t.to_bytes() == orc.mle_to_bytes(field, n_vars, tab)
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_fold_edge_values(field):
+    c = ctx_for(field)
+    p = zk_amd.modulus(field)
+    n_vars = 8
+    for fill in (0, p - 1, 1):
+        tab = F(field, [fill] * (1 << n_vars))
+        t = MLE.new(c, n_vars, tab)
+        for rv in (0, 1, p - 1, 2, (p - 1) // 2):
+            r = F(field, [rv])
+            assert np.array_equal(t.partial_evaluate(0, r).evaluation_slice(),
+                                  orc.mle_partial_evaluate(field, n_vars, tab, 0, r))
+    # alternating extremes maximise the borrow / carry paths
+    tab = F(field, [0 if i & 1 else p - 1 for i in range(1 << n_vars)])
+    t = MLE.new(c, n_vars, tab)
+    for iv in (0, n_vars - 1):
+        r = F(field, [p - 1])
+        assert np.array_equal(t.partial_evaluate(iv, r).evaluation_slice(),
+                              orc.mle_partial_evaluate(field, n_vars, tab, iv, r))
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_fill_random_matches_oracle_generator(field):
+    c = ctx_for(field)
+    t = MLE.random(c, 10, seed=0x5EED0002, first_index=12345)
+    assert np.array_equal(t.evaluation_slice(), orc.fill_random(field, 0x5EED0002, 1 << 10, first_index=12345))
+
+
+# ------------------------------------------------------------------ product / round sums vs oracle
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("k", [1, 2, 3, 5])
+def test_prod_reduce_random(field, k):
+    c = ctx_for(field)
+    n_vars = 10
+    tabs = [orc.fill_random(field, 300 + f, 1 << n_vars) for f in range(k)]
+    pp = ProductPoly.new([MLE.new(c, n_vars, t) for t in tabs])
+    assert np.array_equal(pp.prod_reduce(), orc.prod_reduce(field, n_vars, tabs))
+
+
+def oracle_round_sums(field, n_vars, tabs, D):
+    out = []
+    for t in range(D + 1):
+        a = orc.from_int(field, t)[None, :]
+        folded = [orc.mle_partial_evaluate(field, n_vars, tb, 0, a) for tb in tabs]
+        out.append(sum_elems(field, orc.prod_reduce(field, n_vars - 1, folded)))
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("k,D", [(1, 1), (1, 3), (2, 1), (2, 2), (2, 4), (3, 3), (4, 4), (2, 0), (3, 6), (8, 2)])
+@pytest.mark.parametrize("n_vars", [1, 5, 13])
+def test_round_sums_grid(field, k, D, n_vars):
+    c = ctx_for(field)
+    tabs = [orc.fill_random(field, 400 + 10 * f + k, 1 << n_vars) for f in range(k)]
+    pp = ProductPoly.new([MLE.new(c, n_vars, t) for t in tabs])
+    assert np.array_equal(pp.round_sums(D), oracle_round_sums(field, n_vars, tabs, D))
+
+
+def test_round_sums_lazy_reduction_worst_case():
+    """all elements p-1: every unreduced product is maximal, exercising the wide accumulator's top limb."""
+    for field in FIELDS:
+        c = ctx_for(field)
+        p = zk_amd.modulus(field)
+        n_vars = 14   # > 16 pairs per thread would need > 2048*256*16 pairs; the flush path is hit via lazy == kMaxLazy below
+        tabs = [F(field, [p - 1]) .repeat(1 << n_vars, axis=0) for _ in range(2)]
+        pp = ProductPoly.new([MLE.new(c, n_vars, t) for t in tabs])
+        assert np.array_equal(pp.round_sums(2), oracle_round_sums(field, n_vars, tabs, 2))
+
+
+# ------------------------------------------------------------------ prover vs oracle (bit-exact transcript)
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("k,D,n_vars", [(1, 1, 12), (2, 2, 12), (3, 3, 10), (2, 1, 7), (1, 3, 6), (4, 4, 8), (2, 2, 1),
+                                        (2, 2, 2), (2, 5, 6), (1, 0, 4), (2, 3, 9)])
+@pytest.mark.parametrize("absorb", [False, True])
+def test_sumcheck_matches_oracle(field, k, D, n_vars, absorb):
+    c = ctx_for(field)
+    tabs = [orc.fill_random(field, 500 + 10 * f + k + D, 1 << n_vars) for f in range(k)]
+    claimed = sum_elems(field, orc.prod_reduce(field, n_vars, tabs))
+    want_rp, want_ch = orc.sumcheck_prove(field, n_vars, tabs, D, claimed, absorb)
+    pp = ProductPoly.new([MLE.new(c, n_vars, t) for t in tabs])
+    prover = SumcheckProver(D)
+    for consume in (False, True):   # consume last: it overwrites the tables
+        proof, ch = prover._run(pp, claimed, absorb, consume)
+        assert np.array_equal(proof.round_polys, want_rp)
+        assert np.array_equal(ch, want_ch)
+        if not consume:
+            for q, t in zip(pp.polynomials, tabs):
+                assert np.array_equal(q.evaluation_slice(), t)   # inputs intact
+    if D >= k:
+        sub = SumcheckVerifier.verify_partial(field, proof) if not absorb else None
+        if sub is not None:
+            fresh = ProductPoly.new([MLE.new(c, n_vars, t) for t in tabs])
+            assert np.array_equal(fresh.evaluate(sub.challenges), sub.sum)
+        else:
+            fresh = ProductPoly.new([MLE.new(c, n_vars, t) for t in tabs])
+            assert SumcheckVerifier.verify(fresh, proof) is True
+
+
+def test_sumcheck_zero_variables_and_host_form():
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    pp = ProductPoly.new([MLE.new(c, 0, F(field, [7]))])
+    proof, ch = SumcheckProver(2).prove_partial(pp, zk_amd.fe_from_int(field, 7))
+    assert proof.round_polys.shape[0] == 0 and ch.shape[0] == 0
+
+
+# ------------------------------------------------------------------ fft crate vs oracle
+@pytest.mark.parametrize("field", FIELDS)
+def test_fft_small_vs_faithful_oracle(field):
+    c = ctx_for(field)
+    for lg in range(0, 9):
+        v = orc.fill_random(field, 600 + lg, 1 << lg)
+        f = zk_amd.fft(c, v)
+        assert np.array_equal(f, orc.fft(field, v))
+        assert np.array_equal(zk_amd.ifft(c, f), v)
+    w = orc.root_of_unity(field, 16)
+    w3 = orc.pow_(field, w, 3)   # fft_internal with a caller-chosen primitive root
+    v = orc.fill_random(field, 77, 16)
+    got = zk_amd.fft_internal(c, v, w3)
+    want = np.zeros_like(v)
+    orc._check(orc._lib.orc_fft_internal(field, orc._p(v), orc._c.c_uint64(16), orc._p(w3), orc._p(want)))
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("lg", [10, 13, 16])
+def test_fft_medium_vs_oracle_fast(field, lg):
+    c = ctx_for(field)
+    v = orc.fill_random(field, 700 + lg, 1 << lg)
+    f = zk_amd.fft(c, v)
+    assert np.array_equal(f, orc.ntt_fast(field, v))
+    assert np.array_equal(zk_amd.ifft(c, f), v)
+
+
+def test_fft_error_behaviour():
+    c = ctx_for(zk_amd.BN254_FR)
+    with pytest.raises(ZkError, match="get_root_of_unity"):      # fft/src/lib.rs:6 unwrap on None
+        zk_amd.fft(c, F(zk_amd.BN254_FR, [1, 2, 3]))
+    with pytest.raises(ZkError, match="get_root_of_unity"):
+        zk_amd.fft(c, np.zeros((0, 4), dtype=np.uint64))
+    with pytest.raises(ZkError, match="values must be a power of 2"):   # fft/src/lib.rs:28-30
+        zk_amd.fft_internal(c, F(zk_amd.BN254_FR, [1, 2, 3]), zk_amd.fe_from_int(zk_amd.BN254_FR, 5))
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE.json configs)
+def test_config2_20var_fold_and_sumcheck_properties():
+    """config[1]: 20-var MLE fold + full sumcheck on one GPU.  Too large for the faithful oracle in seconds, so:
+    (a) the fold is checked against the oracle on the full table (one fold is cheap), (b) the sumcheck proof must
+    verify (restated verifier) and its subclaim must equal the product evaluated at the challenges."""
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    n = 20
+    A, B = MLE.random(c, n, 0x5EED0000 + 2, 0), MLE.random(c, n, 0x5EED0000 + 2, 1 << n)
+    tabA = A.evaluation_slice()
+    r = orc.fill_random(field, 4242, 1)
+    assert np.array_equal(A.partial_evaluate(0, r).evaluation_slice(), orc.mle_partial_evaluate(field, n, tabA, 0, r))
+    pp = ProductPoly.new([A, B])
+    s = pp.round_sums(1)
+    claimed = orc.add(field, s[0], s[1])
+    assert np.array_equal(claimed, sum_elems(field, orc.prod_reduce(field, n, [tabA, B.evaluation_slice()])))
+    proof, ch = SumcheckProver(2).prove_partial(pp, claimed)
+    sub = SumcheckVerifier.verify_partial(field, proof)
+    assert np.array_equal(sub.challenges, ch)
+    assert np.array_equal(pp.evaluate(ch), sub.sum)
+
+
+def test_config_24var_fold_properties():
+    """metric config: 2^24-element BN254 table.  Size-independent checks: (a) evaluate(T, [r, rest]) ==
+    evaluate(fold(T, r), rest); (b) linearity of the fold in r on a strided sample vs the oracle's field ops."""
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    n = 24
+    T = MLE.random(c, n, 0x5EED0000 + 24, 0)
+    out = MLE.alloc(c, n - 1)
+    pt = orc.fill_random(field, 31337, n)
+    T.fold_into(pt[0], out)
+    assert np.array_equal(T.evaluate(pt), out.evaluate(pt[1:]))
+    # spot-check 64 output elements against the oracle formula on regenerated inputs
+    half = 1 << (n - 1)
+    got = out.evaluation_slice()
+    for j in [0, 1, 63, 64, 12345, half // 2, half - 1] + [random.Random(1).randrange(half) for _ in range(57)]:
+        lo = orc.fill_random(field, 0x5EED0000 + 24, 1, first_index=j)[0]
+        hi = orc.fill_random(field, 0x5EED0000 + 24, 1, first_index=j + half)[0]
+        want = orc.sub(field, lo, orc.mul(field, pt[0], orc.sub(field, lo, hi)))
+        assert np.array_equal(got[j], want)

@@ -1,0 +1,117 @@
+"""ctypes loader for libzk_amd.so (the gfx950 library behind include/zk_amd.h).
+
+The library is built in-tree by `make -C zk_amd/csrc` (see __graft_entry__.build).  There is no fallback of any
+kind: if the shared object is missing this module raises, and creating a context without a gfx950 device fails
+with ZK_ERR_NO_DEVICE.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzk_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "zk_amd.h")
+
+c = ctypes
+u64p = c.POINTER(c.c_uint64)
+u8p = c.POINTER(c.c_uint8)
+vpp = c.POINTER(c.c_void_p)
+
+
+class ZkError(Exception):
+    """A negative zk_status; str() is the reference's own Err text where one exists (zk_strerror)."""
+
+    def __init__(self, code, text):
+        super().__init__(text)
+        self.code = code
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C zk_amd/csrc` (or __graft_entry__.build()); "
+            "zk_amd has no CPU fallback"
+        )
+    return c.CDLL(LIB_PATH)
+
+
+lib = load()
+lib.zk_strerror.restype = c.c_char_p
+lib.zk_last_hip_error.restype = c.c_char_p
+
+
+def declared_symbols():
+    """Every function name include/zk_amd.h declares (used by the export test)."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", text)))
+
+
+def check(rc):
+    if rc < 0:
+        msg = lib.zk_strerror(rc).decode()
+        if rc == -23:
+            msg += ": " + lib.zk_last_hip_error().decode()
+        raise ZkError(rc, msg)
+    return rc
+
+
+# explicit signatures (everything returns int32 status unless set above)
+_sig = {
+    "zk_device_count": [c.POINTER(c.c_int32)],
+    "zk_ctx_create": [c.c_int32, c.c_int32, vpp],
+    "zk_ctx_destroy": [c.c_void_p],
+    "zk_ctx_synchronize": [c.c_void_p],
+    "zk_ctx_set_stream": [c.c_void_p, c.c_void_p],
+    "zk_ctx_field": [c.c_void_p, c.POINTER(c.c_int32)],
+    "zk_field_modulus": [c.c_int32, u64p],
+    "zk_field_two_adicity": [c.c_int32, c.POINTER(c.c_int32)],
+    "zk_fe_from_u64": [c.c_int32, c.c_uint64, u64p],
+    "zk_fe_from_canonical": [c.c_int32, u64p, u64p],
+    "zk_fe_to_canonical": [c.c_int32, u64p, u64p],
+    "zk_fe_from_be_bytes_mod_order": [c.c_int32, c.c_char_p, c.c_size_t, u64p],
+    "zk_mle_upload": [c.c_void_p, c.c_uint64, u64p, c.c_uint64, vpp],
+    "zk_mle_alloc": [c.c_void_p, c.c_uint64, vpp],
+    "zk_mle_fill_random": [c.c_void_p, c.c_void_p, c.c_uint64, c.c_uint64],
+    "zk_mle_clone": [c.c_void_p, c.c_void_p, vpp],
+    "zk_mle_free": [c.c_void_p, c.c_void_p],
+    "zk_mle_n_vars": [c.c_void_p, u64p],
+    "zk_mle_download": [c.c_void_p, c.c_void_p, u64p],
+    "zk_mle_device_ptr": [c.c_void_p, vpp],
+    "zk_mle_partial_evaluate": [c.c_void_p, c.c_void_p, c.c_uint64, u64p, c.c_uint64, vpp],
+    "zk_mle_fold_into": [c.c_void_p, c.c_void_p, u64p, c.c_void_p],
+    "zk_mle_evaluate": [c.c_void_p, c.c_void_p, u64p, c.c_uint64, u64p],
+    "zk_mle_to_bytes": [c.c_void_p, c.c_void_p, u8p],
+    "zk_mle_partial_evaluate_host": [c.c_void_p, c.c_uint64, u64p, c.c_uint64, c.c_uint64, u64p, c.c_uint64, u64p],
+    "zk_product_check": [vpp, c.c_uint64],
+    "zk_prod_reduce": [c.c_void_p, vpp, c.c_uint64, vpp],
+    "zk_product_evaluate": [c.c_void_p, vpp, c.c_uint64, u64p, c.c_uint64, u64p],
+    "zk_round_sums": [c.c_void_p, vpp, c.c_uint64, c.c_uint32, u64p],
+    "zk_transcript_new": [vpp],
+    "zk_transcript_free": [c.c_void_p],
+    "zk_transcript_append": [c.c_void_p, c.c_char_p, c.c_size_t],
+    "zk_transcript_sample_field_element": [c.c_void_p, c.c_int32, u64p],
+    "zk_transcript_sample_challenge": [c.c_void_p, c.c_char_p],
+    "zk_keccak256": [c.c_char_p, c.c_size_t, c.c_char_p],
+    "zk_sumcheck_prove": [c.c_void_p, vpp, c.c_uint64, c.c_uint32, u64p, c.c_int32, c.c_int32, u64p, u64p],
+    "zk_sumcheck_prove_host": [c.c_void_p, c.POINTER(u64p), c.c_uint64, c.c_uint64, c.c_uint32, u64p, c.c_int32, u64p, u64p],
+    "zk_shard_prover_create": [c.c_void_p, vpp, c.c_uint64, c.c_uint32, u64p, vpp],
+    "zk_shard_prover_destroy": [c.c_void_p],
+    "zk_shard_prover_lanes_ptr": [c.c_void_p, vpp, u64p],
+    "zk_shard_prover_round_begin": [c.c_void_p],
+    "zk_shard_prover_round_finish": [c.c_void_p, u64p, u64p],
+    "zk_shard_prover_remaining": [c.c_void_p, u64p],
+    "zk_sumcheck_verify_partial": [c.c_int32, c.c_uint64, c.c_uint32, u64p, u64p, u64p, u64p],
+    "zk_sumcheck_verify": [c.c_void_p, vpp, c.c_uint64, c.c_uint64, c.c_uint32, u64p, u64p, c.POINTER(c.c_int32)],
+    "zk_ntt": [c.c_void_p, c.c_void_p, c.c_int32, c.c_void_p],
+    "zk_fft_host": [c.c_void_p, u64p, c.c_uint64, u64p],
+    "zk_ifft_host": [c.c_void_p, u64p, c.c_uint64, u64p],
+    "zk_fft_internal_host": [c.c_void_p, u64p, c.c_uint64, u64p, u64p],
+    "zk_bench_fold": [c.c_void_p, c.c_void_p, u64p, c.c_void_p, c.c_int32, c.POINTER(c.c_double)],
+    "zk_bench_modmul": [c.c_void_p, c.c_int32, c.c_int32, c.POINTER(c.c_double)],
+    "zk_bench_copy": [c.c_void_p, c.c_uint64, c.c_int32, c.POINTER(c.c_double)],
+}
+for _name, _args in _sig.items():
+    _f = getattr(lib, _name)
+    _f.argtypes = _args
+    _f.restype = c.c_int32

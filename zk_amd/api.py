@@ -1,0 +1,378 @@
+"""Python mirror of the reference's public API for the hot path, over the C ABI (include/zk_amd.h).
+
+Same names, argument meaning and error behaviour as the reference crates (paths relative to the reference):
+  polynomial::multilinear::evaluation_form::MultiLinearPolynomial   evaluation_form.rs:7-103
+  polynomial::product_poly::ProductPoly                             product_poly.rs:7-88
+  sumcheck::prover::SumcheckProver<MAX_VAR_DEGREE, F>               prover.rs:9-73
+  sumcheck::verifier::SumcheckVerifier<F>                           verifier.rs:9-78
+  transcript::Transcript                                            transcript/src/lib.rs:5-35
+  fft::{fft, ifft, fft_internal}                                    fft/src/lib.rs:4-46
+`Err(&'static str)` becomes ZkError with the same text; misuse the reference panics on becomes ZkError too.
+Field elements are numpy uint64 arrays of shape (..., 4): ark-ff's in-memory layout (Montgomery, 4 LE limbs).
+Everything computes on the GPU; this module is the test/bench harness and the host side of the sharded prover.
+"""
+import numpy as np
+
+from ._lib import ZkError, c, check, lib, u8p, u64p
+
+BN254_FR, BLS12_381_FR, BLS12_377_FR = 0, 1, 2
+FIELD_NAMES = {BN254_FR: "bn254_fr", BLS12_381_FR: "bls12_381_fr", BLS12_377_FR: "bls12_377_fr"}
+
+
+def _p(a):
+    return a.ctypes.data_as(u64p)
+
+
+def _elems(x, n=None):
+    a = np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)
+    if n is not None and a.shape[0] != n:
+        raise ValueError(f"expected {n} field elements, got {a.shape[0]}")
+    return a
+
+
+# ---- host-side element helpers (no GPU needed) ---------------------------------------------------------------
+def modulus(field):
+    out = np.zeros(4, dtype=np.uint64)
+    check(lib.zk_field_modulus(field, _p(out)))
+    return sum(int(v) << (64 * i) for i, v in enumerate(out))
+
+
+def two_adicity(field):
+    s = c.c_int32()
+    check(lib.zk_field_two_adicity(field, c.byref(s)))
+    return s.value
+
+
+def fe_from_int(field, v):
+    """F::from(v) for any Python int (reduced mod p first)."""
+    v %= modulus(field)
+    limbs = np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    out = np.zeros(4, dtype=np.uint64)
+    check(lib.zk_fe_from_canonical(field, _p(limbs), _p(out)))
+    return out
+
+
+def fe_from_ints(field, vs):
+    return np.stack([fe_from_int(field, v) for v in vs]) if len(vs) else np.zeros((0, 4), dtype=np.uint64)
+
+
+def fe_to_int(field, a):
+    a = _elems(a, 1)
+    out = np.zeros(4, dtype=np.uint64)
+    check(lib.zk_fe_to_canonical(field, _p(a), _p(out)))
+    return sum(int(v) << (64 * i) for i, v in enumerate(out))
+
+
+def fe_to_ints(field, arr):
+    arr = _elems(arr)
+    return [fe_to_int(field, arr[i]) for i in range(arr.shape[0])]
+
+
+def keccak256(data: bytes) -> bytes:
+    buf = c.create_string_buffer(32)
+    check(lib.zk_keccak256(bytes(data), len(data), buf))
+    return buf.raw
+
+
+class Transcript:
+    """transcript::Transcript (transcript/src/lib.rs:5-35)."""
+
+    def __init__(self):
+        h = c.c_void_p()
+        check(lib.zk_transcript_new(c.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.zk_transcript_free(self._h)
+            self._h = None
+
+    def append(self, new_data: bytes):
+        check(lib.zk_transcript_append(self._h, bytes(new_data), len(new_data)))
+
+    def sample_challenge(self) -> bytes:
+        buf = c.create_string_buffer(32)
+        check(lib.zk_transcript_sample_challenge(self._h, buf))
+        return buf.raw
+
+    def sample_field_element(self, field):
+        out = np.zeros(4, dtype=np.uint64)
+        check(lib.zk_transcript_sample_field_element(self._h, field, _p(out)))
+        return out
+
+    def sample_n_field_elements(self, field, n):
+        return np.stack([self.sample_field_element(field) for _ in range(n)]) if n else np.zeros((0, 4), np.uint64)
+
+
+# ---- device context ------------------------------------------------------------------------------------------
+class Context:
+    """One device + stream (zk_ctx).  Fails loudly when there is no gfx950 device."""
+
+    def __init__(self, field=BN254_FR, device=0):
+        h = c.c_void_p()
+        check(lib.zk_ctx_create(field, device, c.byref(h)))
+        self._h, self.field, self.device = h, field, device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.zk_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def synchronize(self):
+        check(lib.zk_ctx_synchronize(self._h))
+
+    def set_stream(self, stream_ptr):
+        check(lib.zk_ctx_set_stream(self._h, c.c_void_p(stream_ptr)))
+
+    # measurement hooks
+    def bench_copy(self, nbytes, reps=10):
+        out = c.c_double()
+        check(lib.zk_bench_copy(self._h, nbytes, reps, c.byref(out)))
+        return out.value
+
+    def bench_modmul(self, iters=2000, variant=0):
+        out = c.c_double()
+        check(lib.zk_bench_modmul(self._h, variant, iters, c.byref(out)))
+        return out.value
+
+
+def _handles(polys):
+    arr = (c.c_void_p * max(len(polys), 1))(*[q._h for q in polys])
+    return c.cast(arr, c.POINTER(c.c_void_p)), arr
+
+
+class MultiLinearPolynomial:
+    """Dense MLE table resident in HBM (evaluation_form.rs:7-10)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self._h = ctx, handle
+
+    # MultiLinearPolynomial::new (evaluation_form.rs:15-27)
+    @classmethod
+    def new(cls, ctx, n_vars, evaluations):
+        ev = _elems(evaluations)
+        h = c.c_void_p()
+        check(lib.zk_mle_upload(ctx._h, n_vars, _p(ev), ev.shape[0], c.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def alloc(cls, ctx, n_vars):
+        h = c.c_void_p()
+        check(lib.zk_mle_alloc(ctx._h, n_vars, c.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def random(cls, ctx, n_vars, seed, first_index=0):
+        t = cls.alloc(ctx, n_vars)
+        check(lib.zk_mle_fill_random(ctx._h, t._h, seed, first_index))
+        return t
+
+    def free(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            lib.zk_mle_free(self.ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        self.free()
+
+    def clone(self):
+        h = c.c_void_p()
+        check(lib.zk_mle_clone(self.ctx._h, self._h, c.byref(h)))
+        return MultiLinearPolynomial(self.ctx, h)
+
+    def n_vars(self):
+        n = c.c_uint64()
+        check(lib.zk_mle_n_vars(self._h, c.byref(n)))
+        return n.value
+
+    def device_ptr(self):
+        p = c.c_void_p()
+        check(lib.zk_mle_device_ptr(self._h, c.byref(p)))
+        return p.value
+
+    # partial_evaluate (evaluation_form.rs:40-80)
+    def partial_evaluate(self, initial_var, assignments):
+        a = _elems(assignments)
+        h = c.c_void_p()
+        check(lib.zk_mle_partial_evaluate(self.ctx._h, self._h, initial_var, _p(a), a.shape[0], c.byref(h)))
+        return MultiLinearPolynomial(self.ctx, h)
+
+    def fold_into(self, r, out):
+        r = _elems(r, 1)
+        check(lib.zk_mle_fold_into(self.ctx._h, self._h, _p(r), out._h))
+        return out
+
+    def bench_fold(self, r, out, reps):
+        r = _elems(r, 1)
+        ms = c.c_double()
+        check(lib.zk_bench_fold(self.ctx._h, self._h, _p(r), out._h, reps, c.byref(ms)))
+        return ms.value
+
+    # evaluate (evaluation_form.rs:83-89)
+    def evaluate(self, assignments):
+        a = _elems(assignments)
+        out = np.zeros(4, dtype=np.uint64)
+        check(lib.zk_mle_evaluate(self.ctx._h, self._h, _p(a), a.shape[0], _p(out)))
+        return out
+
+    # evaluation_slice (evaluation_form.rs:92-94)
+    def evaluation_slice(self):
+        out = np.zeros((1 << self.n_vars(), 4), dtype=np.uint64)
+        check(lib.zk_mle_download(self.ctx._h, self._h, _p(out)))
+        return out
+
+    # to_bytes (evaluation_form.rs:97-103)
+    def to_bytes(self):
+        out = np.zeros(32 << self.n_vars(), dtype=np.uint8)
+        check(lib.zk_mle_to_bytes(self.ctx._h, self._h, out.ctypes.data_as(u8p)))
+        return out.tobytes()
+
+    def __eq__(self, other):  # #[derive(PartialEq)] (evaluation_form.rs:4)
+        return (isinstance(other, MultiLinearPolynomial) and self.n_vars() == other.n_vars()
+                and np.array_equal(self.evaluation_slice(), other.evaluation_slice()))
+
+
+class ProductPoly:
+    """P(x) = A(x).B(x).C(x) (product_poly.rs:7-10)."""
+
+    def __init__(self, polynomials):
+        self.polynomials = list(polynomials)
+        self.ctx = self.polynomials[0].ctx
+
+    # ProductPoly::new (product_poly.rs:14-32)
+    @classmethod
+    def new(cls, polynomials):
+        polynomials = list(polynomials)
+        hp, keep = _handles(polynomials)
+        check(lib.zk_product_check(hp, len(polynomials)))
+        return cls(polynomials)
+
+    def n_vars(self):  # product_poly.rs:86
+        return self.polynomials[0].n_vars()
+
+    def evaluate(self, assignments):  # product_poly.rs:36-44
+        a = _elems(assignments)
+        hp, keep = _handles(self.polynomials)
+        out = np.zeros(4, dtype=np.uint64)
+        check(lib.zk_product_evaluate(self.ctx._h, hp, len(self.polynomials), _p(a), a.shape[0], _p(out)))
+        return out
+
+    def partial_evaluate(self, initial_var, assignments):  # product_poly.rs:48-63
+        return ProductPoly([q.partial_evaluate(initial_var, assignments) for q in self.polynomials])
+
+    def prod_reduce(self):  # product_poly.rs:66-74
+        hp, keep = _handles(self.polynomials)
+        h = c.c_void_p()
+        check(lib.zk_prod_reduce(self.ctx._h, hp, len(self.polynomials), c.byref(h)))
+        return MultiLinearPolynomial(self.ctx, h).evaluation_slice()
+
+    def round_sums(self, max_var_degree):  # prover.rs:49-56 for one round
+        hp, keep = _handles(self.polynomials)
+        out = np.zeros((max_var_degree + 1, 4), dtype=np.uint64)
+        check(lib.zk_round_sums(self.ctx._h, hp, len(self.polynomials), max_var_degree, _p(out)))
+        return out
+
+    def to_bytes(self):  # product_poly.rs:77-83
+        return b"".join(q.to_bytes() for q in self.polynomials)
+
+    def clone(self):
+        return ProductPoly([q.clone() for q in self.polynomials])
+
+
+class SumcheckProof:
+    """sumcheck::SumcheckProof (sumcheck/src/lib.rs:8-11)."""
+
+    def __init__(self, sum_, round_polys):
+        self.sum, self.round_polys = sum_, round_polys
+
+
+class SubClaim:
+    """sumcheck::SubClaim (sumcheck/src/lib.rs:17-20)."""
+
+    def __init__(self, sum_, challenges):
+        self.sum, self.challenges = sum_, challenges
+
+
+class SumcheckProver:
+    """SumcheckProver::<MAX_VAR_DEGREE, F> (prover.rs:9-73); MAX_VAR_DEGREE is the constructor argument."""
+
+    def __init__(self, max_var_degree):
+        self.max_var_degree = max_var_degree
+
+    def _run(self, poly, sum_, absorb, consume):
+        D, n, k = self.max_var_degree, poly.n_vars(), len(poly.polynomials)
+        s = _elems(sum_, 1)
+        rp = np.zeros((n, D + 1, 4), dtype=np.uint64)
+        ch = np.zeros((n, 4), dtype=np.uint64)
+        hp, keep = _handles(poly.polynomials)
+        check(lib.zk_sumcheck_prove(poly.ctx._h, hp, k, D, _p(s), int(absorb), int(consume), _p(rp), _p(ch)))
+        return SumcheckProof(s.reshape(4).copy(), rp), ch
+
+    def prove(self, poly, sum_, consume=False):  # prover.rs:15-20
+        return self._run(poly, sum_, True, consume)[0]
+
+    def prove_partial(self, poly, sum_, consume=False):  # prover.rs:24-30
+        return self._run(poly, sum_, False, consume)
+
+
+class SumcheckVerifier:
+    """SumcheckVerifier::<F> (verifier.rs:9-78)."""
+
+    @staticmethod
+    def verify(poly, proof):  # verifier.rs:15-33
+        rp = np.ascontiguousarray(proof.round_polys, dtype=np.uint64)
+        n_rp = rp.shape[0]
+        D = rp.shape[1] - 1 if rp.ndim == 3 and n_rp else 0
+        hp, keep = _handles(poly.polynomials)
+        ok = c.c_int32()
+        s = _elems(proof.sum, 1)
+        check(lib.zk_sumcheck_verify(poly.ctx._h, hp, len(poly.polynomials), n_rp, D, _p(s), _p(rp), c.byref(ok)))
+        return bool(ok.value)
+
+    @staticmethod
+    def verify_partial(field, proof):  # verifier.rs:38-41
+        rp = np.ascontiguousarray(proof.round_polys, dtype=np.uint64)
+        n_rp = rp.shape[0]
+        D = rp.shape[1] - 1 if rp.ndim == 3 and n_rp else 0
+        s = _elems(proof.sum, 1)
+        sub = np.zeros(4, dtype=np.uint64)
+        ch = np.zeros((max(n_rp, 1), 4), dtype=np.uint64)
+        check(lib.zk_sumcheck_verify_partial(field, n_rp, D, _p(s), _p(rp), _p(sub), _p(ch)))
+        return SubClaim(sub, ch[:n_rp])
+
+
+# ---- fft crate (fft/src/lib.rs) ---------------------------------------------------------------------------------
+def _fft_call(fn, ctx, values, *extra):
+    v = _elems(values)
+    out = np.zeros_like(v)
+    check(fn(ctx._h, _p(v), v.shape[0], *extra, _p(out)))
+    return out
+
+
+def fft(ctx, coefficients):  # fft/src/lib.rs:4-8
+    return _fft_call(lib.zk_fft_host, ctx, coefficients)
+
+
+def ifft(ctx, evaluations):  # fft/src/lib.rs:11-19
+    return _fft_call(lib.zk_ifft_host, ctx, evaluations)
+
+
+def fft_internal(ctx, values, omega):  # fft/src/lib.rs:21-46
+    w = _elems(omega, 1)
+    return _fft_call(lib.zk_fft_internal_host, ctx, values, _p(w))
+
+
+def ntt(ctx, vec_in, vec_out, inverse=False):
+    """device-resident form: MultiLinearPolynomial handles double as vectors of 2^n elements."""
+    check(lib.zk_ntt(ctx._h, vec_in._h, int(inverse), vec_out._h))
+    return vec_out
+
+
+__all__ = [
+    "BN254_FR", "BLS12_381_FR", "BLS12_377_FR", "Context", "MultiLinearPolynomial", "ProductPoly", "SumcheckProof",
+    "SubClaim", "SumcheckProver", "SumcheckVerifier", "Transcript", "ZkError", "fft", "ifft", "fft_internal", "ntt",
+    "fe_from_int", "fe_from_ints", "fe_to_int", "fe_to_ints", "keccak256", "modulus", "two_adicity",
+]

@@ -1,0 +1,333 @@
+// field.cuh -- 256-bit prime-field arithmetic for gfx950 (and the host side of the same library).
+//
+// Element = ark-ff 0.5.0 Fp<MontBackend<_,4>> in memory: 4 x u64 LE limbs = 8 x u32 LE limbs, Montgomery form
+// with R = 2^256, always fully reduced (< p).  This is the representation the reference's hot path computes on
+// (polynomial/src/multilinear/evaluation_form.rs:57-70 `left - r*(left-right)`; product_poly.rs:70 `*=`;
+// sumcheck/src/prover.rs:53-54 `.sum::<F>()`), so results are bit-identical limb for limb.
+//
+// The modulus is a RUNTIME parameter (FieldParams, passed by value -> SGPRs): one code object serves BN254 Fr,
+// BLS12-381 Fr and BLS12-377 Fr (the reference is generic over F: PrimeField).
+//
+// Multiplication is product-scanning (Comba) over 32-bit limbs on v_mad_u64_u32: each limb product is ONE
+// quarter-rate multiply-add into a 64-bit column accumulator plus one full-rate v_addc for the column's third
+// word.  The 512-bit product (mul_wide) and the Montgomery reduction (redc) are separate so the sumcheck round
+// kernel can add many unreduced products and reduce once.  No MFMA: these are integer modular ops.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ZK_HD __host__ __device__ __forceinline__
+#define ZK_D __device__ __forceinline__
+#else
+#define ZK_HD inline
+#define ZK_D inline
+#endif
+
+namespace zk {
+
+struct FieldParams {
+    uint32_t p[8];    // modulus
+    uint32_t r1[8];   // R mod p      (Montgomery one)
+    uint32_t r2[8];   // R^2 mod p    (to-Montgomery multiplier)
+    uint32_t inv;     // -p^-1 mod 2^32
+    uint32_t bits;    // bit length of p
+};
+
+struct Fe {
+    uint32_t v[8];
+};
+
+// ---- 96-bit column accumulator: (lo,hi) 64-bit + ex ------------------------------------------------------
+struct Acc {
+    uint64_t lh;
+    uint32_t ex;
+};
+
+// acc += a*b
+ZK_HD void mac(Acc &acc, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM)
+    // one quarter-rate mad whose carry-out feeds the third word directly
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc.lh), "+v"(acc.ex)
+        : "v"(a), "v"(b)
+        : "vcc");
+#else
+    uint64_t s = acc.lh + (uint64_t)a * b;
+    acc.ex += (s < acc.lh) ? 1u : 0u;
+    acc.lh = s;
+#endif
+}
+// acc += a*b with b wave-uniform (modulus limbs, the fold challenge): b stays in an SGPR
+ZK_HD void mac_s(Acc &acc, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM)
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc.lh), "+v"(acc.ex)
+        : "v"(a), "s"(b)
+        : "vcc");
+#else
+    mac(acc, a, b);
+#endif
+}
+// acc += x (32-bit)
+ZK_HD void acc_add32(Acc &acc, uint32_t x) {
+    uint32_t c0, c1;
+    uint32_t lo = __builtin_addc((uint32_t)acc.lh, x, 0u, &c0);
+    uint32_t hi = __builtin_addc((uint32_t)(acc.lh >> 32), 0u, c0, &c1);
+    acc.lh = ((uint64_t)hi << 32) | lo;
+    acc.ex += c1;
+}
+// take the low word, shift the accumulator right by 32
+ZK_HD uint32_t acc_shift(Acc &acc) {
+    uint32_t lo = (uint32_t)acc.lh;
+    acc.lh = (acc.lh >> 32) | ((uint64_t)acc.ex << 32);
+    acc.ex = 0;
+    return lo;
+}
+
+// ---- add / sub -------------------------------------------------------------------------------------------
+// r = a + b (8 limbs), returns carry.  __builtin_addc/__builtin_subc lower to v_add_co/v_addc_co chains.
+ZK_HD uint32_t add8(uint32_t r[8], const uint32_t a[8], const uint32_t b[8]) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t co;
+        r[i] = __builtin_addc(a[i], b[i], c, &co);
+        c = co;
+    }
+    return c;
+}
+// r = a - b (8 limbs), returns borrow (0/1)
+ZK_HD uint32_t sub8(uint32_t r[8], const uint32_t a[8], const uint32_t b[8]) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t co;
+        r[i] = __builtin_subc(a[i], b[i], c, &co);
+        c = co;
+    }
+    return c;
+}
+
+ZK_HD Fe fe_add(const Fe &a, const Fe &b, const FieldParams &P) {
+    Fe s, d, r;
+    uint32_t carry = add8(s.v, a.v, b.v);
+    uint32_t borrow = sub8(d.v, s.v, P.p);
+    bool use_d = carry | (borrow ^ 1u);   // s >= p  (p < 2^255, so carry is only possible in theory)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = use_d ? d.v[i] : s.v[i];
+    return r;
+}
+ZK_HD Fe fe_sub(const Fe &a, const Fe &b, const FieldParams &P) {
+    Fe d, e, r;
+    uint32_t borrow = sub8(d.v, a.v, b.v);
+    add8(e.v, d.v, P.p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = borrow ? e.v[i] : d.v[i];
+    return r;
+}
+ZK_HD Fe fe_neg(const Fe &a, const FieldParams &P) {
+    Fe z = {{0, 0, 0, 0, 0, 0, 0, 0}};
+    return fe_sub(z, a, P);
+}
+ZK_HD bool fe_eq(const Fe &a, const Fe &b) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d |= a.v[i] ^ b.v[i];
+    return d == 0;
+}
+ZK_HD bool fe_is_zero(const Fe &a) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d |= a.v[i];
+    return d == 0;
+}
+ZK_HD Fe fe_zero() {
+    Fe z = {{0, 0, 0, 0, 0, 0, 0, 0}};
+    return z;
+}
+ZK_HD Fe fe_one(const FieldParams &P) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = P.r1[i];
+    return r;
+}
+
+// ---- multiplication -------------------------------------------------------------------------------------
+// t[0..16) = a * b   (full 512-bit product, product scanning)
+ZK_HD void mul_wide(uint32_t t[16], const uint32_t a[8], const uint32_t b[8]) {
+    Acc acc = {0, 0};
+#pragma unroll
+    for (int c = 0; c < 15; ++c) {
+        const int lo = c < 8 ? 0 : c - 7;
+        const int hi = c < 8 ? c : 7;
+#pragma unroll
+        for (int i = lo; i <= hi; ++i) mac(acc, a[i], b[c - i]);
+        t[c] = acc_shift(acc);
+    }
+    t[15] = (uint32_t)acc.lh;
+}
+
+// Montgomery reduction of a 512-bit value t < p*R (+ slack, see `extra`): returns t * R^-1 mod p, fully reduced.
+// `top` is an optional 17th limb of weight 2^512 already folded by the caller (see redc_wide).
+ZK_HD Fe redc(const uint32_t t[16], const FieldParams &P) {
+    uint32_t m[8];
+    Acc acc = {0, 0};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        acc_add32(acc, t[c]);
+#pragma unroll
+        for (int i = 0; i < c; ++i) mac_s(acc, m[i], P.p[c - i]);
+        m[c] = (uint32_t)acc.lh * P.inv;
+        mac_s(acc, m[c], P.p[0]);
+        (void)acc_shift(acc);   // low word is zero by construction
+    }
+    Fe s;
+#pragma unroll
+    for (int c = 8; c < 16; ++c) {
+        acc_add32(acc, t[c]);
+#pragma unroll
+        for (int i = c - 7; i < 8; ++i) mac_s(acc, m[i], P.p[c - i]);
+        s.v[c - 8] = acc_shift(acc);
+    }
+    // result = s + carry*2^256 < 2p when t < p*R
+    uint32_t carry = (uint32_t)acc.lh;
+    Fe d, r;
+    uint32_t borrow = sub8(d.v, s.v, P.p);
+    bool use_d = carry | (borrow ^ 1u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = use_d ? d.v[i] : s.v[i];
+    return r;
+}
+
+ZK_HD Fe fe_mul(const Fe &a, const Fe &b, const FieldParams &P) {
+    uint32_t t[16];
+    mul_wide(t, a.v, b.v);
+    return redc(t, P);
+}
+ZK_HD Fe fe_sqr(const Fe &a, const FieldParams &P) { return fe_mul(a, a, P); }
+
+// ---- conversions ----------------------------------------------------------------------------------------
+ZK_HD Fe fe_from_canonical(const Fe &x, const FieldParams &P) {   // x < p as plain integer -> Montgomery
+    Fe r2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r2.v[i] = P.r2[i];
+    return fe_mul(x, r2, P);
+}
+ZK_HD Fe fe_to_canonical(const Fe &a, const FieldParams &P) {     // Montgomery -> plain integer (into_bigint)
+    uint32_t t[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        t[i] = a.v[i];
+        t[i + 8] = 0;
+    }
+    return redc(t, P);
+}
+ZK_HD Fe fe_from_u32(uint32_t x, const FieldParams &P) {          // F::from(x)
+    Fe v = {{x, 0, 0, 0, 0, 0, 0, 0}};
+    return fe_from_canonical(v, P);
+}
+
+// ---- wide accumulation for the sumcheck round sums -------------------------------------------------------
+// Sum of up to ~2^32 512-bit products in 17 limbs; reduced once with redc_wide.
+struct WideAcc {
+    uint32_t v[17];
+};
+ZK_HD void wide_zero(WideAcc &w) {
+#pragma unroll
+    for (int i = 0; i < 17; ++i) w.v[i] = 0;
+}
+// w += a*b  (unreduced; product scanning straight into the running sum)
+ZK_HD void wide_mac(WideAcc &w, const uint32_t a[8], const uint32_t b[8]) {
+    Acc acc = {0, 0};
+#pragma unroll
+    for (int c = 0; c < 15; ++c) {
+        const int lo = c < 8 ? 0 : c - 7;
+        const int hi = c < 8 ? c : 7;
+        acc_add32(acc, w.v[c]);
+#pragma unroll
+        for (int i = lo; i <= hi; ++i) mac(acc, a[i], b[c - i]);
+        w.v[c] = acc_shift(acc);
+    }
+    acc_add32(acc, w.v[15]);
+    w.v[15] = acc_shift(acc);
+    w.v[16] += (uint32_t)acc.lh;
+}
+// w * R^-1 mod p, fully reduced, for any w < 2^544 with a small top limb (w.v[16] <= 7: at most ~16 products of
+// values < p < 2^255).  redc of the low 512 bits gives s < 2^256 + p; the top limb contributes top * R mod p.
+// The 9-limb sum is < R + p + top*p (< 32p for every supported field while top <= 16) and is brought below p by
+// conditional subtraction of 16p, 8p, 4p, 2p, p.
+ZK_HD Fe redc_wide(const WideAcc &w, const FieldParams &P) {
+    uint32_t m[8];
+    Acc acc = {0, 0};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        acc_add32(acc, w.v[c]);
+#pragma unroll
+        for (int i = 0; i < c; ++i) mac_s(acc, m[i], P.p[c - i]);
+        m[c] = (uint32_t)acc.lh * P.inv;
+        mac_s(acc, m[c], P.p[0]);
+        (void)acc_shift(acc);
+    }
+    uint32_t s[9];
+#pragma unroll
+    for (int c = 8; c < 16; ++c) {
+        acc_add32(acc, w.v[c]);
+#pragma unroll
+        for (int i = c - 7; i < 8; ++i) mac_s(acc, m[i], P.p[c - i]);
+        s[c - 8] = acc_shift(acc);
+    }
+    s[8] = (uint32_t)acc.lh;
+    // s += top * (R mod p)
+    {
+        uint64_t c = 0;
+        const uint32_t top = w.v[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            c += (uint64_t)top * P.r1[i] + s[i];
+            s[i] = (uint32_t)c;
+            c >>= 32;
+        }
+        s[8] += (uint32_t)c;
+    }
+    // conditional subtraction of (p << k), k = 4..0  (9-limb; covers s < 32p)
+#pragma unroll
+    for (int k = 4; k >= 0; --k) {
+        uint32_t d[9];
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            uint32_t pk;
+            if (k == 0) pk = (i < 8) ? P.p[i] : 0u;
+            else pk = ((i < 8) ? (P.p[i] << k) : 0u) | ((i > 0) ? (P.p[i - 1] >> (32 - k)) : 0u);
+            uint64_t dd = (uint64_t)s[i] - pk - borrow;
+            d[i] = (uint32_t)dd;
+            borrow = (uint32_t)(dd >> 63);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s[i] = borrow ? s[i] : d[i];
+    }
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = s[i];
+    return r;
+}
+
+// ---- 32-byte element I/O (two 16-byte accesses: global_load_dwordx4 / global_store_dwordx4) ---------------
+#if defined(__HIPCC__)
+ZK_D Fe fe_load(const uint64_t *base, uint64_t idx) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(base + 4 * idx);
+    uint4 a = q[0], b = q[1];
+    Fe r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+    return r;
+}
+ZK_D void fe_store(uint64_t *base, uint64_t idx, const Fe &r) {
+    uint4 *q = reinterpret_cast<uint4 *>(base + 4 * idx);
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+#endif
+
+}  // namespace zk

@@ -1,0 +1,138 @@
+// keccak.hpp -- Keccak-256 sponge + the reference's Fiat-Shamir transcript (product code; host and device).
+//
+// transcript/src/lib.rs uses sha3 0.10.8 `Keccak256`: Keccak-f[1600], rate 136 bytes, original Keccak padding
+// (domain byte 0x01 ... 0x80) -- not NIST SHA3-256.  `Sponge` is usable from host code and from a single GPU
+// lane (the on-device transcript keeps the prover's round loop free of host round trips).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ZKK_HD __host__ __device__
+#else
+#define ZKK_HD
+#endif
+
+namespace zk {
+
+ZKK_HD inline uint64_t keccak_rotl(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+
+ZKK_HD inline void keccak_f1600(uint64_t a[25]) {
+    const uint64_t RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    for (int round = 0; round < 24; ++round) {
+        // theta
+        uint64_t c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20];
+        uint64_t c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];
+        uint64_t c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22];
+        uint64_t c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
+        uint64_t c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
+        uint64_t d0 = c4 ^ keccak_rotl(c1, 1), d1 = c0 ^ keccak_rotl(c2, 1), d2 = c1 ^ keccak_rotl(c3, 1);
+        uint64_t d3 = c2 ^ keccak_rotl(c4, 1), d4 = c3 ^ keccak_rotl(c0, 1);
+        for (int y = 0; y < 25; y += 5) {
+            a[y] ^= d0;
+            a[y + 1] ^= d1;
+            a[y + 2] ^= d2;
+            a[y + 3] ^= d3;
+            a[y + 4] ^= d4;
+        }
+        // rho + pi (in-place lane walk)
+        uint64_t cur = a[1], nxt;
+        nxt = a[10]; a[10] = keccak_rotl(cur, 1);  cur = nxt;
+        nxt = a[7];  a[7]  = keccak_rotl(cur, 3);  cur = nxt;
+        nxt = a[11]; a[11] = keccak_rotl(cur, 6);  cur = nxt;
+        nxt = a[17]; a[17] = keccak_rotl(cur, 10); cur = nxt;
+        nxt = a[18]; a[18] = keccak_rotl(cur, 15); cur = nxt;
+        nxt = a[3];  a[3]  = keccak_rotl(cur, 21); cur = nxt;
+        nxt = a[5];  a[5]  = keccak_rotl(cur, 28); cur = nxt;
+        nxt = a[16]; a[16] = keccak_rotl(cur, 36); cur = nxt;
+        nxt = a[8];  a[8]  = keccak_rotl(cur, 45); cur = nxt;
+        nxt = a[21]; a[21] = keccak_rotl(cur, 55); cur = nxt;
+        nxt = a[24]; a[24] = keccak_rotl(cur, 2);  cur = nxt;
+        nxt = a[4];  a[4]  = keccak_rotl(cur, 14); cur = nxt;
+        nxt = a[15]; a[15] = keccak_rotl(cur, 27); cur = nxt;
+        nxt = a[23]; a[23] = keccak_rotl(cur, 41); cur = nxt;
+        nxt = a[19]; a[19] = keccak_rotl(cur, 56); cur = nxt;
+        nxt = a[13]; a[13] = keccak_rotl(cur, 8);  cur = nxt;
+        nxt = a[12]; a[12] = keccak_rotl(cur, 25); cur = nxt;
+        nxt = a[2];  a[2]  = keccak_rotl(cur, 43); cur = nxt;
+        nxt = a[20]; a[20] = keccak_rotl(cur, 62); cur = nxt;
+        nxt = a[14]; a[14] = keccak_rotl(cur, 18); cur = nxt;
+        nxt = a[22]; a[22] = keccak_rotl(cur, 39); cur = nxt;
+        nxt = a[9];  a[9]  = keccak_rotl(cur, 61); cur = nxt;
+        nxt = a[6];  a[6]  = keccak_rotl(cur, 20); cur = nxt;
+        a[1] = keccak_rotl(cur, 44);
+        // chi
+        for (int y = 0; y < 25; y += 5) {
+            uint64_t b0 = a[y], b1 = a[y + 1], b2 = a[y + 2], b3 = a[y + 3], b4 = a[y + 4];
+            a[y] = b0 ^ (~b1 & b2);
+            a[y + 1] = b1 ^ (~b2 & b3);
+            a[y + 2] = b2 ^ (~b3 & b4);
+            a[y + 3] = b3 ^ (~b4 & b0);
+            a[y + 4] = b4 ^ (~b0 & b1);
+        }
+        a[0] ^= RC[round];
+    }
+}
+
+// Incremental sponge with sha3::Keccak256 semantics (update / finalize_reset).
+struct Sponge {
+    uint64_t s[25];
+    uint8_t buf[136];
+    uint32_t fill;
+
+    ZKK_HD void init() {
+        for (int i = 0; i < 25; ++i) s[i] = 0;
+        fill = 0;
+    }
+    ZKK_HD void absorb_block(const uint8_t *blk) {
+        for (int i = 0; i < 17; ++i) {
+            uint64_t w = 0;
+            for (int b = 0; b < 8; ++b) w |= (uint64_t)blk[8 * i + b] << (8 * b);
+            s[i] ^= w;
+        }
+        keccak_f1600(s);
+    }
+    ZKK_HD void update(const uint8_t *data, size_t len) {
+        while (len) {
+            if (fill == 0 && len >= 136) {   // whole blocks straight from the input
+                absorb_block(data);
+                data += 136;
+                len -= 136;
+                continue;
+            }
+            size_t take = 136 - fill;
+            if (take > len) take = len;
+            for (size_t i = 0; i < take; ++i) buf[fill + i] = data[i];
+            fill += (uint32_t)take;
+            data += take;
+            len -= take;
+            if (fill == 136) {
+                absorb_block(buf);
+                fill = 0;
+            }
+        }
+    }
+    ZKK_HD void finalize_reset(uint8_t out[32]) {
+        for (uint32_t i = fill; i < 136; ++i) buf[i] = 0;
+        buf[fill] ^= 0x01;
+        buf[135] ^= 0x80;
+        absorb_block(buf);
+        for (int i = 0; i < 4; ++i)
+            for (int b = 0; b < 8; ++b) out[8 * i + b] = (uint8_t)(s[i] >> (8 * b));
+        init();
+    }
+    // transcript/src/lib.rs:20-25 sample_challenge: h = finalize_reset(); update(h); return h
+    ZKK_HD void sample_challenge(uint8_t out[32]) {
+        finalize_reset(out);
+        update(out, 32);
+    }
+};
+
+}  // namespace zk

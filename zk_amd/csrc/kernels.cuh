@@ -1,0 +1,329 @@
+// kernels.cuh -- gfx950 kernels for the MLE fold / sumcheck round / serialisation path.
+//
+// Data layout in HBM: a table is a dense array of 2^m elements, 32 B each (8 x u32, Montgomery), index bit
+// (m-1-v) <-> variable v, i.e. variable 0 is the index MSB (polynomial/src/multilinear/pairing_index.rs:61-65).
+// The sumcheck fold always consumes variable 0, so a round touches the two contiguous half-streams
+// [0, half) and [half, 2*half): every lane reads whole 32-B elements, a wave reads 2 KiB contiguous runs.
+//
+// All kernels are grid-stride with 256-thread workgroups (4 waves); grids are sized >> 256 CUs by the host.
+// These are HBM-streaming integer kernels: no LDS tiling is needed for the fold itself (no reuse), LDS is used
+// for the workgroup reductions of the round sums.  No MFMA (256-bit modular integer ops).
+#pragma once
+#include "field.cuh"
+#include "keccak.hpp"
+
+namespace zk {
+
+constexpr int kBlock = 256;
+constexpr int kMaxFactors = 8;
+constexpr int kMaxLazy = 16;   // products accumulated unreduced between Montgomery reductions (see redc_wide)
+
+struct FactorPtrs {
+    const uint64_t *in[kMaxFactors];
+    uint64_t *out[kMaxFactors];
+};
+
+// pairing_index.rs:16-20 insert_bit(val, index, 0)
+ZK_D uint64_t insert_zero_bit(uint64_t val, uint32_t pos) {
+    const uint64_t low = val & ((1ull << pos) - 1ull);
+    return ((val >> pos) << (pos + 1)) | low;
+}
+
+// ---- MultiLinearPolynomial::partial_evaluate, one assignment (evaluation_form.rs:55-70) ----------------------
+// out[j] = left - r*(left - right), (left,right) = index_pair(m, initial_var)[j], pos = m-1-initial_var.
+// The reference's r==0 / r==1 shortcuts (:61-62) are the same values, so they are not special-cased.
+// Out of place (in != out) for general pos; in place is race-free only for the MSB fold (pos = m-1).
+__global__ __launch_bounds__(kBlock) void k_fold(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                 uint64_t pairs, uint32_t pos, FieldParams P, Fe r) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < pairs; j += stride) {
+        const uint64_t l = insert_zero_bit(j, pos);
+        const Fe lo = fe_load(in, l);
+        const Fe hi = fe_load(in, l | (1ull << pos));
+        const Fe d = fe_sub(lo, hi, P);
+        fe_store(out, j, fe_sub(lo, fe_mul(r, d, P), P));
+    }
+}
+
+// ---- ProductPoly::prod_reduce (product_poly.rs:66-74) --------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_prod_reduce(FactorPtrs fp, int k, uint64_t n, uint64_t *__restrict__ out,
+                                                        FieldParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        Fe acc = fe_load(fp.in[0], j);
+        for (int f = 1; f < k; ++f) acc = fe_mul(acc, fe_load(fp.in[f], j), P);
+        fe_store(out, j, acc);
+    }
+}
+
+// ---- workgroup reduction of NS field elements per thread -> partials[block][NS] -------------------------------
+template <int NS>
+ZK_D void block_reduce_store(Fe (&sum)[NS], uint64_t *__restrict__ partials, const FieldParams &P) {
+    __shared__ uint32_t red[kBlock / 64][NS][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            Fe o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] = __shfl_xor(sum[t].v[i], off, 64);
+            sum[t] = fe_add(sum[t], o, P);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[wave][t][i] = sum[t].v[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        const int t = threadIdx.x;
+        Fe acc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc.v[i] = red[0][t][i];
+        for (int w = 1; w < kBlock / 64; ++w) {
+            Fe o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] = red[w][t][i];
+            acc = fe_add(acc, o, P);
+        }
+        fe_store(partials, (uint64_t)blockIdx.x * NS + t, acc);
+    }
+}
+
+// ---- one sumcheck round (sumcheck/src/prover.rs:44-68), fused ---------------------------------------------------
+// Computes the round polynomial in evaluation form, S_t = sum_x prod_f P_f(t, x) for t = 0..D, over the table pairs
+// (lo, hi) = (T[j], T[j+q]).  With FUSED the pairs are first produced by folding the PREVIOUS round's table at its
+// challenge r (prover.rs:64: T'[j] = T[j] - r*(T[j] - T[j+2q])), written back for the next round and used from
+// registers -- one pass over HBM per round instead of the reference's (D+2)*k folds + (D+1) prod_reduce + sums.
+//   P_f(t, x) = lo + t*(hi - lo)  ==  left - F::from(t)*(left - right)   (evaluation_form.rs:68; exact in F_p)
+// For k >= 2 the last factor's products are accumulated UNREDUCED (512+ bits) and Montgomery-reduced once per
+// kMaxLazy pairs; sums of Montgomery products are exact, so the reduced result is the same canonical element.
+// In-place (out == in) is race-free: index j and j+q are read and written only by the thread that owns j.
+template <int D, bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_round(FactorPtrs fp, int k, uint64_t q, FieldParams P, Fe r,
+                                                  uint64_t *__restrict__ partials) {
+    constexpr int NS = D + 1;
+    Fe sum[NS];
+    WideAcc acc[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        sum[t] = fe_zero();
+        wide_zero(acc[t]);
+    }
+    int lazy = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < q; j += stride) {
+        Fe prod[NS];
+        for (int f = 0; f < k; ++f) {
+            Fe lo, hi;
+            if (FUSED) {
+                const Fe a0 = fe_load(fp.in[f], j), a1 = fe_load(fp.in[f], j + q);
+                const Fe a2 = fe_load(fp.in[f], j + 2 * q), a3 = fe_load(fp.in[f], j + 3 * q);
+                lo = fe_sub(a0, fe_mul(r, fe_sub(a0, a2, P), P), P);
+                hi = fe_sub(a1, fe_mul(r, fe_sub(a1, a3, P), P), P);
+                fe_store(fp.out[f], j, lo);
+                fe_store(fp.out[f], j + q, hi);
+            } else {
+                lo = fe_load(fp.in[f], j);
+                hi = fe_load(fp.in[f], j + q);
+            }
+            const Fe diff = fe_sub(hi, lo, P);
+            Fe v = lo;
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                if (t == 1) v = hi;
+                else if (t > 1) v = fe_add(v, diff, P);
+                if (k == 1) sum[t] = fe_add(sum[t], v, P);
+                else if (f == 0) prod[t] = v;
+                else if (f < k - 1) prod[t] = fe_mul(prod[t], v, P);
+                else wide_mac(acc[t], prod[t].v, v.v);
+            }
+        }
+        if (k > 1 && ++lazy == kMaxLazy) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                sum[t] = fe_add(sum[t], redc_wide(acc[t], P), P);
+                wide_zero(acc[t]);
+            }
+            lazy = 0;
+        }
+    }
+    if (k > 1 && lazy) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) sum[t] = fe_add(sum[t], redc_wide(acc[t], P), P);
+    }
+    block_reduce_store<NS>(sum, partials, P);
+}
+
+// Generic-degree fallback: one evaluation point t per launch (any D up to 255, any k <= kMaxFactors).
+__global__ __launch_bounds__(kBlock) void k_round_single_t(FactorPtrs fp, int k, uint64_t q, FieldParams P, Fe tval,
+                                                           uint64_t *__restrict__ partials) {
+    Fe sum[1] = {fe_zero()};
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < q; j += stride) {
+        Fe prod = fe_zero();
+        for (int f = 0; f < k; ++f) {
+            const Fe lo = fe_load(fp.in[f], j), hi = fe_load(fp.in[f], j + q);
+            const Fe v = fe_sub(lo, fe_mul(tval, fe_sub(lo, hi, P), P), P);
+            prod = (f == 0) ? v : fe_mul(prod, v, P);
+        }
+        sum[0] = fe_add(sum[0], prod, P);
+    }
+    block_reduce_store<1>(sum, partials, P);
+}
+
+// Second stage of the round sums: one workgroup adds the per-block partials -> out[t], t < ns (Montgomery form).
+__global__ __launch_bounds__(kBlock) void k_final_sums(const uint64_t *__restrict__ partials, uint32_t nblocks,
+                                                       uint32_t ns, uint64_t *__restrict__ out, FieldParams P) {
+    __shared__ uint32_t red[kBlock / 64][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t t = 0; t < ns; ++t) {
+        Fe s = fe_zero();
+        for (uint32_t b = threadIdx.x; b < nblocks; b += kBlock) s = fe_add(s, fe_load(partials, (uint64_t)b * ns + t), P);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            Fe o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] = __shfl_xor(s.v[i], off, 64);
+            s = fe_add(s, o, P);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[wave][i] = s.v[i];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Fe acc;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc.v[i] = red[0][i];
+            for (int w = 1; w < kBlock / 64; ++w) {
+                Fe o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o.v[i] = red[w][i];
+                acc = fe_add(acc, o, P);
+            }
+            fe_store(out, t, acc);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- MultiLinearPolynomial::to_bytes (evaluation_form.rs:97-103): 32-byte big-endian canonical integers ----------
+__global__ __launch_bounds__(kBlock) void k_to_bytes(const uint64_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                     uint64_t n, FieldParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        const Fe c = fe_to_canonical(fe_load(in, j), P);
+        uint4 *o = reinterpret_cast<uint4 *>(out + 32 * j);
+        o[0] = make_uint4(__builtin_bswap32(c.v[7]), __builtin_bswap32(c.v[6]), __builtin_bswap32(c.v[5]),
+                          __builtin_bswap32(c.v[4]));
+        o[1] = make_uint4(__builtin_bswap32(c.v[3]), __builtin_bswap32(c.v[2]), __builtin_bswap32(c.v[1]),
+                          __builtin_bswap32(c.v[0]));
+    }
+}
+
+// ---- synthetic inputs: element i = first hash(seed, i, attempt) < p, stored in Montgomery form --------
+ZK_D uint64_t splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(kBlock) void k_fill_random(uint64_t *__restrict__ out, uint64_t n, uint64_t seed,
+                                                        uint64_t first, FieldParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint32_t topbits = P.bits & 31u;
+    const uint32_t topmask = topbits ? ((1u << topbits) - 1u) : 0xffffffffu;
+    const int toplimb = (int)((P.bits + 31u) / 32u) - 1;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        const uint64_t h0 = splitmix64(seed ^ splitmix64(first + j));
+        Fe c;
+        for (uint64_t attempt = 0;; ++attempt) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint64_t x = splitmix64(h0 + 4 * attempt + (uint64_t)w);
+                c.v[2 * w] = (uint32_t)x;
+                c.v[2 * w + 1] = (uint32_t)(x >> 32);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i == toplimb) c.v[i] &= topmask;
+                else if (i > toplimb) c.v[i] = 0;
+            }
+            Fe d;
+            if (sub8(d.v, c.v, P.p)) break;   // borrow => c < p
+        }
+        fe_store(out, j, fe_from_canonical(c, P));
+    }
+}
+
+// ---- fft crate, first form: bit-reversal + one radix-2 DIT stage per launch (fft/src/lib.rs:21-46 computes the
+// same DFT recursively).  tw[i] = omega^i, i < n/2.
+__global__ __launch_bounds__(kBlock) void k_bitrev_copy(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                        uint32_t log_n) {
+    const uint64_t n = 1ull << log_n, stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        const uint64_t rj = log_n ? (__brevll(j) >> (64 - log_n)) : 0;
+        fe_store(out, rj, fe_load(in, j));
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_ntt_stage(uint64_t *__restrict__ data, const uint64_t *__restrict__ tw,
+                                                      uint32_t log_n, uint32_t s, FieldParams P) {
+    const uint64_t half = 1ull << (log_n - 1), stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t h = 1ull << s;   // butterflies span h within blocks of 2h
+    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < half; b += stride) {
+        const uint64_t j = b & (h - 1), base = (b >> s) << (s + 1);
+        const Fe w = fe_load(tw, j << (log_n - 1 - s));
+        const Fe u = fe_load(data, base + j);
+        const Fe t = fe_mul(w, fe_load(data, base + j + h), P);
+        fe_store(data, base + j, fe_add(u, t, P));
+        fe_store(data, base + j + h, fe_sub(u, t, P));
+    }
+}
+// tw[i] = omega^i for i < count: chunked -- each thread starts from omega^(first) via square-and-multiply
+__global__ __launch_bounds__(kBlock) void k_twiddle_table(uint64_t *__restrict__ tw, uint64_t count, Fe omega,
+                                                          FieldParams P) {
+    constexpr uint64_t kChunk = 64;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t chunks = (count + kChunk - 1) / kChunk;
+    for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < chunks; c += stride) {
+        uint64_t e = c * kChunk;
+        Fe acc = fe_one(P), base = omega;
+        while (e) {
+            if (e & 1) acc = fe_mul(acc, base, P);
+            base = fe_sqr(base, P);
+            e >>= 1;
+        }
+        const uint64_t end = (c * kChunk + kChunk < count) ? c * kChunk + kChunk : count;
+        for (uint64_t i = c * kChunk; i < end; ++i) {
+            fe_store(tw, i, acc);
+            acc = fe_mul(acc, omega, P);
+        }
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_scale(uint64_t *__restrict__ data, uint64_t n, Fe s, FieldParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride)
+        fe_store(data, j, fe_mul(fe_load(data, j), s, P));
+}
+
+// ---- measurement kernels -----------------------------------------------------------------------------------------
+// dependent fe_mul chain entirely in registers: 2 independent chains per thread
+__global__ __launch_bounds__(kBlock) void k_bench_modmul(uint64_t *__restrict__ out, int iters, FieldParams P, Fe seed) {
+    Fe a = seed, b = seed;
+    a.v[0] ^= threadIdx.x;
+    b.v[1] ^= blockIdx.x;
+    a = fe_from_canonical(fe_to_canonical(a, P), P);
+    for (int i = 0; i < iters; ++i) {
+        a = fe_mul(a, b, P);
+        b = fe_mul(b, a, P);
+    }
+    if (a.v[0] == 0x12345678u && b.v[3] == 0x9abcdef0u) fe_store(out, 0, a);   // keep the chain live
+}
+__global__ __launch_bounds__(kBlock) void k_bench_copy(const uint4 *__restrict__ in, uint4 *__restrict__ out, uint64_t n16) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n16; j += stride) out[j] = in[j];
+}
+
+}  // namespace zk
