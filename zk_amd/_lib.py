@@ -27,6 +27,15 @@ class ZkError(Exception):
 
 
 def load():
+    # ONE HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64/libhsa-runtime64, and a process
+    # that maps both that copy and /opt/rocm's loses the GPU in whichever initialises second (observed on the
+    # MI355X box: torch.cuda.is_available() -> False after libzk_amd had initialised ROCm's copy, and vice versa).
+    # Importing torch first makes the dynamic linker resolve libzk_amd.so's NEEDED libamdhip64.so.7 to the copy that
+    # is already mapped.  Hosts without torch (the C/C++/Rust side) simply get /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C zk_amd/csrc` (or __graft_entry__.build()); "
