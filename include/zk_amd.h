@@ -71,8 +71,10 @@ int32_t zk_device_count(int32_t *out_count);
 int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out_ctx);
 int32_t zk_ctx_destroy(zk_ctx *ctx);
 int32_t zk_ctx_synchronize(zk_ctx *ctx);
-/* run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own; NULL restores it */
+/* run on a caller-owned hipStream_t (e.g. torch's current stream; NULL = the legacy default stream) instead of the
+ * context's own non-blocking stream; zk_ctx_use_own_stream switches back.  Both synchronise the stream being left. */
 int32_t zk_ctx_set_stream(zk_ctx *ctx, void *hip_stream);
+int32_t zk_ctx_use_own_stream(zk_ctx *ctx);
 int32_t zk_ctx_field(const zk_ctx *ctx, int32_t *out_field);
 /* modulus as 4 LE limbs; two-adicity s of p-1 */
 int32_t zk_field_modulus(int32_t field, uint64_t out_p[4]);
@@ -144,22 +146,36 @@ int32_t zk_sumcheck_prove_host(zk_ctx *ctx, const uint64_t *const *tables, uint6
                                uint32_t max_var_degree, const uint64_t sum[4], int32_t absorb_table,
                                uint64_t *out_round_polys, uint64_t *out_challenges);
 
-/* Stepwise form of the same loop for a table sharded across devices: every rank holds the shard
- * {idx : idx mod world == rank} as an (n_vars - log2 world)-variable table and calls these in lockstep; the
- * caller sums `out_limbs` across ranks between the two calls (one all-reduce of (D+1)*16 uint64 lanes).
- *   begin : local round sums as lazily reduced lanes: per element 16 lanes, lane i holds a 16-bit digit-sum
- *           (radix 2^16) so that up to 2^47 ranks can be added lane-wise without overflow.  Device buffer.
- *   finish: carry-propagate + reduce the summed lanes mod p, absorb, squeeze the challenge, fold every factor.
- * zk_sumcheck_shard_begin folds with the previous challenge first when round > 0 (fused kernel). */
+/* Stepwise form of the same loop for a table sharded across devices.  Rank g of `world` (a power of
+ * two) holds the shard {idx : idx mod world == g} as an (n - log2 world)-variable table with local index idx / world,
+ * so every pair (j, j + 2^(m-1)) of the first n - log2 world rounds is local.  Every rank calls these in lockstep on
+ * its own context; everything is asynchronous on the context's stream (use zk_ctx_set_stream to share the stream the
+ * collective runs on):
+ *   round_begin : (fold at the previous challenge +) local round sums -> digit lanes: per element 8 uint64 lanes, lane i
+ *                 = 32-bit digit i of the Montgomery representative, zero-extended.  The caller all-reduces (sum) the
+ *                 (D+1)*8 lanes across ranks -- the ONE collective of the round; integer lane sums of <= 2^16 ranks
+ *                 cannot overflow and carry exactly the field sum (RCCL has no mod-p reduction).
+ *   round_finish: carry-propagate + reduce the summed lanes mod p, absorb the round polynomial, squeeze the challenge
+ *                 (identical on every rank: same transcript, same bytes).
+ * After the local rounds: tail_ptr gives this rank's k fully folded elements; the caller all-gathers them rank-major
+ * into [world][k] and tail_rounds finishes the last log2 world rounds on every rank (world-element tables).
+ * results downloads the proof (total_rounds = n rounds).  `sum` is the GLOBAL claimed sum (prover.rs:42). */
 typedef struct zk_shard_prover zk_shard_prover;
 int32_t zk_shard_prover_create(zk_ctx *ctx, zk_mle *const *factors, uint64_t k, uint32_t max_var_degree,
-                               const uint64_t sum[4], zk_shard_prover **out);
+                               const uint64_t sum[4], uint32_t world, zk_shard_prover **out);
 int32_t zk_shard_prover_destroy(zk_shard_prover *sp);
+int32_t zk_shard_prover_rounds(zk_shard_prover *sp, uint64_t *out_local, uint64_t *out_total, uint64_t *out_done);
 int32_t zk_shard_prover_lanes_ptr(zk_shard_prover *sp, void **out_device_ptr, uint64_t *out_n_lanes);
 int32_t zk_shard_prover_round_begin(zk_shard_prover *sp);
-int32_t zk_shard_prover_round_finish(zk_shard_prover *sp, uint64_t *out_round_poly, uint64_t out_challenge[4]);
-/* after the local rounds: the (single-element) folded factors, for the cross-rank tail */
-int32_t zk_shard_prover_remaining(zk_shard_prover *sp, uint64_t *out_n_vars_left);
+int32_t zk_shard_prover_round_finish(zk_shard_prover *sp);
+int32_t zk_shard_prover_tail_ptr(zk_shard_prover *sp, void **out_device_ptr, uint64_t *out_n_elems);
+int32_t zk_shard_prover_tail_rounds(zk_shard_prover *sp, const void *gathered_device /* [world][k] elements */);
+int32_t zk_shard_prover_results(zk_shard_prover *sp, uint64_t *out_round_polys, uint64_t *out_challenges);
+/* raw device buffers on the context (pooled) and synchronous copies: for hosts that drive the exchange themselves */
+int32_t zk_ctx_device_alloc(zk_ctx *ctx, uint64_t bytes, void **out_device_ptr);
+int32_t zk_ctx_device_free(zk_ctx *ctx, void *device_ptr, uint64_t bytes);
+int32_t zk_ctx_memcpy_dtoh(zk_ctx *ctx, void *dst_host, const void *src_device, uint64_t bytes);
+int32_t zk_ctx_memcpy_htod(zk_ctx *ctx, void *dst_device, const void *src_host, uint64_t bytes);
 
 /* ---- SumcheckVerifier  (sumcheck/src/verifier.rs) -- host-side protocol logic; oracle check on device ------------ */
 /* ::verify_partial :38-41 -> SubClaim{sum, challenges} */

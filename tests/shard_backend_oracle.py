@@ -1,0 +1,81 @@
+"""A CPU stand-in for GpuShardBackend built on the ORACLE (test infrastructure): lets the sharded prover's host
+orchestration (zk_amd/distributed.py) run under gloo on machines without a GPU.  Same interface, same lane encoding."""
+import numpy as np
+import torch
+
+from oracle import binding as orc
+
+
+class OracleShardBackend:
+    def __init__(self, field, shard_tables, max_var_degree, claimed_sum, world):
+        self.field, self.D, self.world = field, max_var_degree, world
+        self.cur = [np.ascontiguousarray(t, dtype=np.uint64).reshape(-1, 4) for t in shard_tables]
+        self.k = len(self.cur)
+        self.vars_left = int(np.log2(self.cur[0].shape[0]))
+        self.local_rounds = self.vars_left
+        self.total_rounds = self.local_rounds + int(np.log2(world))
+        self.tr = orc.Transcript()
+        self.tr.append(orc.to_bytes_be(field, claimed_sum))          # prover.rs:42 (global sum)
+        self.pending = None
+        self.rp, self.ch = [], []
+        self.p = orc.modulus(field)
+
+    def _apply_pending(self):
+        if self.pending is not None:
+            r = self.pending[None, :]
+            self.cur = [orc.mle_partial_evaluate(self.field, self.vars_left, t, 0, r) for t in self.cur]
+            self.vars_left -= 1
+            self.pending = None
+
+    def _local_sums(self):
+        out = []
+        for t in range(self.D + 1):                                  # prover.rs:49-56 on the local shard
+            a = orc.from_int(self.field, t)[None, :]
+            folded = [orc.mle_partial_evaluate(self.field, self.vars_left, tb, 0, a) for tb in self.cur]
+            acc = np.zeros(4, dtype=np.uint64)
+            for e in orc.prod_reduce(self.field, self.vars_left - 1, folded):
+                acc = orc.add(self.field, acc, e)
+            out.append(acc)
+        return np.stack(out)
+
+    def round_begin(self):
+        self._apply_pending()
+        sums = self._local_sums()                                    # (D+1, 4) u64 Montgomery limbs
+        digits = sums.view(np.uint32).astype(np.int64).reshape(-1)   # 8 zero-extended 32-bit digits per element
+        self.lanes = torch.from_numpy(digits.copy())
+        return self.lanes
+
+    def _absorb_and_squeeze(self, sums):
+        for e in sums:
+            self.tr.append(orc.to_bytes_be(self.field, e))           # prover.rs:59
+        self.pending = self.tr.sample_field_element(self.field)      # prover.rs:62
+        self.rp.append(sums)
+        self.ch.append(self.pending)
+
+    def round_finish(self):
+        lanes = self.lanes.numpy().reshape(self.D + 1, 8)
+        sums = []
+        for row in lanes:                                            # carry-propagate, reduce mod p
+            v = sum(int(x) << (32 * i) for i, x in enumerate(row)) % self.p
+            sums.append(np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64))
+        self._absorb_and_squeeze(np.stack(sums))
+
+    def tail(self):
+        self._apply_pending()
+        elems = np.stack([t[0] for t in self.cur])                   # (k, 4)
+        return torch.from_numpy(elems.view(np.int64).reshape(-1).copy())
+
+    def tail_rounds(self, gathered):
+        g = gathered.numpy().view(np.uint64).reshape(self.world, self.k, 4)
+        self.cur = [np.ascontiguousarray(g[:, f, :]) for f in range(self.k)]
+        self.vars_left = int(np.log2(self.world))
+        while self.vars_left > 0:
+            self._apply_pending()
+            if self.vars_left == 0:
+                break
+            self._absorb_and_squeeze(self._local_sums())
+            if len(self.rp) == self.total_rounds:
+                break
+
+    def results(self):
+        return np.stack(self.rp), np.stack(self.ch)

@@ -72,6 +72,7 @@ _sig = {
     "zk_ctx_destroy": [c.c_void_p],
     "zk_ctx_synchronize": [c.c_void_p],
     "zk_ctx_set_stream": [c.c_void_p, c.c_void_p],
+    "zk_ctx_use_own_stream": [c.c_void_p],
     "zk_ctx_field": [c.c_void_p, c.POINTER(c.c_int32)],
     "zk_field_modulus": [c.c_int32, u64p],
     "zk_field_two_adicity": [c.c_int32, c.POINTER(c.c_int32)],
@@ -104,12 +105,19 @@ _sig = {
     "zk_keccak256": [c.c_char_p, c.c_size_t, c.c_char_p],
     "zk_sumcheck_prove": [c.c_void_p, vpp, c.c_uint64, c.c_uint32, u64p, c.c_int32, c.c_int32, u64p, u64p],
     "zk_sumcheck_prove_host": [c.c_void_p, c.POINTER(u64p), c.c_uint64, c.c_uint64, c.c_uint32, u64p, c.c_int32, u64p, u64p],
-    "zk_shard_prover_create": [c.c_void_p, vpp, c.c_uint64, c.c_uint32, u64p, vpp],
+    "zk_shard_prover_create": [c.c_void_p, vpp, c.c_uint64, c.c_uint32, u64p, c.c_uint32, vpp],
     "zk_shard_prover_destroy": [c.c_void_p],
+    "zk_shard_prover_rounds": [c.c_void_p, u64p, u64p, u64p],
     "zk_shard_prover_lanes_ptr": [c.c_void_p, vpp, u64p],
     "zk_shard_prover_round_begin": [c.c_void_p],
-    "zk_shard_prover_round_finish": [c.c_void_p, u64p, u64p],
-    "zk_shard_prover_remaining": [c.c_void_p, u64p],
+    "zk_shard_prover_round_finish": [c.c_void_p],
+    "zk_shard_prover_tail_ptr": [c.c_void_p, vpp, u64p],
+    "zk_shard_prover_tail_rounds": [c.c_void_p, c.c_void_p],
+    "zk_shard_prover_results": [c.c_void_p, u64p, u64p],
+    "zk_ctx_device_alloc": [c.c_void_p, c.c_uint64, vpp],
+    "zk_ctx_device_free": [c.c_void_p, c.c_void_p, c.c_uint64],
+    "zk_ctx_memcpy_dtoh": [c.c_void_p, c.c_void_p, c.c_void_p, c.c_uint64],
+    "zk_ctx_memcpy_htod": [c.c_void_p, c.c_void_p, c.c_void_p, c.c_uint64],
     "zk_sumcheck_verify_partial": [c.c_int32, c.c_uint64, c.c_uint32, u64p, u64p, u64p, u64p],
     "zk_sumcheck_verify": [c.c_void_p, vpp, c.c_uint64, c.c_uint64, c.c_uint32, u64p, u64p, c.POINTER(c.c_int32)],
     "zk_ntt": [c.c_void_p, c.c_void_p, c.c_int32, c.c_void_p],

@@ -125,7 +125,17 @@ class Context:
         check(lib.zk_ctx_synchronize(self._h))
 
     def set_stream(self, stream_ptr):
-        check(lib.zk_ctx_set_stream(self._h, c.c_void_p(stream_ptr)))
+        """run on a caller-owned hipStream_t (0 / None = the legacy default stream)"""
+        check(lib.zk_ctx_set_stream(self._h, c.c_void_p(stream_ptr or 0)))
+
+    def use_own_stream(self):
+        check(lib.zk_ctx_use_own_stream(self._h))
+
+    def use_torch_stream(self):
+        """share torch's current stream on this device, so kernels and torch.distributed collectives are ordered"""
+        import torch
+
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
     # measurement hooks
     def bench_copy(self, nbytes, reps=10):

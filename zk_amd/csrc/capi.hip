@@ -33,6 +33,8 @@ struct zk_ctx {
     uint64_t *h_pinned;     // pinned staging: kMaxSums*8 u64
     hipEvent_t ev0, ev1;
     std::map<std::pair<uint32_t, int>, uint64_t *> twiddles;   // (log_n, inverse) -> omega^i table, i < n/2
+    std::map<size_t, std::vector<void *>> pool;                // freed device blocks by exact size (stream-ordered reuse)
+    size_t pool_bytes;
 };
 struct zk_mle {
     zk_ctx *ctx;
@@ -72,6 +74,39 @@ static inline uint32_t grid_for(uint64_t items) {
 static inline int32_t use_device(const zk_ctx *ctx) {
     HIPCHK(hipSetDevice(ctx->device));
     return ZK_OK;
+}
+// Device blocks are recycled through a per-context free list keyed by size (tables are powers of two, so the hit
+// rate is high): hipMalloc/hipFree of a 256 MiB block costs milliseconds and synchronises the device, which is more
+// than a whole 2^24 fold.  All use is ordered on the context's stream, so a recycled block is safe to hand out again
+// without a synchronisation.
+static int32_t pool_alloc(zk_ctx *c, size_t bytes, void **out) {
+    if (bytes == 0) bytes = 32;
+    auto it = c->pool.find(bytes);
+    if (it != c->pool.end() && !it->second.empty()) {
+        *out = it->second.back();
+        it->second.pop_back();
+        c->pool_bytes -= bytes;
+        return ZK_OK;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {   // out of memory: drop the cache and retry once
+        for (auto &kv : c->pool)
+            for (void *q : kv.second) (void)hipFree(q);
+        c->pool.clear();
+        c->pool_bytes = 0;
+        e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess) {
+        g_hip_err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return ZK_ERR_ALLOC;
+    }
+    return ZK_OK;
+}
+static void pool_free(zk_ctx *c, void *ptr, size_t bytes) {
+    if (!ptr) return;
+    if (bytes == 0) bytes = 32;
+    c->pool[bytes].push_back(ptr);
+    c->pool_bytes += bytes;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -175,6 +210,7 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     c->fi = fi;
     c->own_stream = nullptr;
     c->d_partials = c->d_sums = c->h_pinned = nullptr;
+    c->pool_bytes = 0;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -191,6 +227,8 @@ extern "C" int32_t zk_ctx_destroy(zk_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &kv : c->twiddles) (void)hipFree(kv.second);
+    for (auto &kv : c->pool)
+        for (void *q : kv.second) (void)hipFree(q);
     (void)hipFree(c->d_partials);
     (void)hipFree(c->d_sums);
     (void)hipHostFree(c->h_pinned);
@@ -210,7 +248,14 @@ extern "C" int32_t zk_ctx_set_stream(zk_ctx *c, void *s) {
     if (!c) return ZK_ERR_BAD_ARG;
     ZKCHK(use_device(c));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;   // NULL is the legacy default stream (what torch uses unless told otherwise)
+    return ZK_OK;
+}
+extern "C" int32_t zk_ctx_use_own_stream(zk_ctx *c) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    ZKCHK(use_device(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stream = c->own_stream;
     return ZK_OK;
 }
 extern "C" int32_t zk_ctx_field(const zk_ctx *c, int32_t *out) {
@@ -229,14 +274,18 @@ static int32_t mle_alloc(zk_ctx *c, uint64_t n_vars, zk_mle **out) {
     t->ctx = c;
     t->n_vars = n_vars;
     t->d = nullptr;
-    hipError_t e = hipMalloc(&t->d, (size_t)32 << n_vars);
-    if (e != hipSuccess) {
-        g_hip_err = std::string("hipMalloc: ") + hipGetErrorString(e);
+    int32_t rc = pool_alloc(c, (size_t)32 << n_vars, (void **)&t->d);
+    if (rc != ZK_OK) {
         delete t;
-        return ZK_ERR_ALLOC;
+        return rc;
     }
     *out = t;
     return ZK_OK;
+}
+static void mle_release(zk_mle *t) {
+    if (!t) return;
+    pool_free(t->ctx, t->d, (size_t)32 << t->n_vars);
+    delete t;
 }
 extern "C" int32_t zk_mle_alloc(zk_ctx *c, uint64_t n_vars, zk_mle **out) {
     if (!c || !out) return ZK_ERR_BAD_ARG;
@@ -253,8 +302,7 @@ extern "C" int32_t zk_mle_upload(zk_ctx *c, uint64_t n_vars, const uint64_t *eva
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         g_hip_err = std::string("upload: ") + hipGetErrorString(e);
-        (void)hipFree(t->d);
-        delete t;
+        mle_release(t);
         return ZK_ERR_HIP;
     }
     *out = t;
@@ -282,10 +330,7 @@ extern "C" int32_t zk_mle_clone(zk_ctx *c, const zk_mle *t, zk_mle **out) {
 extern "C" int32_t zk_mle_free(zk_ctx *c, zk_mle *t) {
     if (!t) return ZK_OK;
     if (!c || t->ctx != c) return ZK_ERR_CONTEXT_MISMATCH;
-    ZKCHK(use_device(c));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipFree(t->d));
-    delete t;
+    mle_release(t);   // back to the context's pool; reuse is stream-ordered
     return ZK_OK;
 }
 extern "C" int32_t zk_mle_n_vars(const zk_mle *t, uint64_t *out) {
@@ -343,15 +388,9 @@ extern "C" int32_t zk_mle_partial_evaluate(zk_ctx *c, const zk_mle *t, uint64_t 
         rc = launch_fold(c, src, dst, t->n_vars - i, initial_var, fe_from_u64limbs(assignments + 4 * i));
         src = dst;
     }
-    if (rc == ZK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = ZK_ERR_HIP;
-    for (int i = 0; i < 2; ++i)
-        if (tmp[i]) {
-            (void)hipFree(tmp[i]->d);
-            delete tmp[i];
-        }
+    for (int i = 0; i < 2; ++i) mle_release(tmp[i]);
     if (rc != ZK_OK) {
-        (void)hipFree(res->d);
-        delete res;
+        mle_release(res);
         return rc;
     }
     *out = res;
@@ -375,7 +414,7 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
         return ZK_OK;
     }
     uint64_t *scratch = nullptr;
-    HIPCHK(hipMalloc(&scratch, (size_t)32 << (n - 1)));
+    ZKCHK(pool_alloc(c, (size_t)32 << (n - 1), (void **)&scratch));
     const uint64_t *src = t->d;
     int32_t rc = ZK_OK;
     for (uint64_t i = 0; i < n && rc == ZK_OK; ++i) {
@@ -383,8 +422,7 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
         src = scratch;
     }
     if (rc == ZK_OK && hipMemcpyAsync(d_out_elem, scratch, 32, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = ZK_ERR_HIP;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = ZK_ERR_HIP;
-    (void)hipFree(scratch);
+    pool_free(c, scratch, (size_t)32 << (n - 1));
     return rc;
 }
 extern "C" int32_t zk_mle_evaluate(zk_ctx *c, const zk_mle *t, const uint64_t *point, uint64_t n_point, uint64_t out[4]) {
@@ -480,36 +518,85 @@ extern "C" int32_t zk_product_evaluate(zk_ctx *c, const zk_mle *const *f, uint64
     return ZK_OK;
 }
 
-// launch one round's sums (+ optional fused fold) and the second-stage reduction; result (D+1 elements) in c->d_sums
+// ---- round machinery ------------------------------------------------------------------------------------------
+// Per-prover device scratch: the word sponge, the current challenge, and the proof being assembled.  Nothing in the
+// round loop waits on the host: k_round (+fold) -> k_round_tail (reduce + transcript) -> k_round (+fold) -> ...
+struct ProverScratch {
+    WordSponge *d_sponge;
+    uint64_t *d_challenge;   // 1 element, Montgomery
+    uint64_t *d_rp;          // rounds * (D+1) elements
+    uint64_t *d_ch;          // rounds elements
+    size_t rp_bytes, ch_bytes;
+};
+static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint32_t D) {
+    ps = {};
+    ps.rp_bytes = (size_t)(rounds ? rounds : 1) * (D + 1) * 32;
+    ps.ch_bytes = (size_t)(rounds ? rounds : 1) * 32;
+    ZKCHK(pool_alloc(c, sizeof(WordSponge), (void **)&ps.d_sponge));
+    ZKCHK(pool_alloc(c, 32, (void **)&ps.d_challenge));
+    ZKCHK(pool_alloc(c, ps.rp_bytes, (void **)&ps.d_rp));
+    ZKCHK(pool_alloc(c, ps.ch_bytes, (void **)&ps.d_ch));
+    return ZK_OK;
+}
+static void scratch_free(zk_ctx *c, ProverScratch &ps) {
+    pool_free(c, ps.d_sponge, sizeof(WordSponge));
+    pool_free(c, ps.d_challenge, 32);
+    pool_free(c, ps.d_rp, ps.rp_bytes);
+    pool_free(c, ps.d_ch, ps.ch_bytes);
+    ps = {};
+}
+
 template <bool FUSED>
-static int32_t launch_round(zk_ctx *c, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, const Fe &r) {
+static int32_t launch_round_kernel(zk_ctx *c, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, const uint64_t *d_r,
+                                   uint32_t *out_grid) {
     const uint32_t g = grid_for(q);
     const FieldParams &P = c->fi->P;
     switch (D) {
-        case 1: k_round<1, FUSED><<<g, kBlock, 0, c->stream>>>(fp, k, q, P, r, c->d_partials); break;
-        case 2: k_round<2, FUSED><<<g, kBlock, 0, c->stream>>>(fp, k, q, P, r, c->d_partials); break;
-        case 3: k_round<3, FUSED><<<g, kBlock, 0, c->stream>>>(fp, k, q, P, r, c->d_partials); break;
-        case 4: k_round<4, FUSED><<<g, kBlock, 0, c->stream>>>(fp, k, q, P, r, c->d_partials); break;
+        case 1: k_round<1, FUSED><<<g, kBlock, 0, c->stream>>>(fp, k, q, P, d_r, c->d_partials); break;
+        case 2: k_round<2, FUSED><<<g, kBlock, 0, c->stream>>>(fp, k, q, P, d_r, c->d_partials); break;
+        case 3: k_round<3, FUSED><<<g, kBlock, 0, c->stream>>>(fp, k, q, P, d_r, c->d_partials); break;
+        case 4: k_round<4, FUSED><<<g, kBlock, 0, c->stream>>>(fp, k, q, P, d_r, c->d_partials); break;
         default: return ZK_ERR_UNSUPPORTED;
     }
     HIPCHK(hipGetLastError());
-    k_final_sums<<<1, kBlock, 0, c->stream>>>(c->d_partials, g, D + 1, c->d_sums, P);
-    HIPCHK(hipGetLastError());
-    return ZK_OK;
-}
-// any degree: per evaluation point t one pass (tables already folded); used for D = 0 and D > 4
-static int32_t launch_round_generic(zk_ctx *c, const FactorPtrs &fp, int k, uint64_t q, uint32_t D) {
-    const uint32_t g = grid_for(q);
-    const FieldParams &P = c->fi->P;
-    for (uint32_t t = 0; t <= D; ++t) {
-        k_round_single_t<<<g, kBlock, 0, c->stream>>>(fp, k, q, P, fe_from_u32(t, P), c->d_partials);
-        HIPCHK(hipGetLastError());
-        k_final_sums<<<1, kBlock, 0, c->stream>>>(c->d_partials, g, 1, c->d_sums + 4 * t, P);
-        HIPCHK(hipGetLastError());
-    }
+    *out_grid = g;
     return ZK_OK;
 }
 static inline bool fast_degree(uint32_t D) { return D >= 1 && D <= 4; }
+
+// Where a round's sums go after the second-stage reduction.
+struct TailTargets {
+    WordSponge *sponge;     // run the transcript step (single-GPU prover)
+    uint64_t *out_rp;       // round polynomial, D+1 elements (device)
+    uint64_t *out_ch;       // challenge record (device), may be null
+    uint64_t *d_challenge;  // challenge for the next fused fold
+    uint64_t *lanes;        // 32-bit digit lanes for the cross-GPU all-reduce, may be null
+};
+// sums of the current tables (already folded) -> targets.  Handles every degree.
+static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused, const uint64_t *d_r,
+                           const TailTargets &tt) {
+    const FieldParams &P = c->fi->P;
+    if (fast_degree(D)) {
+        uint32_t g = 0;
+        if (fused) ZKCHK(launch_round_kernel<true>(c, fp, k, q, D, d_r, &g));
+        else ZKCHK(launch_round_kernel<false>(c, fp, k, q, D, d_r, &g));
+        k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, g, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
+                                                  tt.lanes, P);
+        HIPCHK(hipGetLastError());
+        return ZK_OK;
+    }
+    // any other degree (0, or > 4): one pass per evaluation point over tables that are already folded
+    const uint32_t g = grid_for(q);
+    for (uint32_t t = 0; t <= D; ++t) {
+        k_round_single_t<<<g, kBlock, 0, c->stream>>>(fp, k, q, P, fe_from_u32(t, P), c->d_partials);
+        HIPCHK(hipGetLastError());
+        k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, g, 1, nullptr, c->d_sums + 4 * t, nullptr, nullptr, nullptr, P);
+        HIPCHK(hipGetLastError());
+    }
+    k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_sums, 1, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge, tt.lanes, P);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
 
 extern "C" int32_t zk_round_sums(zk_ctx *c, const zk_mle *const *f, uint64_t k, uint32_t D, uint64_t *out) {
     if (!out) return ZK_ERR_BAD_ARG;
@@ -519,9 +606,10 @@ extern "C" int32_t zk_round_sums(zk_ctx *c, const zk_mle *const *f, uint64_t k, 
     FactorPtrs fp = {};
     for (uint64_t i = 0; i < k; ++i) fp.in[i] = f[i]->d;
     const uint64_t q = 1ull << (f[0]->n_vars - 1);
-    if (fast_degree(D)) ZKCHK(launch_round<false>(c, fp, (int)k, q, D, fe_zero()));
-    else ZKCHK(launch_round_generic(c, fp, (int)k, q, D));
-    HIPCHK(hipMemcpyAsync(out, c->d_sums, (size_t)(D + 1) * 32, hipMemcpyDeviceToHost, c->stream));
+    uint64_t *d_out = c->d_sums + 4 * kMaxSums;   // second third of d_sums
+    TailTargets tt = {nullptr, d_out, nullptr, nullptr, nullptr};
+    ZKCHK(launch_sums(c, fp, (int)k, q, D, false, nullptr, tt));
+    HIPCHK(hipMemcpyAsync(out, d_out, (size_t)(D + 1) * 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return ZK_OK;
 }
@@ -611,69 +699,99 @@ static int32_t absorb_tables(zk_ctx *c, Sponge &sp, zk_mle *const *f, uint64_t k
 // ------------------------------------------------------------------------------------------------------------
 struct RoundState {
     zk_ctx *c;
-    uint64_t k, n_vars, round;
+    uint64_t k;
+    uint64_t vars_left;               // variables of the tables in `cur` (before any pending fold)
+    uint64_t round;                   // rounds completed
     uint32_t D;
+    bool pending_fold;                // the last challenge has not been applied to `cur` yet (it is fused into the next round)
+    bool first_out_of_place;          // next fold must leave `cur` intact (caller keeps the inputs): write to scratch
     uint64_t *cur[kMaxFactors];       // current tables (device)
-    uint64_t *scratch[kMaxFactors];   // owned half-size tables when the inputs must stay intact
-    bool consume;
-    Fe last_challenge;
+    uint64_t *scratch[kMaxFactors];   // owned tables
+    size_t scratch_bytes[kMaxFactors];
+    ProverScratch ps;
 };
 static void round_state_release(RoundState &st) {
-    for (uint64_t i = 0; i < st.k; ++i)
+    for (uint64_t i = 0; i < (uint64_t)kMaxFactors; ++i)
         if (st.scratch[i]) {
-            (void)hipFree(st.scratch[i]);
+            pool_free(st.c, st.scratch[i], st.scratch_bytes[i]);
             st.scratch[i] = nullptr;
         }
+    scratch_free(st.c, st.ps);
 }
-static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uint64_t k, uint32_t D, bool consume) {
+static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uint64_t k, uint32_t D, bool consume,
+                                uint64_t total_rounds) {
     st.c = c;
     st.k = k;
-    st.n_vars = f[0]->n_vars;
+    st.vars_left = f[0]->n_vars;
     st.round = 0;
     st.D = D;
-    st.consume = consume;
-    st.last_challenge = fe_zero();
+    st.pending_fold = false;
+    st.first_out_of_place = !consume;
+    st.ps = {};
     for (uint64_t i = 0; i < (uint64_t)kMaxFactors; ++i) {
         st.cur[i] = i < k ? f[i]->d : nullptr;
         st.scratch[i] = nullptr;
+        st.scratch_bytes[i] = 0;
     }
-    if (!consume && st.n_vars >= 2)
-        for (uint64_t i = 0; i < k; ++i)
-            if (hipMalloc(&st.scratch[i], (size_t)32 << (st.n_vars - 1)) != hipSuccess) {
-                round_state_release(st);
-                return ZK_ERR_ALLOC;
-            }
-    return ZK_OK;
+    int32_t rc = scratch_alloc(c, st.ps, total_rounds, D);
+    if (rc == ZK_OK && !consume && st.vars_left >= 2)
+        for (uint64_t i = 0; i < k && rc == ZK_OK; ++i) {
+            st.scratch_bytes[i] = (size_t)32 << (st.vars_left - 1);
+            rc = pool_alloc(c, st.scratch_bytes[i], (void **)&st.scratch[i]);
+        }
+    if (rc != ZK_OK) round_state_release(st);
+    return rc;
 }
-// Enqueue round `st.round`: fold the previous round's tables at its challenge (fused) and compute this round's sums.
-// Leaves the D+1 sums in c->d_sums.
-static int32_t round_enqueue(RoundState &st) {
+// Enqueue the next round: apply the pending fold (prover.rs:64 of the previous round, fused) and compute this round's
+// sums (prover.rs:49-56).  `lanes` selects the sharded form (sums -> digit lanes, transcript deferred).
+static int32_t round_enqueue(RoundState &st, uint64_t *lanes) {
     zk_ctx *c = st.c;
-    const uint64_t m = st.n_vars - st.round;          // variables left in this round's table
+    if (st.pending_fold) st.vars_left -= 1;           // tables shrink by the fold fused into this launch
+    const uint64_t m = st.vars_left;                  // variables of this round's table
+    if (m == 0) return ZK_ERR_BAD_ARG;
     const uint64_t q = 1ull << (m - 1);
     FactorPtrs fp = {};
-    if (st.round == 0) {
-        for (uint64_t i = 0; i < st.k; ++i) fp.in[i] = st.cur[i];
-        if (fast_degree(st.D)) return launch_round<false>(c, fp, (int)st.k, q, st.D, fe_zero());
-        return launch_round_generic(c, fp, (int)st.k, q, st.D);
-    }
     for (uint64_t i = 0; i < st.k; ++i) {
         fp.in[i] = st.cur[i];
-        uint64_t *dst = (st.round == 1 && !st.consume) ? st.scratch[i] : st.cur[i];   // in place afterwards
-        fp.out[i] = dst;
+        fp.out[i] = (st.pending_fold && st.first_out_of_place && st.scratch[i]) ? st.scratch[i] : st.cur[i];   // else in place
     }
+    TailTargets tt;
+    tt.sponge = lanes ? nullptr : st.ps.d_sponge;
+    tt.out_rp = st.ps.d_rp + st.round * (st.D + 1) * 4;
+    tt.out_ch = st.ps.d_ch + st.round * 4;
+    tt.d_challenge = st.ps.d_challenge;
+    tt.lanes = lanes;
     int32_t rc;
-    if (fast_degree(st.D)) {
-        rc = launch_round<true>(c, fp, (int)st.k, q, st.D, st.last_challenge);
-    } else {
+    if (st.pending_fold && !fast_degree(st.D)) {
+        // generic degree: fold as separate launches, then the per-point passes
+        Fe r;
+        (void)r;
         rc = ZK_OK;
-        for (uint64_t i = 0; i < st.k && rc == ZK_OK; ++i) rc = launch_fold(c, fp.in[i], fp.out[i], m + 1, 0, st.last_challenge);
+        for (uint64_t i = 0; i < st.k && rc == ZK_OK; ++i) {
+            k_fold_dev<<<grid_for(q * 2), kBlock, 0, c->stream>>>(fp.in[i], fp.out[i], q * 2, (uint32_t)m, c->fi->P, st.ps.d_challenge);
+            if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+        }
         FactorPtrs g = {};
         for (uint64_t i = 0; i < st.k; ++i) g.in[i] = fp.out[i];
-        if (rc == ZK_OK) rc = launch_round_generic(c, g, (int)st.k, q, st.D);
+        if (rc == ZK_OK) rc = launch_sums(c, g, (int)st.k, q, st.D, false, nullptr, tt);
+    } else {
+        rc = launch_sums(c, fp, (int)st.k, q, st.D, st.pending_fold, st.ps.d_challenge, tt);
     }
-    for (uint64_t i = 0; i < st.k; ++i) st.cur[i] = fp.out[i];
+    if (st.pending_fold) {
+        for (uint64_t i = 0; i < st.k; ++i) st.cur[i] = fp.out[i];
+        st.first_out_of_place = false;
+    }
+    st.pending_fold = true;    // this round's challenge gets applied by the next launch
     return rc;
+}
+
+// host byte sponge (table + claimed sum absorbed) -> device word sponge
+static int32_t sponge_to_device(zk_ctx *c, const Sponge &host, WordSponge *d_sponge) {
+    WordSponge *w = reinterpret_cast<WordSponge *>(c->h_pinned);
+    if (!w->from_byte_sponge(host)) return ZK_ERR_BAD_ARG;
+    HIPCHK(hipMemcpyAsync(d_sponge, w, sizeof(WordSponge), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // h_pinned is reused
+    return ZK_OK;
 }
 
 extern "C" int32_t zk_sumcheck_prove(zk_ctx *c, zk_mle *const *f, uint64_t k, uint32_t D, const uint64_t sum[4],
@@ -683,30 +801,26 @@ extern "C" int32_t zk_sumcheck_prove(zk_ctx *c, zk_mle *const *f, uint64_t k, ui
     if (f[0]->n_vars && (!out_rp || !out_ch)) return ZK_ERR_BAD_ARG;
     if (D >= kMaxSums) return ZK_ERR_UNSUPPORTED;
     const FieldParams &P = c->fi->P;
+    const uint64_t n = f[0]->n_vars;
     Sponge sp;
     sp.init();                                                           // Transcript::new (prover.rs:16,28)
     if (absorb_table) ZKCHK(absorb_tables(c, sp, f, k));                 // prover.rs:17
     absorb_elements(sp, sum, 1, P);                                      // prover.rs:42
+    if (n == 0) return ZK_OK;                                            // no rounds (prover.rs:44)
     RoundState st;
-    ZKCHK(round_state_init(st, c, f, k, D, consume != 0));
-    int32_t rc = ZK_OK;
-    const uint64_t n = st.n_vars;
-    for (; st.round < n && rc == ZK_OK; ++st.round) {                    // prover.rs:44
-        rc = round_enqueue(st);                                          // prover.rs:49-56 (+ :64 of the previous round)
-        if (rc != ZK_OK) break;
-        uint64_t *rp = out_rp + st.round * (D + 1) * 4;
-        if (hipMemcpyAsync(rp, c->d_sums, (size_t)(D + 1) * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess) {
+    ZKCHK(round_state_init(st, c, f, k, D, consume != 0, n));
+    int32_t rc = sponge_to_device(c, sp, st.ps.d_sponge);
+    for (; st.round < n && rc == ZK_OK; ++st.round) rc = round_enqueue(st, nullptr);   // prover.rs:44-68, all on device
+    // prover.rs:64 after the LAST round folds to a 0-variable polynomial the reference drops: not computed.
+    if (rc == ZK_OK) {
+        if (hipMemcpyAsync(out_rp, st.ps.d_rp, (size_t)n * (D + 1) * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(out_ch, st.ps.d_ch, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
             rc = ZK_ERR_HIP;
-            break;
-        }
-        absorb_elements(sp, rp, D + 1, P);                               // prover.rs:59
-        st.last_challenge = squeeze_field_element(sp, P);                // prover.rs:62
-        fe_to_u64limbs(st.last_challenge, out_ch + 4 * st.round);
-        // prover.rs:64 (fold at the challenge) is fused into the next round's kernel; the fold after the last
-        // round produces a 0-variable polynomial the reference drops, so it is not computed.
     }
-    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == ZK_OK) rc = ZK_ERR_HIP;
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == ZK_OK) {
+        g_hip_err = "sumcheck: stream synchronize failed";
+        rc = ZK_ERR_HIP;
+    }
     round_state_release(st);
     return rc;
 }
@@ -725,44 +839,54 @@ extern "C" int32_t zk_sumcheck_prove_host(zk_ctx *c, const uint64_t *const *tabl
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// sharded prover: same loop, one exchange point per round
+// sharded prover: the same loop with one exchange point per round
 // ------------------------------------------------------------------------------------------------------------
 struct zk_shard_prover {
     RoundState st;
-    Sponge sp;
-    uint64_t *d_lanes;   // (D+1)*8 u64 lanes: 32-bit digits of the local sums, zero-extended
+    uint32_t world;
+    uint64_t local_rounds, total_rounds;
+    uint64_t *d_lanes;    // (D+1)*8 u64 lanes
+    uint64_t *d_tail;     // k elements: this rank's fully folded factors
+    bool tail_done;
 };
-__global__ void k_sums_to_lanes(const uint64_t *__restrict__ sums, uint64_t *__restrict__ lanes, uint32_t n_elems) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // one lane per thread
-    if (i < n_elems * 8) {
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(sums);
-        lanes[i] = (uint64_t)w[i];
-    }
-}
 extern "C" int32_t zk_shard_prover_create(zk_ctx *c, zk_mle *const *f, uint64_t k, uint32_t D, const uint64_t sum[4],
-                                          zk_shard_prover **out) {
+                                          uint32_t world, zk_shard_prover **out) {
     if (!out || !sum) return ZK_ERR_BAD_ARG;
     ZKCHK(product_args(c, (const zk_mle *const *)f, k));
     if (D >= kMaxSums) return ZK_ERR_UNSUPPORTED;
+    if (world == 0 || (world & (world - 1)) || world > 65536) return ZK_ERR_BAD_ARG;
+    uint32_t lw = 0;
+    while ((1u << lw) < world) ++lw;
     zk_shard_prover *sp = new (std::nothrow) zk_shard_prover();
     if (!sp) return ZK_ERR_ALLOC;
-    int32_t rc = round_state_init(sp->st, c, f, k, D, /*consume=*/true);
-    if (rc == ZK_OK && hipMalloc(&sp->d_lanes, (size_t)(D + 1) * 8 * sizeof(uint64_t)) != hipSuccess) rc = ZK_ERR_ALLOC;
+    sp->world = world;
+    sp->local_rounds = f[0]->n_vars;
+    sp->total_rounds = f[0]->n_vars + lw;
+    sp->d_lanes = sp->d_tail = nullptr;
+    sp->tail_done = false;
+    int32_t rc = round_state_init(sp->st, c, f, k, D, /*consume=*/true, sp->total_rounds);
+    if (rc == ZK_OK) rc = pool_alloc(c, (size_t)kMaxSums * 8 * sizeof(uint64_t), (void **)&sp->d_lanes);
+    if (rc == ZK_OK) rc = pool_alloc(c, (size_t)kMaxFactors * 32, (void **)&sp->d_tail);
+    if (rc == ZK_OK) {
+        Sponge host;
+        host.init();
+        absorb_elements(host, sum, 1, c->fi->P);   // prover.rs:42 -- the GLOBAL claimed sum, identical on every rank
+        rc = sponge_to_device(c, host, sp->st.ps.d_sponge);
+    }
     if (rc != ZK_OK) {
-        delete sp;
+        (void)zk_shard_prover_destroy(sp);
         return rc;
     }
-    sp->sp.init();
-    absorb_elements(sp->sp, sum, 1, c->fi->P);   // prover.rs:42 -- the GLOBAL claimed sum, identical on every rank
     *out = sp;
     return ZK_OK;
 }
 extern "C" int32_t zk_shard_prover_destroy(zk_shard_prover *sp) {
     if (!sp) return ZK_OK;
-    (void)hipSetDevice(sp->st.c->device);
-    (void)hipStreamSynchronize(sp->st.c->stream);
+    zk_ctx *c = sp->st.c;
+    (void)hipSetDevice(c->device);
     round_state_release(sp->st);
-    (void)hipFree(sp->d_lanes);
+    pool_free(c, sp->d_lanes, (size_t)kMaxSums * 8 * sizeof(uint64_t));
+    pool_free(c, sp->d_tail, (size_t)kMaxFactors * 32);
     delete sp;
     return ZK_OK;
 }
@@ -772,68 +896,122 @@ extern "C" int32_t zk_shard_prover_lanes_ptr(zk_shard_prover *sp, void **out_ptr
     *out_n = (uint64_t)(sp->st.D + 1) * 8;
     return ZK_OK;
 }
-extern "C" int32_t zk_shard_prover_remaining(zk_shard_prover *sp, uint64_t *out) {
-    if (!sp || !out) return ZK_ERR_BAD_ARG;
-    *out = sp->st.n_vars - sp->st.round;
+extern "C" int32_t zk_shard_prover_rounds(zk_shard_prover *sp, uint64_t *out_local, uint64_t *out_total, uint64_t *out_done) {
+    if (!sp) return ZK_ERR_BAD_ARG;
+    if (out_local) *out_local = sp->local_rounds;
+    if (out_total) *out_total = sp->total_rounds;
+    if (out_done) *out_done = sp->st.round;
     return ZK_OK;
 }
+// local part of a round: (fold +) sums -> digit lanes.  Asynchronous.
 extern "C" int32_t zk_shard_prover_round_begin(zk_shard_prover *sp) {
     if (!sp) return ZK_ERR_BAD_ARG;
     RoundState &st = sp->st;
-    if (st.round >= st.n_vars) return ZK_ERR_BAD_ARG;
+    if (st.round >= sp->local_rounds) return ZK_ERR_BAD_ARG;
     ZKCHK(use_device(st.c));
-    ZKCHK(round_enqueue(st));
-    const uint32_t lanes = (st.D + 1) * 8;
-    k_sums_to_lanes<<<(lanes + 63) / 64, 64, 0, st.c->stream>>>(st.c->d_sums, sp->d_lanes, st.D + 1);
+    return round_enqueue(st, sp->d_lanes);
+}
+// after the caller's all-reduce of the lanes: reduce mod p, absorb, squeeze.  Asynchronous.
+extern "C" int32_t zk_shard_prover_round_finish(zk_shard_prover *sp) {
+    if (!sp) return ZK_ERR_BAD_ARG;
+    RoundState &st = sp->st;
+    zk_ctx *c = st.c;
+    if (st.round >= sp->local_rounds || !st.pending_fold) return ZK_ERR_BAD_ARG;
+    ZKCHK(use_device(c));
+    k_lanes_transcript<<<1, 64, 0, c->stream>>>(sp->d_lanes, st.D + 1, st.ps.d_sponge, st.ps.d_rp + st.round * (st.D + 1) * 4,
+                                                st.ps.d_ch + st.round * 4, st.ps.d_challenge, c->fi->P);
     HIPCHK(hipGetLastError());
+    ++st.round;
     return ZK_OK;
 }
-// lanes (sum over ranks of 32-bit digits) -> canonical Montgomery element: carry-propagate, then reduce mod p
-static Fe lanes_to_fe(const uint64_t lanes[8], const FieldParams &P) {
-    uint32_t v[10] = {0};
-    uint64_t carry = 0;
-    for (int i = 0; i < 8; ++i) {
-        carry += lanes[i];
-        v[i] = (uint32_t)carry;
-        carry >>= 32;
-    }
-    v[8] = (uint32_t)carry;
-    v[9] = (uint32_t)(carry >> 32);
-    // v < 2^64 * p: shift-subtract p << k for k = 64..0 (10-limb arithmetic)
-    for (int k = 64; k >= 0; --k) {
-        uint32_t sh[10] = {0}, d[10];
-        const int ws = k / 32, bs = k % 32;
-        for (int i = 0; i < 8; ++i) {
-            const uint64_t x = (uint64_t)P.p[i] << bs;
-            if (i + ws < 10) sh[i + ws] |= (uint32_t)x;
-            if (i + ws + 1 < 10) sh[i + ws + 1] |= (uint32_t)(x >> 32);
+// after the last local round: apply the last challenge -> one element per factor (device, k elements) for the all-gather
+extern "C" int32_t zk_shard_prover_tail_ptr(zk_shard_prover *sp, void **out_ptr, uint64_t *out_elems) {
+    if (!sp || !out_ptr || !out_elems) return ZK_ERR_BAD_ARG;
+    RoundState &st = sp->st;
+    zk_ctx *c = st.c;
+    if (st.round != sp->local_rounds) return ZK_ERR_BAD_ARG;
+    ZKCHK(use_device(c));
+    if (!sp->tail_done) {
+        for (uint64_t i = 0; i < st.k; ++i) {
+            if (st.pending_fold) {   // vars_left == 1: fold the last two elements
+                k_fold_dev<<<1, kBlock, 0, c->stream>>>(st.cur[i], sp->d_tail + 4 * i, 1, 0, c->fi->P, st.ps.d_challenge);
+                HIPCHK(hipGetLastError());
+            } else {                 // 0 local variables: the element itself
+                HIPCHK(hipMemcpyAsync(sp->d_tail + 4 * i, st.cur[i], 32, hipMemcpyDeviceToDevice, c->stream));
+            }
         }
-        uint32_t borrow = 0;
-        for (int i = 0; i < 10; ++i) {
-            uint32_t bo;
-            d[i] = __builtin_subc(v[i], sh[i], borrow, &bo);
-            borrow = bo;
-        }
-        if (!borrow) memcpy(v, d, sizeof v);
+        sp->tail_done = true;
     }
-    Fe r;
-    memcpy(r.v, v, 32);
-    return r;
+    *out_ptr = sp->d_tail;
+    *out_elems = st.k;
+    return ZK_OK;
 }
-extern "C" int32_t zk_shard_prover_round_finish(zk_shard_prover *sp, uint64_t *out_rp, uint64_t out_ch[4]) {
+// gathered: device array [world][k] elements (rank-major), identical on every rank.  Runs the remaining log2(world)
+// rounds on the world-element tables table_f[rank] -- the (log2 world)-variable remainder in the reference's index
+// order, because rank = the low index bits.  Asynchronous.
+extern "C" int32_t zk_shard_prover_tail_rounds(zk_shard_prover *sp, const void *gathered) {
+    if (!sp || !gathered) return ZK_ERR_BAD_ARG;
+    RoundState &st = sp->st;
+    zk_ctx *c = st.c;
+    if (st.round != sp->local_rounds || !sp->tail_done) return ZK_ERR_BAD_ARG;
+    ZKCHK(use_device(c));
+    if (sp->world == 1) return ZK_OK;
+    FactorPtrs fp = {};
+    for (uint64_t i = 0; i < st.k; ++i) {
+        if (st.scratch[i]) pool_free(c, st.scratch[i], st.scratch_bytes[i]);
+        st.scratch_bytes[i] = (size_t)sp->world * 32;
+        st.scratch[i] = nullptr;
+        ZKCHK(pool_alloc(c, st.scratch_bytes[i], (void **)&st.scratch[i]));
+        fp.out[i] = st.scratch[i];
+        st.cur[i] = st.scratch[i];
+    }
+    const uint32_t items = (uint32_t)st.k * sp->world;
+    k_gather_to_tables<<<(items + 255) / 256, 256, 0, c->stream>>>((const uint64_t *)gathered, fp, (uint32_t)st.k, sp->world);
+    HIPCHK(hipGetLastError());
+    st.pending_fold = false;
+    st.first_out_of_place = false;
+    st.vars_left = sp->total_rounds - sp->local_rounds;
+    int32_t rc = ZK_OK;
+    for (; st.round < sp->total_rounds && rc == ZK_OK; ++st.round) rc = round_enqueue(st, nullptr);
+    return rc;
+}
+// download what has been proven so far (synchronises): total_rounds*(D+1) and total_rounds elements
+extern "C" int32_t zk_shard_prover_results(zk_shard_prover *sp, uint64_t *out_rp, uint64_t *out_ch) {
     if (!sp || !out_rp || !out_ch) return ZK_ERR_BAD_ARG;
     RoundState &st = sp->st;
     zk_ctx *c = st.c;
-    if (st.round >= st.n_vars) return ZK_ERR_BAD_ARG;
     ZKCHK(use_device(c));
-    const uint32_t ns = st.D + 1;
-    HIPCHK(hipMemcpyAsync(c->h_pinned, sp->d_lanes, (size_t)ns * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (st.round) {
+        HIPCHK(hipMemcpyAsync(out_rp, st.ps.d_rp, (size_t)st.round * (st.D + 1) * 32, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(out_ch, st.ps.d_ch, (size_t)st.round * 32, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (uint32_t t = 0; t < ns; ++t) fe_to_u64limbs(lanes_to_fe(c->h_pinned + 8 * t, c->fi->P), out_rp + 4 * t);
-    absorb_elements(sp->sp, out_rp, ns, c->fi->P);                       // prover.rs:59
-    st.last_challenge = squeeze_field_element(sp->sp, c->fi->P);         // prover.rs:62
-    fe_to_u64limbs(st.last_challenge, out_ch);
-    ++st.round;
+    return ZK_OK;
+}
+// plain device <-> host copies on the context's stream (synchronous): lets a host without a HIP binding (tests, the
+// single-process rehearsal of the sharded prover) move the lanes / tail buffers
+extern "C" int32_t zk_ctx_memcpy_dtoh(zk_ctx *c, void *dst_host, const void *src_dev, uint64_t bytes) {
+    if (!c || !dst_host || !src_dev) return ZK_ERR_BAD_ARG;
+    ZKCHK(use_device(c));
+    HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+extern "C" int32_t zk_ctx_memcpy_htod(zk_ctx *c, void *dst_dev, const void *src_host, uint64_t bytes) {
+    if (!c || !dst_dev || !src_host) return ZK_ERR_BAD_ARG;
+    ZKCHK(use_device(c));
+    HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+extern "C" int32_t zk_ctx_device_alloc(zk_ctx *c, uint64_t bytes, void **out) {
+    if (!c || !out) return ZK_ERR_BAD_ARG;
+    ZKCHK(use_device(c));
+    return pool_alloc(c, bytes, out);
+}
+extern "C" int32_t zk_ctx_device_free(zk_ctx *c, void *ptr, uint64_t bytes) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    pool_free(c, ptr, bytes);
     return ZK_OK;
 }
 

@@ -230,6 +230,27 @@ ZK_HD Fe fe_from_u32(uint32_t x, const FieldParams &P) {          // F::from(x)
     return fe_from_canonical(v, P);
 }
 
+// s (9 limbs) -= (p << k) while s >= (p << k), for k = KMAX..0: brings any s < 2^(KMAX+1) * p below p.
+template <int KMAX>
+ZK_HD void ladder9(uint32_t s[9], const FieldParams &P) {
+#pragma unroll
+    for (int k = KMAX; k >= 0; --k) {
+        uint32_t d[9];
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            uint32_t pk;
+            if (k == 0) pk = (i < 8) ? P.p[i] : 0u;
+            else pk = ((i < 8) ? (P.p[i] << k) : 0u) | ((i > 0) ? (P.p[i - 1] >> (32 - k)) : 0u);
+            uint32_t bo;
+            d[i] = __builtin_subc(s[i], pk, borrow, &bo);
+            borrow = bo;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s[i] = borrow ? s[i] : d[i];
+    }
+}
+
 // ---- wide accumulation for the sumcheck round sums -------------------------------------------------------
 // Sum of up to ~2^32 512-bit products in 17 limbs; reduced once with redc_wide.
 struct WideAcc {
@@ -292,23 +313,21 @@ ZK_HD Fe redc_wide(const WideAcc &w, const FieldParams &P) {
         }
         s[8] += (uint32_t)c;
     }
-    // conditional subtraction of (p << k), k = 4..0  (9-limb; covers s < 32p)
+    ladder9<4>(s, P);
+    Fe r;
 #pragma unroll
-    for (int k = 4; k >= 0; --k) {
-        uint32_t d[9];
-        uint32_t borrow = 0;
+    for (int i = 0; i < 8; ++i) r.v[i] = s[i];
+    return r;
+}
+
+// x mod p for any 256-bit x (8 LE limbs), as a canonical (non-Montgomery) integer.  p > 2^251 for every supported
+// field, so x < 32p and the ladder 16p..p suffices.  Used for F::from_be_bytes_mod_order (transcript/src/lib.rs:29).
+ZK_HD Fe fe_reduce_u256(const uint32_t x[8], const FieldParams &P) {
+    uint32_t s[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            uint32_t pk;
-            if (k == 0) pk = (i < 8) ? P.p[i] : 0u;
-            else pk = ((i < 8) ? (P.p[i] << k) : 0u) | ((i > 0) ? (P.p[i - 1] >> (32 - k)) : 0u);
-            uint64_t dd = (uint64_t)s[i] - pk - borrow;
-            d[i] = (uint32_t)dd;
-            borrow = (uint32_t)(dd >> 63);
-        }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) s[i] = borrow ? s[i] : d[i];
-    }
+    for (int i = 0; i < 8; ++i) s[i] = x[i];
+    s[8] = 0;
+    ladder9<4>(s, P);
     Fe r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.v[i] = s[i];

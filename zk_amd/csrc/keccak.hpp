@@ -135,4 +135,73 @@ struct Sponge {
     }
 };
 
+
+// The same sponge kept as 64-bit lanes with a WORD cursor: every message the prover absorbs is a whole number of
+// 8-byte words (32-byte big-endian elements, 32-byte digests, tables of 32-byte elements), so no byte buffer is needed
+// and the state lives in registers of a single GPU lane.  Absorbing the 32-byte big-endian image of a 256-bit integer
+// with little-endian u64 limbs l0..l3 XORs bswap(l3), bswap(l2), bswap(l1), bswap(l0) into consecutive lanes.
+struct WordSponge {
+    uint64_t s[25];
+    uint32_t pos;   // next lane to absorb into, 0..16
+    uint32_t pad_;
+
+    ZKK_HD static uint64_t bswap64(uint64_t x) { return __builtin_bswap64(x); }
+    ZKK_HD void init() {
+        for (int i = 0; i < 25; ++i) s[i] = 0;
+        pos = 0;
+        pad_ = 0;
+    }
+    ZKK_HD void absorb_word(uint64_t w) {
+        // pos is data dependent: select the lane without dynamic register indexing
+#pragma unroll
+        for (int i = 0; i < 17; ++i)
+            if ((uint32_t)i == pos) s[i] ^= w;
+        if (++pos == 17) {
+            keccak_f1600(s);
+            pos = 0;
+        }
+    }
+    // 32-byte big-endian image of the integer with LE u64 limbs l[0..4)
+    ZKK_HD void absorb_u256_be(const uint64_t l[4]) {
+        absorb_word(bswap64(l[3]));
+        absorb_word(bswap64(l[2]));
+        absorb_word(bswap64(l[1]));
+        absorb_word(bswap64(l[0]));
+    }
+    // transcript/src/lib.rs:20-25: digest = finalize_reset(); update(digest).  Returns the digest as the LE u64 limbs
+    // of int(digest, big endian) -- the integer from_be_bytes_mod_order reduces (transcript/src/lib.rs:29).
+    ZKK_HD void sample_challenge_u256(uint64_t out_le_limbs[4]) {
+#pragma unroll
+        for (int i = 0; i < 17; ++i)
+            if ((uint32_t)i == pos) s[i] ^= 0x01ull;
+        s[16] ^= 0x8000000000000000ull;
+        keccak_f1600(s);
+        const uint64_t d0 = s[0], d1 = s[1], d2 = s[2], d3 = s[3];
+        out_le_limbs[0] = bswap64(d3);
+        out_le_limbs[1] = bswap64(d2);
+        out_le_limbs[2] = bswap64(d1);
+        out_le_limbs[3] = bswap64(d0);
+        for (int i = 0; i < 25; ++i) s[i] = 0;
+        s[0] = d0;
+        s[1] = d1;
+        s[2] = d2;
+        s[3] = d3;
+        pos = 4;
+    }
+    // continue a byte sponge whose buffered length is a multiple of 8 (always true for the prover's messages)
+    ZKK_HD bool from_byte_sponge(const Sponge &b) {
+        if (b.fill % 8) return false;
+        for (int i = 0; i < 25; ++i) s[i] = b.s[i];
+        pos = 0;
+        pad_ = 0;
+        for (uint32_t w = 0; w < b.fill / 8; ++w) {
+            uint64_t x = 0;
+            for (int k = 0; k < 8; ++k) x |= (uint64_t)b.buf[8 * w + k] << (8 * k);
+            s[w] ^= x;
+        }
+        pos = b.fill / 8;
+        return true;
+    }
+};
+
 }  // namespace zk

@@ -33,7 +33,7 @@ ZK_D uint64_t insert_zero_bit(uint64_t val, uint32_t pos) {
 // out[j] = left - r*(left - right), (left,right) = index_pair(m, initial_var)[j], pos = m-1-initial_var.
 // The reference's r==0 / r==1 shortcuts (:61-62) are the same values, so they are not special-cased.
 // Out of place (in != out) for general pos; in place is race-free only for the MSB fold (pos = m-1).
-__global__ __launch_bounds__(kBlock) void k_fold(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+__global__ __launch_bounds__(kBlock) void k_fold(const uint64_t *in, uint64_t *out,
                                                  uint64_t pairs, uint32_t pos, FieldParams P, Fe r) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < pairs; j += stride) {
@@ -42,6 +42,20 @@ __global__ __launch_bounds__(kBlock) void k_fold(const uint64_t *__restrict__ in
         const Fe hi = fe_load(in, l | (1ull << pos));
         const Fe d = fe_sub(lo, hi, P);
         fe_store(out, j, fe_sub(lo, fe_mul(r, d, P), P));
+    }
+}
+
+// same fold with the challenge read from device memory (produced by the on-device transcript); m = variables of `in`,
+// always the MSB fold.  `pairs` = 2^(m-1).
+__global__ __launch_bounds__(kBlock) void k_fold_dev(const uint64_t *in, uint64_t *out, uint64_t pairs, uint32_t m,
+                                                     FieldParams P, const uint64_t *__restrict__ rptr) {
+    (void)m;
+    const Fe r = fe_load(rptr, 0);
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < pairs; j += stride) {
+        const Fe lo = fe_load(in, j);
+        const Fe hi = fe_load(in, j + pairs);
+        fe_store(out, j, fe_sub(lo, fe_mul(r, fe_sub(lo, hi, P), P), P));
     }
 }
 
@@ -101,9 +115,16 @@ ZK_D void block_reduce_store(Fe (&sum)[NS], uint64_t *__restrict__ partials, con
 // kMaxLazy pairs; sums of Montgomery products are exact, so the reduced result is the same canonical element.
 // In-place (out == in) is race-free: index j and j+q are read and written only by the thread that owns j.
 template <int D, bool FUSED>
-__global__ __launch_bounds__(kBlock) void k_round(FactorPtrs fp, int k, uint64_t q, FieldParams P, Fe r,
-                                                  uint64_t *__restrict__ partials) {
+__global__ __launch_bounds__(kBlock) void k_round(FactorPtrs fp, int k, uint64_t q, FieldParams P,
+                                                  const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials) {
     constexpr int NS = D + 1;
+    // the previous round's challenge is produced on the device by k_round_tail (no host round trip)
+    Fe r = fe_zero();
+    if (FUSED) {
+        r = fe_load(rptr, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.v[i] = __builtin_amdgcn_readfirstlane(r.v[i]);   // wave-uniform -> SGPRs
+    }
     Fe sum[NS];
     WideAcc acc[NS];
 #pragma unroll
@@ -173,10 +194,44 @@ __global__ __launch_bounds__(kBlock) void k_round_single_t(FactorPtrs fp, int k,
     block_reduce_store<1>(sum, partials, P);
 }
 
-// Second stage of the round sums: one workgroup adds the per-block partials -> out[t], t < ns (Montgomery form).
-__global__ __launch_bounds__(kBlock) void k_final_sums(const uint64_t *__restrict__ partials, uint32_t nblocks,
-                                                       uint32_t ns, uint64_t *__restrict__ out, FieldParams P) {
+// ---- device-side Fiat-Shamir step (sumcheck/src/prover.rs:59-62 on one GPU lane) --------------------------------------
+// absorb the round polynomial (32-byte BE canonical elements, sumcheck/src/lib.rs:23-29), squeeze the challenge
+// (transcript/src/lib.rs:20-30) and publish it in Montgomery form for the next round's fused fold.
+ZK_D void transcript_round(WordSponge *__restrict__ gsp, const Fe *sums, uint32_t ns, uint64_t *__restrict__ d_challenge,
+                           uint64_t *__restrict__ out_ch, const FieldParams &P) {
+    WordSponge sp = *gsp;
+    for (uint32_t t = 0; t < ns; ++t) {
+        const Fe c = fe_to_canonical(sums[t], P);
+        uint64_t l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l[i] = (uint64_t)c.v[2 * i] | ((uint64_t)c.v[2 * i + 1] << 32);
+        sp.absorb_u256_be(l);
+    }
+    uint64_t h[4];
+    sp.sample_challenge_u256(h);
+    uint32_t x[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[2 * i] = (uint32_t)h[i];
+        x[2 * i + 1] = (uint32_t)(h[i] >> 32);
+    }
+    const Fe ch = fe_from_canonical(fe_reduce_u256(x, P), P);
+    fe_store(d_challenge, 0, ch);
+    if (out_ch) fe_store(out_ch, 0, ch);
+    *gsp = sp;
+}
+
+// Second stage of a round: one workgroup adds the per-block partials -> ns sums (Montgomery form); then, on lane 0,
+//   out_rp   != null : store the sums (the round polynomial);
+//   lanes    != null : store them as 8 zero-extended 32-bit digits per element (uint64 lanes) for the cross-GPU
+//                      all-reduce (RCCL has no mod-p sum; integer lane sums cannot overflow);
+//   sponge   != null : run the transcript step and publish the challenge.
+__global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restrict__ partials, uint32_t nblocks, uint32_t ns,
+                                                       WordSponge *__restrict__ sponge, uint64_t *__restrict__ out_rp,
+                                                       uint64_t *__restrict__ out_ch, uint64_t *__restrict__ d_challenge,
+                                                       uint64_t *__restrict__ lanes, FieldParams P) {
     __shared__ uint32_t red[kBlock / 64][8];
+    __shared__ Fe fin[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t t = 0; t < ns; ++t) {
         Fe s = fe_zero();
@@ -203,9 +258,53 @@ __global__ __launch_bounds__(kBlock) void k_final_sums(const uint64_t *__restric
                 for (int i = 0; i < 8; ++i) o.v[i] = red[w][i];
                 acc = fe_add(acc, o, P);
             }
-            fe_store(out, t, acc);
+            fin[t] = acc;
         }
         __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        for (uint32_t t = 0; t < ns; ++t) {
+            if (out_rp) fe_store(out_rp, t, fin[t]);
+            if (lanes)
+                for (int i = 0; i < 8; ++i) lanes[8 * t + i] = (uint64_t)fin[t].v[i];
+        }
+        if (sponge) transcript_round(sponge, fin, ns, d_challenge, out_ch, P);
+    }
+}
+
+// Sharded prover, after the all-reduce: lanes hold sums over ranks of 32-bit digits.  Carry-propagate, reduce mod p
+// (value < world * p, world <= 2^16), then the same transcript step.  One lane.
+__global__ void k_lanes_transcript(const uint64_t *__restrict__ lanes, uint32_t ns, WordSponge *__restrict__ sponge,
+                                   uint64_t *__restrict__ out_rp, uint64_t *__restrict__ out_ch,
+                                   uint64_t *__restrict__ d_challenge, FieldParams P) {
+    __shared__ Fe fin[256];
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (uint32_t t = 0; t < ns; ++t) {
+        uint32_t v[9];
+        uint64_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            carry += lanes[8 * t + i];
+            v[i] = (uint32_t)carry;
+            carry >>= 32;
+        }
+        v[8] = (uint32_t)carry;
+        ladder9<16>(v, P);
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.v[i] = v[i];
+        fin[t] = r;
+        fe_store(out_rp, t, r);
+    }
+    transcript_round(sponge, fin, ns, d_challenge, out_ch, P);
+}
+
+// transpose the all-gathered tail elements [rank][factor] into k tables of `world` elements (table_f[rank])
+__global__ void k_gather_to_tables(const uint64_t *__restrict__ gathered, FactorPtrs fp, uint32_t k, uint32_t world) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k * world) {
+        const uint32_t rank = i / k, f = i % k;
+        fe_store(fp.out[f], rank, fe_load(gathered, i));
     }
 }
 

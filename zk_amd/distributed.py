@@ -1,0 +1,124 @@
+"""Sumcheck prover over a table sharded across the GPUs of one node.
+
+The reference (sumcheck/src/prover.rs:33-73) is a single-process loop; this module is its multi-GPU form: one process
+per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI) for the one exchange per round.
+
+Sharding.  The reference folds variable 0 = the index MSB first (pairing_index.rs:61-65), pairing j with
+j + 2^(m-1).  Rank g of W = 2^w holds {idx : idx mod W == g} (the LAST w variables select the rank) as an
+(n-w)-variable table with local index idx >> w.  Then every pair of rounds 0 .. n-w-1 is local, every rank runs the
+same rounds with the same challenges, and the global round sums are the field sums of the local ones:
+
+    per round:  local (fold +) sums  ->  ONE all-reduce of (D+1)*8 int64 lanes  ->  transcript step on every rank
+
+(the lanes are the 32-bit digits of the Montgomery representatives; integer lane sums are exact and cannot overflow,
+RCCL has no mod-p reduction).  After n-w rounds every rank holds one element per factor; one all-gather of W*k
+elements gives the w-variable remainder (indexed by rank = the low index bits, i.e. in the reference's own order)
+and every rank finishes the last w rounds redundantly -- W elements, no further collective.
+
+`ShardedSumcheckProver` is the orchestration (host logic, backend-agnostic: tests drive it over gloo on CPU with a
+checker backend); `GpuShardBackend` is the product backend over the C ABI (zk_shard_prover_*).
+"""
+import numpy as np
+
+from ._lib import c, check, lib, u64p
+
+
+def shard_of(table, rank, world):
+    """Rows {idx : idx mod world == rank} of a (2^n, 4) table, in local-index order (idx >> log2 world)."""
+    t = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
+    return np.ascontiguousarray(t[rank::world])
+
+
+class _DevArray:
+    """Zero-copy view of a device buffer for torch.as_tensor (__cuda_array_interface__ v2)."""
+
+    def __init__(self, ptr, n_int64):
+        self.__cuda_array_interface__ = {"shape": (n_int64,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+
+class GpuShardBackend:
+    """One rank's share of the prover on its GPU (zk_shard_prover_* in include/zk_amd.h)."""
+
+    def __init__(self, poly, max_var_degree, claimed_sum, world):
+        import torch
+
+        self.ctx, self.poly = poly.ctx, poly
+        self.ctx.use_torch_stream()   # kernels, lane all-reduce and tail all-gather are ordered on one stream
+        self.k, self.D, self.world = len(poly.polynomials), max_var_degree, world
+        s = np.ascontiguousarray(claimed_sum, dtype=np.uint64).reshape(4)
+        arr = (c.c_void_p * self.k)(*[q._h for q in poly.polynomials])
+        h = c.c_void_p()
+        check(lib.zk_shard_prover_create(self.ctx._h, c.cast(arr, c.POINTER(c.c_void_p)), self.k, self.D,
+                                         s.ctypes.data_as(u64p), world, c.byref(h)))
+        self._h = h
+        loc, tot = c.c_uint64(), c.c_uint64()
+        check(lib.zk_shard_prover_rounds(h, c.byref(loc), c.byref(tot), None))
+        self.local_rounds, self.total_rounds = loc.value, tot.value
+        p, n = c.c_void_p(), c.c_uint64()
+        check(lib.zk_shard_prover_lanes_ptr(h, c.byref(p), c.byref(n)))
+        self.lanes = torch.as_tensor(_DevArray(p.value, n.value), device=f"cuda:{self.ctx.device}")
+        self._torch = torch
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.zk_shard_prover_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def round_begin(self):
+        check(lib.zk_shard_prover_round_begin(self._h))
+        return self.lanes
+
+    def round_finish(self):
+        check(lib.zk_shard_prover_round_finish(self._h))
+
+    def tail(self):
+        p, n = c.c_void_p(), c.c_uint64()
+        check(lib.zk_shard_prover_tail_ptr(self._h, c.byref(p), c.byref(n)))
+        return self._torch.as_tensor(_DevArray(p.value, n.value * 4), device=f"cuda:{self.ctx.device}")
+
+    def tail_rounds(self, gathered):
+        self._gathered = gathered.contiguous()   # keep alive until the stream has consumed it
+        check(lib.zk_shard_prover_tail_rounds(self._h, c.c_void_p(self._gathered.data_ptr())))
+
+    def results(self):
+        rp = np.zeros((self.total_rounds, self.D + 1, 4), dtype=np.uint64)
+        ch = np.zeros((max(self.total_rounds, 1), 4), dtype=np.uint64)
+        check(lib.zk_shard_prover_results(self._h, rp.ctypes.data_as(u64p), ch.ctypes.data_as(u64p)))
+        return rp, ch[: self.total_rounds]
+
+
+class ShardedSumcheckProver:
+    """SumcheckProver::prove_partial (prover.rs:24-30) for a table sharded over the ranks of `group`.
+
+    backend: an object with local_rounds, total_rounds, round_begin() -> int64 lane tensor, round_finish(), tail() ->
+    int64 tensor of k*4, tail_rounds(gathered), results().  Every rank returns the same
+    (round_polys, challenges) as the single-process prover on the unsharded table.
+    """
+
+    def __init__(self, backend, group=None):
+        self.backend, self.group = backend, group
+
+    def prove_partial(self):
+        import torch.distributed as dist
+
+        b = self.backend
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        for _ in range(b.local_rounds):
+            lanes = b.round_begin()
+            if multi:
+                dist.all_reduce(lanes, op=dist.ReduceOp.SUM, group=self.group)   # the round's one collective
+            b.round_finish()
+        tail = b.tail()
+        if multi:
+            import torch
+
+            parts = [torch.empty_like(tail) for _ in range(dist.get_world_size(self.group))]
+            dist.all_gather(parts, tail, group=self.group)                       # once, W*k elements, rank-major
+            gathered = torch.cat(parts)
+        else:
+            gathered = tail
+        b.tail_rounds(gathered)
+        return b.results()
