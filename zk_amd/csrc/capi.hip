@@ -15,6 +15,7 @@
 #include "../../include/zk_amd.h"
 #include "host_field.hpp"
 #include "kernels.cuh"
+#include "launch.hpp"
 #include "keccak.hpp"
 
 using namespace zk;
@@ -45,7 +46,8 @@ struct zk_transcript {
     Sponge sp;
 };
 
-static constexpr uint32_t kMaxGrid = 2048;    // 8 workgroups per CU on 256 CUs
+static constexpr uint32_t kMaxGrid = 2048;    // round kernels: 8 workgroups per CU on 256 CUs (partials are sized for it)
+static constexpr uint32_t kMaxGridStream = 16384;   // pure streaming kernels (fold): measured +10% over 2048 at 2^24
 static constexpr uint32_t kMaxSums = 256;     // max_var_degree is a u8 in the reference (prover.rs:9)
 static constexpr uint64_t kMaxVars = 40;
 
@@ -356,7 +358,9 @@ extern "C" int32_t zk_mle_device_ptr(const zk_mle *t, void **out) {
 static int32_t launch_fold(zk_ctx *c, const uint64_t *in, uint64_t *out, uint64_t m, uint64_t initial_var, const Fe &r) {
     const uint64_t pairs = 1ull << (m - 1);
     const uint32_t pos = (uint32_t)(m - 1 - initial_var);
-    k_fold<<<grid_for(pairs), kBlock, 0, c->stream>>>(in, out, pairs, pos, c->fi->P, r);
+    uint64_t g = (pairs + kBlock - 1) / kBlock;
+    if (g > kMaxGridStream) g = kMaxGridStream;
+    k_fold<<<(uint32_t)(g ? g : 1), kBlock, 0, c->stream>>>(in, out, pairs, pos, c->fi->P, r);
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
@@ -546,21 +550,9 @@ static void scratch_free(zk_ctx *c, ProverScratch &ps) {
     ps = {};
 }
 
-template <bool FUSED>
-static int32_t launch_round_kernel(zk_ctx *c, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, const uint64_t *d_r,
-                                   uint32_t *out_grid) {
-    const uint32_t g = grid_for(q);
-    const FieldParams &P = c->fi->P;
-    switch (D) {
-        case 1: k_round<1, FUSED><<<g, kBlock, 0, c->stream>>>(fp, k, q, P, d_r, c->d_partials); break;
-        case 2: k_round<2, FUSED><<<g, kBlock, 0, c->stream>>>(fp, k, q, P, d_r, c->d_partials); break;
-        case 3: k_round<3, FUSED><<<g, kBlock, 0, c->stream>>>(fp, k, q, P, d_r, c->d_partials); break;
-        case 4: k_round<4, FUSED><<<g, kBlock, 0, c->stream>>>(fp, k, q, P, d_r, c->d_partials); break;
-        default: return ZK_ERR_UNSUPPORTED;
-    }
-    HIPCHK(hipGetLastError());
-    *out_grid = g;
-    return ZK_OK;
+static inline RoundLaunchCtx launch_ctx(zk_ctx *c) {
+    RoundLaunchCtx lc = {c->stream, &c->fi->P, c->d_partials, (uint64_t)kMaxGrid * kMaxSums};
+    return lc;
 }
 static inline bool fast_degree(uint32_t D) { return D >= 1 && D <= 4; }
 
@@ -578,18 +570,24 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, int k, uint64_t q, u
     const FieldParams &P = c->fi->P;
     if (fast_degree(D)) {
         uint32_t g = 0;
-        if (fused) ZKCHK(launch_round_kernel<true>(c, fp, k, q, D, d_r, &g));
-        else ZKCHK(launch_round_kernel<false>(c, fp, k, q, D, d_r, &g));
+        const int lrc = launch_round(launch_ctx(c), fp, k, q, D, fused, d_r, &g);
+        if (lrc == kLaunchUnsupported) return ZK_ERR_UNSUPPORTED;
+        if (lrc != kLaunchOk) {
+            g_hip_err = "round kernel launch failed";
+            return ZK_ERR_HIP;
+        }
         k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, g, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
                                                   tt.lanes, P);
         HIPCHK(hipGetLastError());
         return ZK_OK;
     }
     // any other degree (0, or > 4): one pass per evaluation point over tables that are already folded
-    const uint32_t g = grid_for(q);
     for (uint32_t t = 0; t <= D; ++t) {
-        k_round_single_t<<<g, kBlock, 0, c->stream>>>(fp, k, q, P, fe_from_u32(t, P), c->d_partials);
-        HIPCHK(hipGetLastError());
+        uint32_t g = 0;
+        if (launch_round_single_t(launch_ctx(c), fp, k, q, fe_from_u32(t, P), &g) != kLaunchOk) {
+            g_hip_err = "round kernel launch failed";
+            return ZK_ERR_HIP;
+        }
         k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, g, 1, nullptr, c->d_sums + 4 * t, nullptr, nullptr, nullptr, P);
         HIPCHK(hipGetLastError());
     }

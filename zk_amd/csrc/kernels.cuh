@@ -9,19 +9,10 @@
 // These are HBM-streaming integer kernels: no LDS tiling is needed for the fold itself (no reuse), LDS is used
 // for the workgroup reductions of the round sums.  No MFMA (256-bit modular integer ops).
 #pragma once
-#include "field.cuh"
+#include "common.cuh"
 #include "keccak.hpp"
 
 namespace zk {
-
-constexpr int kBlock = 256;
-constexpr int kMaxFactors = 8;
-constexpr int kMaxLazy = 16;   // products accumulated unreduced between Montgomery reductions (see redc_wide)
-
-struct FactorPtrs {
-    const uint64_t *in[kMaxFactors];
-    uint64_t *out[kMaxFactors];
-};
 
 // pairing_index.rs:16-20 insert_bit(val, index, 0)
 ZK_D uint64_t insert_zero_bit(uint64_t val, uint32_t pos) {
@@ -70,141 +61,29 @@ __global__ __launch_bounds__(kBlock) void k_prod_reduce(FactorPtrs fp, int k, ui
     }
 }
 
-// ---- workgroup reduction of NS field elements per thread -> partials[block][NS] -------------------------------
-template <int NS>
-ZK_D void block_reduce_store(Fe (&sum)[NS], uint64_t *__restrict__ partials, const FieldParams &P) {
-    __shared__ uint32_t red[kBlock / 64][NS][8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            Fe o;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o.v[i] = __shfl_xor(sum[t].v[i], off, 64);
-            sum[t] = fe_add(sum[t], o, P);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) red[wave][t][i] = sum[t].v[i];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < NS) {
-        const int t = threadIdx.x;
-        Fe acc;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc.v[i] = red[0][t][i];
-        for (int w = 1; w < kBlock / 64; ++w) {
-            Fe o;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o.v[i] = red[w][t][i];
-            acc = fe_add(acc, o, P);
-        }
-        fe_store(partials, (uint64_t)blockIdx.x * NS + t, acc);
-    }
-}
-
-// ---- one sumcheck round (sumcheck/src/prover.rs:44-68), fused ---------------------------------------------------
-// Computes the round polynomial in evaluation form, S_t = sum_x prod_f P_f(t, x) for t = 0..D, over the table pairs
-// (lo, hi) = (T[j], T[j+q]).  With FUSED the pairs are first produced by folding the PREVIOUS round's table at its
-// challenge r (prover.rs:64: T'[j] = T[j] - r*(T[j] - T[j+2q])), written back for the next round and used from
-// registers -- one pass over HBM per round instead of the reference's (D+2)*k folds + (D+1) prod_reduce + sums.
-//   P_f(t, x) = lo + t*(hi - lo)  ==  left - F::from(t)*(left - right)   (evaluation_form.rs:68; exact in F_p)
-// For k >= 2 the last factor's products are accumulated UNREDUCED (512+ bits) and Montgomery-reduced once per
-// kMaxLazy pairs; sums of Montgomery products are exact, so the reduced result is the same canonical element.
-// In-place (out == in) is race-free: index j and j+q are read and written only by the thread that owns j.
-template <int D, bool FUSED>
-__global__ __launch_bounds__(kBlock) void k_round(FactorPtrs fp, int k, uint64_t q, FieldParams P,
-                                                  const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials) {
-    constexpr int NS = D + 1;
-    // the previous round's challenge is produced on the device by k_round_tail (no host round trip)
-    Fe r = fe_zero();
-    if (FUSED) {
-        r = fe_load(rptr, 0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r.v[i] = __builtin_amdgcn_readfirstlane(r.v[i]);   // wave-uniform -> SGPRs
-    }
-    Fe sum[NS];
-    WideAcc acc[NS];
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-        sum[t] = fe_zero();
-        wide_zero(acc[t]);
-    }
-    int lazy = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < q; j += stride) {
-        Fe prod[NS];
-        for (int f = 0; f < k; ++f) {
-            Fe lo, hi;
-            if (FUSED) {
-                const Fe a0 = fe_load(fp.in[f], j), a1 = fe_load(fp.in[f], j + q);
-                const Fe a2 = fe_load(fp.in[f], j + 2 * q), a3 = fe_load(fp.in[f], j + 3 * q);
-                lo = fe_sub(a0, fe_mul(r, fe_sub(a0, a2, P), P), P);
-                hi = fe_sub(a1, fe_mul(r, fe_sub(a1, a3, P), P), P);
-                fe_store(fp.out[f], j, lo);
-                fe_store(fp.out[f], j + q, hi);
-            } else {
-                lo = fe_load(fp.in[f], j);
-                hi = fe_load(fp.in[f], j + q);
-            }
-            const Fe diff = fe_sub(hi, lo, P);
-            Fe v = lo;
-#pragma unroll
-            for (int t = 0; t < NS; ++t) {
-                if (t == 1) v = hi;
-                else if (t > 1) v = fe_add(v, diff, P);
-                if (k == 1) sum[t] = fe_add(sum[t], v, P);
-                else if (f == 0) prod[t] = v;
-                else if (f < k - 1) prod[t] = fe_mul(prod[t], v, P);
-                else wide_mac(acc[t], prod[t].v, v.v);
-            }
-        }
-        if (k > 1 && ++lazy == kMaxLazy) {
-#pragma unroll
-            for (int t = 0; t < NS; ++t) {
-                sum[t] = fe_add(sum[t], redc_wide(acc[t], P), P);
-                wide_zero(acc[t]);
-            }
-            lazy = 0;
-        }
-    }
-    if (k > 1 && lazy) {
-#pragma unroll
-        for (int t = 0; t < NS; ++t) sum[t] = fe_add(sum[t], redc_wide(acc[t], P), P);
-    }
-    block_reduce_store<NS>(sum, partials, P);
-}
-
-// Generic-degree fallback: one evaluation point t per launch (any D up to 255, any k <= kMaxFactors).
-__global__ __launch_bounds__(kBlock) void k_round_single_t(FactorPtrs fp, int k, uint64_t q, FieldParams P, Fe tval,
-                                                           uint64_t *__restrict__ partials) {
-    Fe sum[1] = {fe_zero()};
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < q; j += stride) {
-        Fe prod = fe_zero();
-        for (int f = 0; f < k; ++f) {
-            const Fe lo = fe_load(fp.in[f], j), hi = fe_load(fp.in[f], j + q);
-            const Fe v = fe_sub(lo, fe_mul(tval, fe_sub(lo, hi, P), P), P);
-            prod = (f == 0) ? v : fe_mul(prod, v, P);
-        }
-        sum[0] = fe_add(sum[0], prod, P);
-    }
-    block_reduce_store<1>(sum, partials, P);
-}
-
 // ---- device-side Fiat-Shamir step (sumcheck/src/prover.rs:59-62 on one GPU lane) --------------------------------------
 // absorb the round polynomial (32-byte BE canonical elements, sumcheck/src/lib.rs:23-29), squeeze the challenge
 // (transcript/src/lib.rs:20-30) and publish it in Montgomery form for the next round's fused fold.
-ZK_D void transcript_round(WordSponge *__restrict__ gsp, const Fe *sums, uint32_t ns, uint64_t *__restrict__ d_challenge,
-                           uint64_t *__restrict__ out_ch, const FieldParams &P) {
-    WordSponge sp = *gsp;
+// Runs on ALL lanes of one wave with wave-uniform data: the sponge state and the sums are forced into SGPRs
+// (readfirstlane), so the 24 Keccak rounds compile to 64-bit SCALAR ALU ops (s_xor_b64, s_andn2_b64, s_lshl_b64 ...)
+// instead of a single active lane's VALU stream -- several times faster for this latency-critical serial step.
+ZK_D uint64_t uniform64(uint64_t x) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+ZK_D void transcript_round(WordSponge *gsp, const Fe *sums, uint32_t ns, uint64_t *d_challenge, uint64_t *out_ch,
+                           const FieldParams &P) {
+    WordSponge sp;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) sp.s[i] = uniform64(gsp->s[i]);
+    sp.pos = __builtin_amdgcn_readfirstlane(gsp->pos);
+    sp.pad_ = 0;
     for (uint32_t t = 0; t < ns; ++t) {
         const Fe c = fe_to_canonical(sums[t], P);
         uint64_t l[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) l[i] = (uint64_t)c.v[2 * i] | ((uint64_t)c.v[2 * i + 1] << 32);
+        for (int i = 0; i < 4; ++i) l[i] = uniform64((uint64_t)c.v[2 * i] | ((uint64_t)c.v[2 * i + 1] << 32));
         sp.absorb_u256_be(l);
     }
     uint64_t h[4];
@@ -216,9 +95,13 @@ ZK_D void transcript_round(WordSponge *__restrict__ gsp, const Fe *sums, uint32_
         x[2 * i + 1] = (uint32_t)(h[i] >> 32);
     }
     const Fe ch = fe_from_canonical(fe_reduce_u256(x, P), P);
-    fe_store(d_challenge, 0, ch);
-    if (out_ch) fe_store(out_ch, 0, ch);
-    *gsp = sp;
+    if ((threadIdx.x & 63) == 0) {
+        fe_store(d_challenge, 0, ch);
+        if (out_ch) fe_store(out_ch, 0, ch);
+#pragma unroll
+        for (int i = 0; i < 25; ++i) gsp->s[i] = sp.s[i];
+        gsp->pos = sp.pos;
+    }
 }
 
 // Second stage of a round: one workgroup adds the per-block partials -> ns sums (Montgomery form); then, on lane 0,
@@ -268,8 +151,8 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
             if (lanes)
                 for (int i = 0; i < 8; ++i) lanes[8 * t + i] = (uint64_t)fin[t].v[i];
         }
-        if (sponge) transcript_round(sponge, fin, ns, d_challenge, out_ch, P);
     }
+    if (sponge && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) transcript_round(sponge, fin, ns, d_challenge, out_ch, P);
 }
 
 // Sharded prover, after the all-reduce: lanes hold sums over ranks of 32-bit digits.  Carry-propagate, reduce mod p
@@ -278,7 +161,7 @@ __global__ void k_lanes_transcript(const uint64_t *__restrict__ lanes, uint32_t 
                                    uint64_t *__restrict__ out_rp, uint64_t *__restrict__ out_ch,
                                    uint64_t *__restrict__ d_challenge, FieldParams P) {
     __shared__ Fe fin[256];
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;   // one wave, uniform control flow
     for (uint32_t t = 0; t < ns; ++t) {
         uint32_t v[9];
         uint64_t carry = 0;
@@ -293,9 +176,12 @@ __global__ void k_lanes_transcript(const uint64_t *__restrict__ lanes, uint32_t 
         Fe r;
 #pragma unroll
         for (int i = 0; i < 8; ++i) r.v[i] = v[i];
-        fin[t] = r;
-        fe_store(out_rp, t, r);
+        if (threadIdx.x == 0) {
+            fin[t] = r;
+            fe_store(out_rp, t, r);
+        }
     }
+    __syncthreads();
     transcript_round(sponge, fin, ns, d_challenge, out_ch, P);
 }
 

@@ -1,0 +1,219 @@
+// round_kernels.cuh -- the sumcheck round kernels (sumcheck/src/prover.rs:44-68 on the GPU).  Own translation unit
+// (rounds.hip): these are the heavy instantiations.
+#pragma once
+#include "common.cuh"
+
+namespace zk {
+
+// ---- workgroup reduction of NS field elements per thread -> partials[block][NS] -------------------------------
+template <int NS>
+ZK_D void block_reduce_store(Fe (&sum)[NS], uint64_t *__restrict__ partials, const FieldParams &P) {
+    __shared__ uint32_t red[kBlock / 64][NS][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            Fe o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] = __shfl_xor(sum[t].v[i], off, 64);
+            sum[t] = fe_add(sum[t], o, P);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[wave][t][i] = sum[t].v[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        const int t = threadIdx.x;
+        Fe acc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc.v[i] = red[0][t][i];
+        for (int w = 1; w < kBlock / 64; ++w) {
+            Fe o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] = red[w][t][i];
+            acc = fe_add(acc, o, P);
+        }
+        fe_store(partials, (uint64_t)blockIdx.x * NS + t, acc);
+    }
+}
+
+// ---- one sumcheck round (sumcheck/src/prover.rs:44-68), fused ---------------------------------------------------
+// Computes the round polynomial in evaluation form, S_t = sum_x prod_f P_f(t, x) for t = 0..D, over the table pairs
+// (lo, hi) = (T[j], T[j+q]).  With FUSED the pairs are first produced by folding the PREVIOUS round's table at its
+// challenge r (prover.rs:64: T'[j] = T[j] - r*(T[j] - T[j+2q])), written back for the next round and used from
+// registers -- one pass over HBM per round instead of the reference's (D+2)*k folds + (D+1) prod_reduce + sums.
+//   P_f(t, x) = lo + t*(hi - lo)  ==  left - F::from(t)*(left - right)   (evaluation_form.rs:68; exact in F_p)
+// For k >= 2 the last factor's products are accumulated UNREDUCED (512+ bits) and Montgomery-reduced once per
+// kMaxLazy pairs; sums of Montgomery products are exact, so the reduced result is the same canonical element.
+// In-place (out == in) is race-free: index j and j+q are read and written only by the thread that owns j.
+template <int D, bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_round(FactorPtrs fp, int k, uint64_t q, FieldParams P,
+                                                  const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials) {
+    constexpr int NS = D + 1;
+    // the previous round's challenge is produced on the device by k_round_tail (no host round trip)
+    Fe r = fe_zero();
+    if (FUSED) {
+        r = fe_load(rptr, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.v[i] = __builtin_amdgcn_readfirstlane(r.v[i]);   // wave-uniform -> SGPRs
+    }
+    Fe sum[NS];
+    WideAcc acc[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        sum[t] = fe_zero();
+        wide_zero(acc[t]);
+    }
+    int lazy = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < q; j += stride) {
+        Fe prod[NS];
+        for (int f = 0; f < k; ++f) {
+            Fe lo, hi;
+            if (FUSED) {
+                const Fe a0 = fe_load(fp.in[f], j), a1 = fe_load(fp.in[f], j + q);
+                const Fe a2 = fe_load(fp.in[f], j + 2 * q), a3 = fe_load(fp.in[f], j + 3 * q);
+                lo = fe_sub(a0, fe_mul(r, fe_sub(a0, a2, P), P), P);
+                hi = fe_sub(a1, fe_mul(r, fe_sub(a1, a3, P), P), P);
+                fe_store(fp.out[f], j, lo);
+                fe_store(fp.out[f], j + q, hi);
+            } else {
+                lo = fe_load(fp.in[f], j);
+                hi = fe_load(fp.in[f], j + q);
+            }
+            const Fe diff = fe_sub(hi, lo, P);
+            Fe v = lo;
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                if (t == 1) v = hi;
+                else if (t > 1) v = fe_add(v, diff, P);
+                if (k == 1) sum[t] = fe_add(sum[t], v, P);
+                else if (f == 0) prod[t] = v;
+                else if (f < k - 1) prod[t] = fe_mul(prod[t], v, P);
+                else wide_mac(acc[t], prod[t].v, v.v);
+            }
+        }
+        if (k > 1 && ++lazy == kMaxLazy) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                sum[t] = fe_add(sum[t], redc_wide(acc[t], P), P);
+                wide_zero(acc[t]);
+            }
+            lazy = 0;
+        }
+    }
+    if (k > 1 && lazy) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) sum[t] = fe_add(sum[t], redc_wide(acc[t], P), P);
+    }
+    block_reduce_store<NS>(sum, partials, P);
+}
+
+// ---- the same round, specialised: K factors and degree D at compile time ------------------------------------------
+// This is the kernel the prover normally runs (the common (k, D) shapes).  Differences from k_round above, all scheduling:
+//  * every load of a pair-index j is issued before any arithmetic, and the loads of the thread's NEXT j are issued the
+//    moment a factor's registers have been consumed, so a wave hides its own HBM latency (the arithmetic of one j is
+//    ~7.7k cycles per wave, several times the memory latency) even at 2 waves per SIMD;
+//  * the host sizes the grid so that a thread handles at most kMaxLazy pairs: the unreduced accumulators are reduced
+//    once, after the loop (no flush path, no separate running sums in registers);
+//  * factor indices are template parameters (round_factor<F>), so every array index is static and nothing spills.
+template <int K, int D, bool FUSED>
+struct RoundRegs {
+    static constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
+    Fe cur[K][NL];
+    Fe prod[NS];
+    Fe sum[NS];
+    WideAcc acc[K > 1 ? NS : 1];
+};
+template <int F, int K, int D, bool FUSED>
+ZK_D void round_factor(RoundRegs<K, D, FUSED> &R, const FactorPtrs &fp, uint64_t j, uint64_t jn, bool more, uint64_t q,
+                       const Fe &r, const FieldParams &P) {
+    constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
+    Fe lo, hi;
+    if (FUSED) {
+        lo = fe_sub(R.cur[F][0], fe_mul(r, fe_sub(R.cur[F][0], R.cur[F][2], P), P), P);
+        hi = fe_sub(R.cur[F][1], fe_mul(r, fe_sub(R.cur[F][1], R.cur[F][3], P), P), P);
+        fe_store(fp.out[F], j, lo);
+        fe_store(fp.out[F], j + q, hi);
+    } else {
+        lo = R.cur[F][0];
+        hi = R.cur[F][1];
+    }
+    if (more) {   // this factor's input registers are free: start the next pair's loads now
+#pragma unroll
+        for (int l = 0; l < NL; ++l) R.cur[F][l] = fe_load(fp.in[F], jn + (uint64_t)l * q);
+    }
+    const Fe diff = fe_sub(hi, lo, P);
+    Fe v = lo;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        if (t == 1) v = hi;
+        else if (t > 1) v = fe_add(v, diff, P);
+        if (K == 1) R.sum[t] = fe_add(R.sum[t], v, P);
+        else if (F == 0) R.prod[t] = v;
+        else if (F < K - 1) R.prod[t] = fe_mul(R.prod[t], v, P);
+        else wide_mac(R.acc[t], R.prod[t].v, v.v);
+    }
+}
+// K <= 2 fits 2 waves per SIMD (<= 256 VGPRs); K >= 3 keeps K*4 elements in flight and gets the whole register file.
+template <int K, int D, bool FUSED>
+__global__ __launch_bounds__(kBlock, (K <= 2 ? 2 : 1)) void k_round_kd(FactorPtrs fp, uint64_t q, FieldParams P,
+                                                        const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials) {
+    constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
+    Fe r = fe_zero();
+    if (FUSED) {
+        r = fe_load(rptr, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.v[i] = __builtin_amdgcn_readfirstlane(r.v[i]);
+    }
+    RoundRegs<K, D, FUSED> R;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        R.sum[t] = fe_zero();
+        if (K > 1) wide_zero(R.acc[t]);
+    }
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j < q) {
+#pragma unroll
+        for (int f = 0; f < K; ++f)
+#pragma unroll
+            for (int l = 0; l < NL; ++l) R.cur[f][l] = fe_load(fp.in[f], j + (uint64_t)l * q);
+    }
+    while (j < q) {
+        const uint64_t jn = j + stride;
+        const bool more = jn < q;
+        round_factor<0, K, D, FUSED>(R, fp, j, jn, more, q, r, P);
+        if constexpr (K > 1) round_factor<1, K, D, FUSED>(R, fp, j, jn, more, q, r, P);
+        if constexpr (K > 2) round_factor<2, K, D, FUSED>(R, fp, j, jn, more, q, r, P);
+        if constexpr (K > 3) round_factor<3, K, D, FUSED>(R, fp, j, jn, more, q, r, P);
+        j = jn;
+    }
+    if (K > 1) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) R.sum[t] = redc_wide(R.acc[t], P);
+    }
+    block_reduce_store<NS>(R.sum, partials, P);
+}
+
+// Generic-degree fallback: one evaluation point t per launch (any D up to 255, any k <= kMaxFactors).
+__global__ __launch_bounds__(kBlock) void k_round_single_t(FactorPtrs fp, int k, uint64_t q, FieldParams P, Fe tval,
+                                                           uint64_t *__restrict__ partials) {
+    Fe sum[1] = {fe_zero()};
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < q; j += stride) {
+        Fe prod = fe_zero();
+        for (int f = 0; f < k; ++f) {
+            const Fe lo = fe_load(fp.in[f], j), hi = fe_load(fp.in[f], j + q);
+            const Fe v = fe_sub(lo, fe_mul(tval, fe_sub(lo, hi, P), P), P);
+            prod = (f == 0) ? v : fe_mul(prod, v, P);
+        }
+        sum[0] = fe_add(sum[0], prod, P);
+    }
+    block_reduce_store<1>(sum, partials, P);
+}
+
+}  // namespace zk

@@ -1,0 +1,71 @@
+// rounds.hip -- instantiations + launch logic of the sumcheck round kernels.
+#include "launch.hpp"
+#include "round_kernels.cuh"
+
+namespace zk {
+
+static constexpr uint32_t kCapGrid = 2048;   // 8 workgroups per CU on 256 CUs
+
+// every thread handles at most kMaxLazy pairs (the lazy accumulators of k_round_kd are reduced once, after the loop)
+static inline uint32_t round_grid(uint64_t q) {
+    uint64_t b = (q + kBlock - 1) / kBlock;
+    if (b > kCapGrid) b = kCapGrid;
+    const uint64_t need = (q + (uint64_t)kBlock * kMaxLazy - 1) / ((uint64_t)kBlock * kMaxLazy);
+    if (b < need) b = need;
+    return (uint32_t)(b ? b : 1);
+}
+static inline uint32_t capped_grid(uint64_t q) {
+    uint64_t b = (q + kBlock - 1) / kBlock;
+    if (b > kCapGrid) b = kCapGrid;
+    return (uint32_t)(b ? b : 1);
+}
+
+template <int K, int D>
+static void launch_kd(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, bool fused, const uint64_t *d_r, uint32_t g) {
+    if (fused) k_round_kd<K, D, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+    else k_round_kd<K, D, false><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+}
+template <int D>
+static void launch_generic(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, bool fused, const uint64_t *d_r, uint32_t g) {
+    if (fused) k_round<D, true><<<g, kBlock, 0, lc.stream>>>(fp, k, q, *lc.P, d_r, lc.d_partials);
+    else k_round<D, false><<<g, kBlock, 0, lc.stream>>>(fp, k, q, *lc.P, d_r, lc.d_partials);
+}
+
+int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused,
+                 const uint64_t *d_r, uint32_t *out_grid) {
+    if (D < 1 || D > 4 || k < 1 || k > kMaxFactors) return kLaunchUnsupported;
+    uint32_t g = round_grid(q);
+    const bool fits = (uint64_t)g * (D + 1) <= lc.capacity_elems;
+    // specialised shapes (GKR-style products have D = k): everything else takes the runtime-k kernel
+    const int shape = fits ? k * 10 + (int)D : 0;
+    switch (shape) {
+        case 11: launch_kd<1, 1>(lc, fp, q, fused, d_r, g); break;
+        case 12: launch_kd<1, 2>(lc, fp, q, fused, d_r, g); break;
+        case 21: launch_kd<2, 1>(lc, fp, q, fused, d_r, g); break;
+        case 22: launch_kd<2, 2>(lc, fp, q, fused, d_r, g); break;
+        case 23: launch_kd<2, 3>(lc, fp, q, fused, d_r, g); break;
+        case 32: launch_kd<3, 2>(lc, fp, q, fused, d_r, g); break;
+        case 33: launch_kd<3, 3>(lc, fp, q, fused, d_r, g); break;
+        default:
+            g = capped_grid(q);   // k_round flushes its lazy accumulators itself
+            switch (D) {
+                case 1: launch_generic<1>(lc, fp, k, q, fused, d_r, g); break;
+                case 2: launch_generic<2>(lc, fp, k, q, fused, d_r, g); break;
+                case 3: launch_generic<3>(lc, fp, k, q, fused, d_r, g); break;
+                default: launch_generic<4>(lc, fp, k, q, fused, d_r, g); break;
+            }
+    }
+    if (hipGetLastError() != hipSuccess) return kLaunchHipError;
+    *out_grid = g;
+    return kLaunchOk;
+}
+
+int launch_round_single_t(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, const Fe &tval, uint32_t *out_grid) {
+    const uint32_t g = capped_grid(q);
+    k_round_single_t<<<g, kBlock, 0, lc.stream>>>(fp, k, q, *lc.P, tval, lc.d_partials);
+    if (hipGetLastError() != hipSuccess) return kLaunchHipError;
+    *out_grid = g;
+    return kLaunchOk;
+}
+
+}  // namespace zk
