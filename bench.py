@@ -159,6 +159,12 @@ def main():
                     ts.append(time.perf_counter() - t1)
                 extra[f"sumcheck_prove_partial_ms_n{n}_k2_d2"] = sorted(ts)[len(ts) // 2] * 1e3
                 A.free(); B.free()
+            # config[4]: 2^24-point NTT (3 LDS-staged passes), device resident
+            x = zk_amd.MultiLinearPolynomial.random(ctx, 24, 0x5EED0005, 0)
+            y = zk_amd.MultiLinearPolynomial.alloc(ctx, 24)
+            extra["ntt_2p24_ms"] = zk_amd.bench_ntt(ctx, x, y, False, 5)
+            extra["intt_2p24_ms"] = zk_amd.bench_ntt(ctx, x, y, True, 5)
+            x.free(); y.free()
             extra["modmul_per_s_register_resident"] = ctx.bench_modmul(2000)
             extra["copy_gbps_1GiB"] = ctx.bench_copy(1 << 30, 10)
         except Exception as e:  # extras never invalidate the headline line

@@ -284,6 +284,49 @@ def test_fft_medium_vs_oracle_fast(field, lg):
     assert np.array_equal(zk_amd.ifft(c, f), v)
 
 
+@pytest.mark.parametrize("lg", [8, 9, 11, 12, 15, 17, 18, 20])
+def test_fft_lds_passes_vs_oracle_fast(lg):
+    """sizes that exercise 2 passes (2^8..2^16), 3 passes (2^17..2^24) and uneven radix splits, BN254 + one other field"""
+    for field in (zk_amd.BN254_FR, FIELDS[lg % 3]):
+        c = ctx_for(field)
+        v = orc.fill_random(field, 800 + lg, 1 << lg)
+        f = zk_amd.fft(c, v)
+        assert np.array_equal(f, orc.ntt_fast(field, v))
+        assert np.array_equal(zk_amd.ifft(c, f), v)
+
+
+def test_config5_ntt_2_24_properties():
+    """config[4]: 2^24-point NTT on one GPU.  (a) ifft(fft(x)) == x on the device-resident vector; (b) two output
+    coefficients against the definition X[k] = sum_j x[j] w^(jk): X[0] = sum x[j] and X[n/2] = sum (-1)^j x[j]
+    (w^(n/2) = -1), computed exactly with Python integers (Montgomery representatives add like the values)."""
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    lg = 24
+    x = MLE.random(c, lg, 0x5EED0000 + 5, 0)
+    X, back = MLE.alloc(c, lg), MLE.alloc(c, lg)
+    zk_amd.ntt(c, x, X)
+    zk_amd.ntt(c, X, back, inverse=True)
+    xs = x.evaluation_slice()
+    assert np.array_equal(back.evaluation_slice(), xs)
+    Xs = X.evaluation_slice()
+    p = zk_amd.modulus(field)
+
+    def exact_col_sum(col):   # exact sum of a uint64 column: 32-bit halves, chunked so uint64 partial sums cannot wrap
+        lo = (col & np.uint64(0xFFFFFFFF)).reshape(-1, 1 << 12).sum(axis=1, dtype=np.uint64)
+        hi = (col >> np.uint64(32)).reshape(-1, 1 << 12).sum(axis=1, dtype=np.uint64)
+        return sum(int(v) for v in lo) + (sum(int(v) for v in hi) << 32)
+
+    def mont_sum(rows):
+        return sum(exact_col_sum(np.ascontiguousarray(rows[:, i])) << (64 * i) for i in range(4)) % p
+
+    def limbs_to_int(r):
+        return int(r[0]) | (int(r[1]) << 64) | (int(r[2]) << 128) | (int(r[3]) << 192)
+
+    s_even, s_odd = mont_sum(xs[0::2]), mont_sum(xs[1::2])
+    assert limbs_to_int(Xs[0]) == (s_even + s_odd) % p
+    assert limbs_to_int(Xs[1 << (lg - 1)]) == (s_even - s_odd) % p
+
+
 def test_fft_error_behaviour():
     c = ctx_for(zk_amd.BN254_FR)
     with pytest.raises(ZkError, match="get_root_of_unity"):      # fft/src/lib.rs:6 unwrap on None

@@ -381,8 +381,14 @@ def ntt(ctx, vec_in, vec_out, inverse=False):
     return vec_out
 
 
+def bench_ntt(ctx, vec_in, vec_out, inverse=False, reps=5):
+    ms = c.c_double()
+    check(lib.zk_bench_ntt(ctx._h, vec_in._h, int(inverse), vec_out._h, reps, c.byref(ms)))
+    return ms.value
+
+
 __all__ = [
     "BN254_FR", "BLS12_381_FR", "BLS12_377_FR", "Context", "MultiLinearPolynomial", "ProductPoly", "SumcheckProof",
-    "SubClaim", "SumcheckProver", "SumcheckVerifier", "Transcript", "ZkError", "fft", "ifft", "fft_internal", "ntt",
+    "SubClaim", "SumcheckProver", "SumcheckVerifier", "Transcript", "ZkError", "fft", "ifft", "fft_internal", "ntt", "bench_ntt",
     "fe_from_int", "fe_from_ints", "fe_to_int", "fe_to_ints", "keccak256", "modulus", "two_adicity",
 ]

@@ -16,6 +16,7 @@
 #include "host_field.hpp"
 #include "kernels.cuh"
 #include "launch.hpp"
+#include "ntt_kernels.cuh"
 #include "keccak.hpp"
 
 using namespace zk;
@@ -33,7 +34,8 @@ struct zk_ctx {
     uint64_t *d_sums;       // final round sums (kMaxSums elements) + lanes area
     uint64_t *h_pinned;     // pinned staging: kMaxSums*8 u64
     hipEvent_t ev0, ev1;
-    std::map<std::pair<uint32_t, int>, uint64_t *> twiddles;   // (log_n, inverse) -> omega^i table, i < n/2
+    std::map<std::pair<uint32_t, int>, uint64_t *> twiddles;   // (log_n, inverse) -> omega^i table, i < n/2 (n < 2^8 path)
+    std::map<std::pair<uint32_t, int>, NttPlan> ntt_plans;     // (log_n, inverse) -> pass plan + two-level twiddle tables
     std::map<size_t, std::vector<void *>> pool;                // freed device blocks by exact size (stream-ordered reuse)
     size_t pool_bytes;
 };
@@ -229,6 +231,10 @@ extern "C" int32_t zk_ctx_destroy(zk_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &kv : c->twiddles) (void)hipFree(kv.second);
+    for (auto &kv : c->ntt_plans) {
+        (void)hipFree((void *)kv.second.w_lo);
+        (void)hipFree((void *)kv.second.w_hi);
+    }
     for (auto &kv : c->pool)
         for (void *q : kv.second) (void)hipFree(q);
     (void)hipFree(c->d_partials);
@@ -1105,6 +1111,75 @@ static int32_t ntt_with_table(zk_ctx *c, const uint64_t *in, uint64_t *out, uint
     }
     return ZK_OK;
 }
+// ---- LDS-staged multi-pass NTT (ntt_kernels.cuh) for n >= 2^8 ----
+static void ntt_make_plan(uint32_t log_n, NttPlan &pl) {
+    pl.log_n = log_n;
+    pl.n_pass = (log_n + kNttMaxLog - 1) / kNttMaxLog;
+    if (pl.n_pass < 2) pl.n_pass = 2;
+    const uint32_t base = log_n / pl.n_pass, rem = log_n % pl.n_pass;
+    for (uint32_t p = 0; p < 4; ++p) pl.l[p] = p < pl.n_pass ? base + (p < rem ? 1 : 0) : 0;
+    pl.lo_bits = log_n < 12 ? log_n : 12;
+    pl.w_lo = pl.w_hi = nullptr;
+}
+static int32_t ntt_build_tables(zk_ctx *c, NttPlan &pl, const Fe &omega) {
+    const uint32_t hi_bits = pl.log_n - pl.lo_bits;
+    uint64_t *lo = nullptr, *hi = nullptr;
+    HIPCHK(hipMalloc(&lo, (size_t)32 << pl.lo_bits));
+    if (hipMalloc(&hi, (size_t)32 << hi_bits) != hipSuccess) {
+        (void)hipFree(lo);
+        return ZK_ERR_ALLOC;
+    }
+    k_ntt_tables<<<grid_for((1ull << pl.lo_bits) + (1ull << hi_bits)), kBlock, 0, c->stream>>>(lo, hi, pl.lo_bits, hi_bits, omega, c->fi->P);
+    if (hipGetLastError() != hipSuccess) {
+        (void)hipFree(lo);
+        (void)hipFree(hi);
+        return ZK_ERR_HIP;
+    }
+    pl.w_lo = lo;
+    pl.w_hi = hi;
+    return ZK_OK;
+}
+static int32_t ntt_run_plan(zk_ctx *c, const NttPlan &pl, const uint64_t *in, uint64_t *out, bool inverse) {
+    const FieldParams &P = c->fi->P;
+    const uint64_t n = 1ull << pl.log_n;
+    uint64_t *scratch = nullptr;
+    ZKCHK(pool_alloc(c, (size_t)n * 32, (void **)&scratch));
+    Fe scale = fe_one(P);
+    if (inverse) {                                                               // fft/src/lib.rs:17: * F::from(n).inverse()
+        const uint64_t nl[4] = {n, 0, 0, 0};
+        scale = fe_inverse(fe_from_canonical(fe_from_u64limbs(nl), P), P);
+    }
+    int32_t rc = ZK_OK;
+    const uint64_t *src = in;
+    for (uint32_t p = 0; p < pl.n_pass && rc == ZK_OK; ++p) {
+        const uint32_t R = 1u << pl.l[p];
+        const size_t lds = 2 * (size_t)R * kNttRowBytes + (size_t)(R / 2) * 32;
+        const uint32_t tiles = (uint32_t)(n / ((uint64_t)R * kNttCols));
+        const bool last = p + 1 == pl.n_pass;
+        hipError_t e;
+        if (!last) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_pass<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) {
+                k_ntt_pass<false><<<tiles, kNttThreads, lds, c->stream>>>(src, scratch, pl, p, P, scale, 0);
+                e = hipGetLastError();
+            }
+            src = scratch;   // middle passes keep their addresses: later ones run in place on scratch
+        } else {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_pass<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) {
+                k_ntt_pass<true><<<tiles, kNttThreads, lds, c->stream>>>(src, out, pl, p, P, scale, inverse ? 1 : 0);
+                e = hipGetLastError();
+            }
+        }
+        if (e != hipSuccess) {
+            g_hip_err = std::string("ntt pass: ") + hipGetErrorString(e);
+            rc = ZK_ERR_HIP;
+        }
+    }
+    pool_free(c, scratch, (size_t)n * 32);
+    return rc;
+}
+
 extern "C" int32_t zk_ntt(zk_ctx *c, const zk_mle *in, int32_t inverse, zk_mle *out) {
     if (!c || !in || !out) return ZK_ERR_BAD_ARG;
     if (in->ctx != c || out->ctx != c) return ZK_ERR_CONTEXT_MISMATCH;
@@ -1116,6 +1191,16 @@ extern "C" int32_t zk_ntt(zk_ctx *c, const zk_mle *in, int32_t inverse, zk_mle *
     const FieldParams &P = c->fi->P;
     if (inverse) omega = fe_inverse(omega, P);                                   // fft/src/lib.rs:14
     auto key = std::make_pair(log_n, inverse ? 1 : 0);
+    if (log_n >= 8) {
+        auto pit = c->ntt_plans.find(key);
+        if (pit == c->ntt_plans.end()) {
+            NttPlan pl;
+            ntt_make_plan(log_n, pl);
+            ZKCHK(ntt_build_tables(c, pl, omega));
+            pit = c->ntt_plans.emplace(key, pl).first;
+        }
+        return ntt_run_plan(c, pit->second, in->d, out->d, inverse != 0);
+    }
     auto it = c->twiddles.find(key);
     if (it == c->twiddles.end()) {
         uint64_t *tw = nullptr;
@@ -1146,7 +1231,15 @@ static int32_t fft_host_common(zk_ctx *c, const uint64_t *in, uint64_t n, uint64
     ZKCHK(zk_mle_upload(c, log_n, in, n, &a));
     int32_t rc = mle_alloc(c, log_n, &b);
     if (rc == ZK_OK) {
-        if (mode == 2) {
+        if (mode == 2 && log_n >= 8) {
+            NttPlan pl;
+            ntt_make_plan(log_n, pl);
+            rc = ntt_build_tables(c, pl, fe_from_u64limbs(omega_user));
+            if (rc == ZK_OK) rc = ntt_run_plan(c, pl, a->d, b->d, false);
+            if (hipStreamSynchronize(c->stream) != hipSuccess && rc == ZK_OK) rc = ZK_ERR_HIP;
+            if (pl.w_lo) (void)hipFree((void *)pl.w_lo);
+            if (pl.w_hi) (void)hipFree((void *)pl.w_hi);
+        } else if (mode == 2) {
             uint64_t *tw = nullptr;
             rc = make_twiddles(c, log_n, fe_from_u64limbs(omega_user), &tw);
             if (rc == ZK_OK) rc = ntt_with_table(c, a->d, b->d, log_n, tw);
@@ -1179,6 +1272,18 @@ extern "C" int32_t zk_bench_fold(zk_ctx *c, const zk_mle *t, const uint64_t r[4]
     const Fe rr = fe_from_u64limbs(r);
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     for (int i = 0; i < reps; ++i) ZKCHK(launch_fold(c, t->d, out->d, t->n_vars, 0, rr));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *out_ms = (double)ms / reps;
+    return ZK_OK;
+}
+extern "C" int32_t zk_bench_ntt(zk_ctx *c, const zk_mle *in, int32_t inverse, zk_mle *out, int32_t reps, double *out_ms) {
+    if (!c || !in || !out || !out_ms || reps <= 0) return ZK_ERR_BAD_ARG;
+    ZKCHK(zk_ntt(c, in, inverse, out));   // builds the twiddle tables / warms up
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < reps; ++i) ZKCHK(zk_ntt(c, in, inverse, out));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     float ms = 0.f;

@@ -64,30 +64,116 @@ __global__ __launch_bounds__(kBlock) void k_prod_reduce(FactorPtrs fp, int k, ui
 // ---- device-side Fiat-Shamir step (sumcheck/src/prover.rs:59-62 on one GPU lane) --------------------------------------
 // absorb the round polynomial (32-byte BE canonical elements, sumcheck/src/lib.rs:23-29), squeeze the challenge
 // (transcript/src/lib.rs:20-30) and publish it in Montgomery form for the next round's fused fold.
-// Runs on ALL lanes of one wave with wave-uniform data: the sponge state and the sums are forced into SGPRs
-// (readfirstlane), so the 24 Keccak rounds compile to 64-bit SCALAR ALU ops (s_xor_b64, s_andn2_b64, s_lshl_b64 ...)
-// instead of a single active lane's VALU stream -- several times faster for this latency-critical serial step.
-ZK_D uint64_t uniform64(uint64_t x) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+// Lane-parallel sponge: lane i = x + 5y of one wave holds Keccak state word A[x][y]; one permutation round is 9 cross-lane
+// moves (ds_bpermute) + ~30 VALU ops for the whole state instead of ~190 serial 64-bit ops.  The 24-round permutation
+// is the latency floor of every sumcheck round (prover.rs:59-62 is inherently serial), so it is built for latency.
+struct LaneKeccak {
+    int lane, up1, up2, up3, up4, xm1, xp1, xp2, src_pi;
+    uint32_t rot;
+};
+ZK_D uint64_t shfl64(uint64_t v, int src) {
+    const uint32_t lo = __shfl((uint32_t)v, src, 64), hi = __shfl((uint32_t)(v >> 32), src, 64);
     return ((uint64_t)hi << 32) | lo;
 }
+ZK_D LaneKeccak lane_keccak_init() {
+    // rho offsets indexed by x + 5y
+    constexpr uint8_t kRho[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    LaneKeccak L;
+    const int lane = threadIdx.x & 63;
+    L.lane = lane;
+    if (lane < 25) {
+        const int x = lane % 5, y = lane / 5;
+        L.up1 = x + 5 * ((y + 1) % 5);
+        L.up2 = x + 5 * ((y + 2) % 5);
+        L.up3 = x + 5 * ((y + 3) % 5);
+        L.up4 = x + 5 * ((y + 4) % 5);
+        L.xm1 = (x + 4) % 5 + 5 * y;
+        L.xp1 = (x + 1) % 5 + 5 * y;
+        L.xp2 = (x + 2) % 5 + 5 * y;
+        // pi: B[y'][2x'+3y'] = A[x'][y'], i.e. destination (X, Y) = (y', 2x'+3y').  For destination (x, y) the source is
+        // x' = (x + 3y) mod 5, y' = x.
+        const int sx = (x + 3 * y) % 5, sy = x;
+        L.src_pi = sx + 5 * sy;
+        uint32_t rot = 0;
+#pragma unroll
+        for (int i = 0; i < 25; ++i)
+            if (i == lane) rot = kRho[i];
+        L.rot = rot;
+    } else {
+        L.up1 = L.up2 = L.up3 = L.up4 = L.xm1 = L.xp1 = L.xp2 = L.src_pi = lane;
+        L.rot = 0;
+    }
+    return L;
+}
+ZK_D uint64_t lane_keccak_f1600(uint64_t a, const LaneKeccak &L) {
+    constexpr uint64_t RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    for (int round = 0; round < 24; ++round) {
+        // theta: column parity of my column, then D = C[x-1] ^ rotl(C[x+1], 1)
+        const uint64_t c = a ^ shfl64(a, L.up1) ^ shfl64(a, L.up2) ^ shfl64(a, L.up3) ^ shfl64(a, L.up4);
+        const uint64_t cp = shfl64(c, L.xp1);
+        a ^= shfl64(c, L.xm1) ^ ((cp << 1) | (cp >> 63));
+        // rho (rotate my word) + pi (fetch the word that lands here)
+        const uint64_t rr = (a << L.rot) | (a >> ((64 - L.rot) & 63));
+        const uint64_t b = shfl64(rr, L.src_pi);
+        // chi + iota
+        a = b ^ (~shfl64(b, L.xp1) & shfl64(b, L.xp2));
+        if (L.lane == 0) a ^= RC[round];
+    }
+    return a;
+}
+struct LaneSponge {   // word-cursor sponge (see WordSponge) spread over lanes 0..24
+    uint64_t a;
+    uint32_t pos;
+};
+ZK_D void lane_absorb_word(LaneSponge &sp, uint64_t w, const LaneKeccak &L) {   // w wave-uniform
+    if ((uint32_t)L.lane == sp.pos) sp.a ^= w;
+    if (++sp.pos == 17) {
+        sp.a = lane_keccak_f1600(sp.a, L);
+        sp.pos = 0;
+    }
+}
+
+// One transcript step on one wave (all 64 lanes execute it; lanes >= 25 idle along):
+// absorb the round polynomial as 32-byte big-endian canonical elements (sumcheck/src/lib.rs:23-29), squeeze the
+// challenge (transcript/src/lib.rs:20-30) and publish it in Montgomery form for the next round's fused fold.
 ZK_D void transcript_round(WordSponge *gsp, const Fe *sums, uint32_t ns, uint64_t *d_challenge, uint64_t *out_ch,
                            const FieldParams &P) {
-    WordSponge sp;
-#pragma unroll
-    for (int i = 0; i < 25; ++i) sp.s[i] = uniform64(gsp->s[i]);
+    const LaneKeccak L = lane_keccak_init();
+    LaneSponge sp;
+    sp.a = (L.lane < 25) ? gsp->s[L.lane] : 0ull;
     sp.pos = __builtin_amdgcn_readfirstlane(gsp->pos);
-    sp.pad_ = 0;
-    for (uint32_t t = 0; t < ns; ++t) {
-        const Fe c = fe_to_canonical(sums[t], P);
-        uint64_t l[4];
+    for (uint32_t base = 0; base < ns; base += 64) {
+        // lane t converts sum (base + t): Montgomery -> canonical, in parallel across lanes
+        const uint32_t mine = base + (uint32_t)L.lane < ns ? base + (uint32_t)L.lane : ns - 1;
+        const Fe c = fe_to_canonical(sums[mine], P);
+        uint64_t w[4];   // the element's 32-byte big-endian image as 4 little-endian lane words
 #pragma unroll
-        for (int i = 0; i < 4; ++i) l[i] = uniform64((uint64_t)c.v[2 * i] | ((uint64_t)c.v[2 * i + 1] << 32));
-        sp.absorb_u256_be(l);
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t limb = (uint64_t)c.v[2 * (3 - k)] | ((uint64_t)c.v[2 * (3 - k) + 1] << 32);
+            w[k] = WordSponge::bswap64(limb);
+        }
+        const uint32_t cnt = ns - base < 64 ? ns - base : 64;
+        for (uint32_t t = 0; t < cnt; ++t) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lane_absorb_word(sp, shfl64(w[k], (int)t), L);
+        }
     }
-    uint64_t h[4];
-    sp.sample_challenge_u256(h);
+    // squeeze: pad10*1 with Keccak's 0x01 domain byte, permute, digest = words 0..3
+    if ((uint32_t)L.lane == sp.pos) sp.a ^= 0x01ull;
+    if (L.lane == 16) sp.a ^= 0x8000000000000000ull;
+    sp.a = lane_keccak_f1600(sp.a, L);
+    const uint64_t d0 = shfl64(sp.a, 0), d1 = shfl64(sp.a, 1), d2 = shfl64(sp.a, 2), d3 = shfl64(sp.a, 3);
+    // finalize_reset + update(digest) (transcript/src/lib.rs:22-23): state = digest words, cursor 4
+    sp.a = (L.lane < 4) ? sp.a : 0ull;
+    sp.pos = 4;
+    // int(digest, big endian) mod p -> Montgomery (transcript/src/lib.rs:29)
+    const uint64_t h[4] = {WordSponge::bswap64(d3), WordSponge::bswap64(d2), WordSponge::bswap64(d1), WordSponge::bswap64(d0)};
     uint32_t x[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -95,13 +181,12 @@ ZK_D void transcript_round(WordSponge *gsp, const Fe *sums, uint32_t ns, uint64_
         x[2 * i + 1] = (uint32_t)(h[i] >> 32);
     }
     const Fe ch = fe_from_canonical(fe_reduce_u256(x, P), P);
-    if ((threadIdx.x & 63) == 0) {
+    if (L.lane == 0) {
         fe_store(d_challenge, 0, ch);
         if (out_ch) fe_store(out_ch, 0, ch);
-#pragma unroll
-        for (int i = 0; i < 25; ++i) gsp->s[i] = sp.s[i];
         gsp->pos = sp.pos;
     }
+    if (L.lane < 25) gsp->s[L.lane] = sp.a;
 }
 
 // Second stage of a round: one workgroup adds the per-block partials -> ns sums (Montgomery form); then, on lane 0,
