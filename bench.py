@@ -117,6 +117,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # HBM traffic per k_fold launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 on gfx950 +
+    # WRITE_SIZE, tools/summarize_prof.py); bench.py cannot collect PMC counters itself.
+    traffic, traffic_src = None, None
+    try:
+        import glob
+
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+        if cands:
+            tj = json.load(open(cands[-1]))
+            if "zk::k_fold" in tj:
+                traffic, traffic_src = tj["zk::k_fold"]["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
+    except Exception:
+        pass
+
     total_ops = FIELD_OPS_PER_FOLD * args.steps * world
     achieved_gbps = ALG_BYTES_PER_FOLD / (kernel_ms * 1e-3) / 1e9
     result = {
@@ -135,7 +149,7 @@ def main():
         "config": {"workload": "mle_fold_msb 2^24 BN254-Fr elements per GPU (partial_evaluate(0,[r]))",
                    "n_vars": N_VARS, "field": "bn254_fr", "shard": "index mod n_gpus (no collective in the fold)"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "zk::k_fold", "kernel_ms": kernel_ms, "algorithmic_bytes": ALG_BYTES_PER_FOLD},
     }
 

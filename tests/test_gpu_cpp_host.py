@@ -1,0 +1,29 @@
+"""Runs the C++ host-mirror tests (tests/cpp/test_reference_kats.cpp: the reference's own unit tests restated over
+zk_amd/host/zk.hpp and the C ABI, no Python in the data path) on the GPU box."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "test_reference_kats")
+
+
+@pytest.mark.gpu
+def test_cpp_reference_kats_on_gpu():
+    if not os.path.exists(BIN):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ok: 11 reference tests passed" in r.stdout
+
+
+def test_cpp_host_mirror_compiles_and_fails_loudly_without_gpu():
+    import torch
+
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True, capture_output=True)
+    assert os.path.exists(BIN)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "no CPU fallback" in r.stdout
