@@ -127,8 +127,8 @@ def main():
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
         if cands:
             tj = json.load(open(cands[-1]))
-            if "zk::k_fold" in tj:
-                traffic, traffic_src = tj["zk::k_fold"]["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
+            if "zk::k_fold_msb" in tj:
+                traffic, traffic_src = tj["zk::k_fold_msb"]["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
     except Exception:
         pass
 
@@ -151,7 +151,7 @@ def main():
                    "n_vars": N_VARS, "field": "bn254_fr", "shard": "index mod n_gpus (no collective in the fold)"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "zk::k_fold", "kernel_ms": kernel_ms, "algorithmic_bytes": ALG_BYTES_PER_FOLD},
+                     "kernel": "zk::k_fold_msb", "kernel_ms": kernel_ms, "algorithmic_bytes": ALG_BYTES_PER_FOLD},
     }
 
     if rank == 0 and not args.no_extra:
@@ -181,6 +181,7 @@ def main():
             extra["intt_2p24_ms"] = zk_amd.bench_ntt(ctx, x, y, True, 5)
             x.free(); y.free()
             extra["modmul_per_s_register_resident"] = ctx.bench_modmul(2000)
+            extra["modmul29_per_s_register_resident"] = ctx.bench_modmul(2000, 1)
             extra["copy_gbps_1GiB"] = ctx.bench_copy(1 << 30, 10)
         except Exception as e:  # extras never invalidate the headline line
             extra["error"] = repr(e)

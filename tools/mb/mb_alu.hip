@@ -127,6 +127,35 @@ __global__ __launch_bounds__(256) void k_mov_dpp(uint64_t* out, int iters, uint3
     if (s == 0x1234567) out[0] = s;
 }
 
+
+#define GEN_KERNEL32(NAME, ASM) \
+__global__ __launch_bounds__(256) void NAME(uint64_t* out, int iters, uint32_t a, uint32_t b) { \
+    uint32_t acc[8]; for (int i = 0; i < 8; ++i) acc[i] = threadIdx.x + i + a; \
+    uint32_t y = (b ^ threadIdx.x) | 1; \
+    for (int it = 0; it < iters; ++it) { \
+        _Pragma("unroll") for (int rep = 0; rep < 4; ++rep) { \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile(ASM : "+v"(acc[i]) : "v"(y)); } } \
+    uint32_t s = 0; for (int i = 0; i < 8; ++i) s += acc[i]; if (s == 0x1234567) out[0] = s; }
+GEN_KERNEL32(k_alignbit, "v_alignbit_b32 %0, %0, %1, 29")
+GEN_KERNEL32(k_and, "v_and_b32 %0, %0, %1")
+GEN_KERNEL32(k_bfe, "v_bfe_u32 %0, %0, 3, 29")
+GEN_KERNEL32(k_andor, "v_and_or_b32 %0, %0, %1, %1")
+GEN_KERNEL32(k_lshl_or, "v_lshl_or_b32 %0, %0, 3, %1")
+GEN_KERNEL32(k_add3, "v_add3_u32 %0, %0, %1, %1")
+GEN_KERNEL32(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+GEN_KERNEL32(k_add_co, "v_add_co_u32 %0, vcc, %0, %1")
+GEN_KERNEL32(k_sub_co, "v_sub_co_u32 %0, vcc, %0, %1")
+#define GEN_KERNEL64(NAME, ASM) \
+__global__ __launch_bounds__(256) void NAME(uint64_t* out, int iters, uint32_t a, uint32_t b) { \
+    uint64_t acc[8]; for (int i = 0; i < 8; ++i) acc[i] = ((uint64_t)(threadIdx.x + i + a) << 32) | b; \
+    uint64_t y = ((uint64_t)b << 20) ^ threadIdx.x; \
+    for (int it = 0; it < iters; ++it) { \
+        _Pragma("unroll") for (int rep = 0; rep < 4; ++rep) { \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile(ASM : "+v"(acc[i]) : "v"(y)); } } \
+    uint64_t s = 0; for (int i = 0; i < 8; ++i) s += acc[i]; if (s == 0x1234567) out[0] = s; }
+GEN_KERNEL64(k_lshr64, "v_lshrrev_b64 %0, 29, %0")
+GEN_KERNEL64(k_lshladd64, "v_lshl_add_u64 %0, %0, 0, %1")
+
 int main() {
     uint64_t* out; CK(hipMalloc(&out, 64));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -149,6 +178,17 @@ int main() {
     run("mad64+addc", [&](int it) { k_mad64_addc<<<blocks, 256>>>(out, it, 1, 2); }, 64);
     run("v_fma_f32", [&](int it) { k_fma32<<<blocks, 256>>>(out, it, 1.f, 2.f); }, 32);
     run("v_fma_f64", [&](int it) { k_fma64<<<blocks, 256>>>(out, it, 1.0, 2.0); }, 32);
+    run("v_alignbit_b32", [&](int it) { k_alignbit<<<blocks, 256>>>(out, it, 1, 2); }, 32);
+    run("v_and_b32", [&](int it) { k_and<<<blocks, 256>>>(out, it, 1, 2); }, 32);
+    run("v_bfe_u32", [&](int it) { k_bfe<<<blocks, 256>>>(out, it, 1, 2); }, 32);
+    run("v_and_or_b32", [&](int it) { k_andor<<<blocks, 256>>>(out, it, 1, 2); }, 32);
+    run("v_lshl_or_b32", [&](int it) { k_lshl_or<<<blocks, 256>>>(out, it, 1, 2); }, 32);
+    run("v_add3_u32", [&](int it) { k_add3<<<blocks, 256>>>(out, it, 1, 2); }, 32);
+    run("v_cndmask_b32", [&](int it) { k_cndmask<<<blocks, 256>>>(out, it, 1, 2); }, 32);
+    run("v_add_co_u32", [&](int it) { k_add_co<<<blocks, 256>>>(out, it, 1, 2); }, 32);
+    run("v_sub_co_u32", [&](int it) { k_sub_co<<<blocks, 256>>>(out, it, 1, 2); }, 32);
+    run("v_lshrrev_b64", [&](int it) { k_lshr64<<<blocks, 256>>>(out, it, 1, 2); }, 32);
+    run("v_lshl_add_u64", [&](int it) { k_lshladd64<<<blocks, 256>>>(out, it, 1, 2); }, 32);
     run("v_mov_dpp", [&](int it) { k_mov_dpp<<<blocks, 256>>>(out, it, 1, 2); }, 32);
     return 0;
 }

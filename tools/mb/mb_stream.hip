@@ -70,6 +70,17 @@ __global__ __launch_bounds__(256) void fold_v(const uint64_t* in, uint64_t* out,
         }
     }
 }
+// fold with the modular multiply stubbed out (same loads/stores, same subs): what the access pattern alone sustains
+template <int MODE>
+__global__ __launch_bounds__(256) void fold_nomul(const uint64_t* in, uint64_t* out, uint64_t half, FieldParams P, Fe r) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < half; j += stride) {
+        const Fe lo = fe_load(in, j), hi = fe_load(in, j + half);
+        Fe d = fe_sub(lo, hi, P);
+        if (MODE == 1) { Fe m = d; for (int i = 0; i < 8; ++i) m.v[i] ^= r.v[i]; d = m; }   // trivial "multiply"
+        fe_store(out, j, MODE == 0 ? d : fe_sub(lo, d, P));
+    }
+}
 // C: lane-pair coalesced access: a wave reads 128 consecutive elements as 4 fully coalesced 1-KiB loads per stream;
 // lanes 2i / 2i+1 exchange halves so that each lane ends up with 2 whole elements.
 ZK_D uint32_t xchg1(uint32_t v) { return __builtin_amdgcn_mov_dpp(v, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true); }
@@ -159,7 +170,7 @@ int main(int argc, char** argv) {
         printf("copy hipMemcpyDtoD: %.0f GB/s\n", copy_bytes / tm / 1e6);
     }
     // ---- fold
-    k_fold<<<2048, 256>>>(in, ref, half, n - 1, P, r);
+    k_fold<<<2048, 256>>>(in, ref, half, n - 1, P, mul29_prepare(r, P));
     CK(hipDeviceSynchronize());
     std::vector<uint64_t> href(half * 4), hout(half * 4);
     CK(hipMemcpy(href.data(), ref, half * 32, hipMemcpyDeviceToHost));
@@ -169,13 +180,16 @@ int main(int argc, char** argv) {
         CK(hipMemset(out, 0, half * 32));
     };
     for (int grid : {1024, 2048, 4096, 8192, 16384, 32768}) {
-        double a = T.ms([&] { k_fold<<<grid, 256>>>(in, out, half, n - 1, P, r); }, 20); check("k_fold");
+        double a = T.ms([&] { k_fold<<<grid, 256>>>(in, out, half, n - 1, P, mul29_prepare(r, P)); }, 20); check("k_fold");
         double b = T.ms([&] { fold_v<true, true, 1><<<grid, 256>>>(in, out, half, P, r); }, 20); check("nt");
         double c = T.ms([&] { fold_v<false, false, 2><<<grid, 256>>>(in, out, half, P, r); }, 20); check("u2");
         double d = T.ms([&] { fold_v<true, true, 2><<<grid, 256>>>(in, out, half, P, r); }, 20); check("u2nt");
         double e = T.ms([&] { fold_v<true, false, 1><<<grid, 256>>>(in, out, half, P, r); }, 20); check("ntl");
         double f = T.ms([&] { fold_pair<false><<<grid, 256>>>(in, out, half, P, r); }, 20); check("pair");
         double g = T.ms([&] { fold_pair<true><<<grid, 256>>>(in, out, half, P, r); }, 20); check("pair_nt");
+        double h0 = T.ms([&] { fold_nomul<0><<<grid, 256>>>(in, out, half, P, r); }, 20);
+        double h1 = T.ms([&] { fold_nomul<1><<<grid, 256>>>(in, out, half, P, r); }, 20);
+        printf("fold grid %5d: nomul(sub only) %.0f  nomul(2 subs+xor) %.0f GB/s\n", grid, fold_bytes / h0 / 1e6, fold_bytes / h1 / 1e6);
         printf("fold grid %5d: base %.0f  nt %.0f  u2 %.0f  u2nt %.0f  ntl %.0f  pair %.0f  pair_nt %.0f GB/s\n", grid, fold_bytes / a / 1e6, fold_bytes / b / 1e6,
                fold_bytes / c / 1e6, fold_bytes / d / 1e6, fold_bytes / e / 1e6, fold_bytes / f / 1e6, fold_bytes / g / 1e6);
     }

@@ -364,9 +364,16 @@ extern "C" int32_t zk_mle_device_ptr(const zk_mle *t, void **out) {
 static int32_t launch_fold(zk_ctx *c, const uint64_t *in, uint64_t *out, uint64_t m, uint64_t initial_var, const Fe &r) {
     const uint64_t pairs = 1ull << (m - 1);
     const uint32_t pos = (uint32_t)(m - 1 - initial_var);
+    if (initial_var == 0 && pairs >= 64) {   // the sumcheck fold: lane-pair coalesced, nontemporal streaming kernel
+        uint64_t g = pairs / kBlock;           // one 64-element run per wave
+        if (g > 2 * kMaxGridStream) g = 2 * kMaxGridStream;
+        k_fold_msb<<<(uint32_t)(g ? g : 1), kBlock, 0, c->stream>>>(in, out, pairs, c->fi->P, mul29_prepare(r, c->fi->P));
+        HIPCHK(hipGetLastError());
+        return ZK_OK;
+    }
     uint64_t g = (pairs + kBlock - 1) / kBlock;
     if (g > kMaxGridStream) g = kMaxGridStream;
-    k_fold<<<(uint32_t)(g ? g : 1), kBlock, 0, c->stream>>>(in, out, pairs, pos, c->fi->P, r);
+    k_fold<<<(uint32_t)(g ? g : 1), kBlock, 0, c->stream>>>(in, out, pairs, pos, c->fi->P, mul29_prepare(r, c->fi->P));
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
@@ -543,14 +550,14 @@ static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint
     ps.rp_bytes = (size_t)(rounds ? rounds : 1) * (D + 1) * 32;
     ps.ch_bytes = (size_t)(rounds ? rounds : 1) * 32;
     ZKCHK(pool_alloc(c, sizeof(WordSponge), (void **)&ps.d_sponge));
-    ZKCHK(pool_alloc(c, 32, (void **)&ps.d_challenge));
+    ZKCHK(pool_alloc(c, kChallengeBytes, (void **)&ps.d_challenge));
     ZKCHK(pool_alloc(c, ps.rp_bytes, (void **)&ps.d_rp));
     ZKCHK(pool_alloc(c, ps.ch_bytes, (void **)&ps.d_ch));
     return ZK_OK;
 }
 static void scratch_free(zk_ctx *c, ProverScratch &ps) {
     pool_free(c, ps.d_sponge, sizeof(WordSponge));
-    pool_free(c, ps.d_challenge, 32);
+    pool_free(c, ps.d_challenge, kChallengeBytes);
     pool_free(c, ps.d_rp, ps.rp_bytes);
     pool_free(c, ps.d_ch, ps.ch_bytes);
     ps = {};
@@ -1293,13 +1300,14 @@ extern "C" int32_t zk_bench_ntt(zk_ctx *c, const zk_mle *in, int32_t inverse, zk
 }
 extern "C" int32_t zk_bench_modmul(zk_ctx *c, int32_t variant, int32_t iters, double *out) {
     if (!c || !out || iters <= 0) return ZK_ERR_BAD_ARG;
-    if (variant != 0) return ZK_ERR_UNSUPPORTED;
+    if (variant != 0 && variant != 1) return ZK_ERR_UNSUPPORTED;
     ZKCHK(use_device(c));
     const uint32_t blocks = 256 * 8;
     Fe seed = c->fi->two_adic_root;
-    k_bench_modmul<<<blocks, kBlock, 0, c->stream>>>(c->d_sums, 8, c->fi->P, seed);   // warm-up
+    const Mul29 seed29 = mul29_prepare(seed, c->fi->P);
+    k_bench_modmul<<<blocks, kBlock, 0, c->stream>>>(c->d_sums, 8, c->fi->P, seed, seed29, variant);   // warm-up
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    k_bench_modmul<<<blocks, kBlock, 0, c->stream>>>(c->d_sums, iters, c->fi->P, seed);
+    k_bench_modmul<<<blocks, kBlock, 0, c->stream>>>(c->d_sums, iters, c->fi->P, seed, seed29, variant);
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     float ms = 0.f;

@@ -32,6 +32,8 @@ struct FieldParams {
     uint32_t r2[8];   // R^2 mod p    (to-Montgomery multiplier)
     uint32_t inv;     // -p^-1 mod 2^32
     uint32_t bits;    // bit length of p
+    uint32_t p29[9];  // the modulus in nine 29-bit limbs (unsaturated multiplier, see fe_mul29)
+    uint32_t inv29;   // -p^-1 mod 2^29
 };
 
 struct Fe {
@@ -332,6 +334,77 @@ ZK_HD Fe fe_reduce_u256(const uint32_t x[8], const FieldParams &P) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.v[i] = s[i];
     return r;
+}
+
+// ---- multiplication by a prepared operand on unsaturated 29-bit limbs ---------------------------------------------------
+// On gfx950 a carry add (v_addc_co_u32) costs as much as a multiply (v_mad_u64_u32): both ~4 cycles per wave
+// (tools/mb/mb_alu.hip).  With nine 29-bit limbs every column sum of the fused multiply + Montgomery reduction
+// (<= 18 products < 2^58 plus a carry) fits a 64-bit accumulator, so the whole product needs NO carry instructions:
+// 162 multiply-adds, 9 low multiplies, 17 shifts and the limb split / merge -- about 260 instructions against ~420 for
+// the saturated form.  The reduction then divides by 2^261 instead of 2^256; the operand that is wave-uniform or comes
+// from a table (the fold challenge, NTT twiddles) is therefore prepared once as c * 2^5 mod p, split into 29-bit limbs:
+//   fe_mul29(a, prepare(c)) = a * (c * 2^5) * 2^-261 = a * c * 2^-256 mod p = fe_mul(a, c),  bit for bit.
+struct Mul29 {
+    uint32_t l[9];
+};
+ZK_HD void split29(const uint32_t a[8], uint32_t out[9]) {
+    constexpr uint32_t M = (1u << 29) - 1;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int bit = 29 * i, w = bit >> 5, sh = bit & 31;
+        uint32_t v = a[w] >> sh;
+        if (sh > 3 && w + 1 < 8) v |= a[w + 1] << (32 - sh);   // the limb straddles two words
+        out[i] = (i < 8) ? (v & M) : v;                          // limb 8 = bits 232..255
+    }
+}
+ZK_HD Mul29 mul29_prepare(const Fe &c, const FieldParams &P) {
+    Fe t = c;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) t = fe_add(t, t, P);   // c * 2^5 mod p
+    Mul29 m;
+    split29(t.v, m.l);
+    return m;
+}
+ZK_HD Fe fe_mul29(const Fe &a, const Mul29 &c, const FieldParams &P) {
+    constexpr uint32_t M = (1u << 29) - 1;
+    uint32_t x[9], m[9], r[9];
+    split29(a.v, x);
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (uint64_t)x[i] * c.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P.p29[k - i];
+        m[k] = ((uint32_t)acc * P.inv29) & M;
+        acc += (uint64_t)m[k] * P.p29[0];   // low 29 bits are now zero
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; ++k) {
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)x[i] * c.l[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * P.p29[k - i];
+        r[k - 9] = (uint32_t)acc & M;
+        acc >>= 29;
+    }
+    r[8] = (uint32_t)acc;
+    // merge the 29-bit limbs back into eight 32-bit words (value < 2p < 2^256)
+    Fe s;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const int bit = 32 * w, i = bit / 29, sh = bit - 29 * i;   // word w starts inside limb i at offset sh
+        uint32_t v = r[i] >> sh;
+        v |= r[i + 1] << (29 - sh);
+        if (29 - sh + 29 < 32 && i + 2 < 9) v |= r[i + 2] << (58 - sh);
+        s.v[w] = v;
+    }
+    Fe d, o;
+    const uint32_t borrow = sub8(d.v, s.v, P.p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = borrow ? s.v[i] : d.v[i];
+    return o;
 }
 
 // ---- 32-byte element I/O (two 16-byte accesses: global_load_dwordx4 / global_store_dwordx4) ---------------

@@ -94,6 +94,9 @@ inline const FieldInfo *field_info(int field) {
         if (i == 255) memcpy(P.r1, v, 32);
     }
     memcpy(P.r2, v, 32);
+    // 29-bit limb view of p and -p^-1 mod 2^29 for the unsaturated multiplier
+    split29(P.p, P.p29);
+    P.inv29 = P.inv & ((1u << 29) - 1);
     I.two_adicity = adicity[field];
     I.generator = gen[field];
     // TWO_ADIC_ROOT_OF_UNITY = g^t with p - 1 = 2^s * t

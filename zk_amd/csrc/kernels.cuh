@@ -25,14 +25,73 @@ ZK_D uint64_t insert_zero_bit(uint64_t val, uint32_t pos) {
 // The reference's r==0 / r==1 shortcuts (:61-62) are the same values, so they are not special-cased.
 // Out of place (in != out) for general pos; in place is race-free only for the MSB fold (pos = m-1).
 __global__ __launch_bounds__(kBlock) void k_fold(const uint64_t *in, uint64_t *out,
-                                                 uint64_t pairs, uint32_t pos, FieldParams P, Fe r) {
+                                                 uint64_t pairs, uint32_t pos, FieldParams P, Mul29 r) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < pairs; j += stride) {
         const uint64_t l = insert_zero_bit(j, pos);
         const Fe lo = fe_load(in, l);
         const Fe hi = fe_load(in, l | (1ull << pos));
         const Fe d = fe_sub(lo, hi, P);
-        fe_store(out, j, fe_sub(lo, fe_mul(r, d, P), P));
+        fe_store(out, j, fe_sub(lo, fe_mul29(d, r, P), P));   // r is prepared on the host: mul29_prepare(challenge)
+    }
+}
+
+// ---- the sumcheck fold (variable 0 = index MSB) as the bandwidth kernel --------------------------------------------
+// Same arithmetic as k_fold with pos = m-1, different data movement: a wave moves 64 consecutive elements of each of
+// the three streams (lo, hi, out) as two fully coalesced 1-KiB dwordx4 accesses (lane l touches bytes [16l, 16l+16) of
+// the run), and lanes 2i / 2i+1 swap halves with one DPP quad_perm so each lane ends up owning one whole element
+// (even lane: element i, odd lane: element 32+i).  All accesses are nontemporal: the table is streamed once.
+// Measured on MI355X (tools/mb/mb_stream.hip, 2^24): 5.8-5.9 TB/s vs 5.4 TB/s for the 32-B-per-lane form.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+ZK_D uint4 nt_load16(const uint4 *p) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+ZK_D void nt_store16(uint4 v, uint4 *p) {
+    const u32x4_t w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(p));
+}
+ZK_D uint32_t swap_pair_lane(uint32_t v) { return __builtin_amdgcn_mov_dpp(v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true); }
+// chunks A (elements 0..31 of the run) and B (elements 32..63): lane l holds half (l & 1) of element (l >> 1) of each
+ZK_D Fe pair_gather(const uint4 &A, const uint4 &B, bool odd) {
+    const uint4 send = odd ? A : B;   // what the neighbour needs from me
+    const uint4 recv = make_uint4(swap_pair_lane(send.x), swap_pair_lane(send.y), swap_pair_lane(send.z), swap_pair_lane(send.w));
+    Fe r;
+    if (!odd) r = {{A.x, A.y, A.z, A.w, recv.x, recv.y, recv.z, recv.w}};
+    else r = {{recv.x, recv.y, recv.z, recv.w, B.x, B.y, B.z, B.w}};
+    return r;
+}
+ZK_D void pair_scatter(const Fe &e, bool odd, uint4 &A, uint4 &B) {
+    const uint4 lo = make_uint4(e.v[0], e.v[1], e.v[2], e.v[3]), hi = make_uint4(e.v[4], e.v[5], e.v[6], e.v[7]);
+    const uint4 send = odd ? lo : hi;
+    const uint4 recv = make_uint4(swap_pair_lane(send.x), swap_pair_lane(send.y), swap_pair_lane(send.z), swap_pair_lane(send.w));
+    if (!odd) {
+        A = lo;
+        B = recv;
+    } else {
+        A = recv;
+        B = hi;
+    }
+}
+// half = 2^(m-1) >= 64 (a multiple of 64).  Out of place or in place (a wave reads its 64 lo/hi elements before
+// writing the 64 outputs at the lo positions; no other wave touches them).
+__global__ __launch_bounds__(kBlock) void k_fold_msb(const uint64_t *in, uint64_t *out, uint64_t half, FieldParams P, Mul29 r) {
+    const uint32_t lane = threadIdx.x & 63;
+    const bool odd = lane & 1;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * kBlock) >> 6;
+    const uint4 *in4 = reinterpret_cast<const uint4 *>(in);
+    uint4 *out4 = reinterpret_cast<uint4 *>(out);
+    for (uint64_t e0 = wave * 64; e0 < half; e0 += nwaves * 64) {
+        const uint64_t c0 = 2 * e0 + lane;   // element e occupies uint4 slots 2e, 2e+1
+        const uint4 la = nt_load16(in4 + c0), lb = nt_load16(in4 + c0 + 64);
+        const uint4 ha = nt_load16(in4 + c0 + 2 * half), hb = nt_load16(in4 + c0 + 2 * half + 64);
+        const Fe lo = pair_gather(la, lb, odd), hi = pair_gather(ha, hb, odd);
+        const Fe o = fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P);
+        uint4 oa, ob;
+        pair_scatter(o, odd, oa, ob);
+        nt_store16(oa, out4 + c0);
+        nt_store16(ob, out4 + c0 + 64);
     }
 }
 
@@ -41,12 +100,12 @@ __global__ __launch_bounds__(kBlock) void k_fold(const uint64_t *in, uint64_t *o
 __global__ __launch_bounds__(kBlock) void k_fold_dev(const uint64_t *in, uint64_t *out, uint64_t pairs, uint32_t m,
                                                      FieldParams P, const uint64_t *__restrict__ rptr) {
     (void)m;
-    const Fe r = fe_load(rptr, 0);
+    const Mul29 r = load_challenge29(rptr);
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < pairs; j += stride) {
         const Fe lo = fe_load(in, j);
         const Fe hi = fe_load(in, j + pairs);
-        fe_store(out, j, fe_sub(lo, fe_mul(r, fe_sub(lo, hi, P), P), P));
+        fe_store(out, j, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P));
     }
 }
 
@@ -181,8 +240,12 @@ ZK_D void transcript_round(WordSponge *gsp, const Fe *sums, uint32_t ns, uint64_
         x[2 * i + 1] = (uint32_t)(h[i] >> 32);
     }
     const Fe ch = fe_from_canonical(fe_reduce_u256(x, P), P);
+    const Mul29 ch29 = mul29_prepare(ch, P);   // the form the next round's fused fold multiplies by (fe_mul29)
     if (L.lane == 0) {
         fe_store(d_challenge, 0, ch);
+        uint32_t *rec = reinterpret_cast<uint32_t *>(d_challenge) + 8;   // challenge record: [Fe r][Mul29 r*2^5]
+#pragma unroll
+        for (int i = 0; i < 9; ++i) rec[i] = ch29.l[i];
         if (out_ch) fe_store(out_ch, 0, ch);
         gsp->pos = sp.pos;
     }
@@ -380,14 +443,22 @@ __global__ __launch_bounds__(kBlock) void k_scale(uint64_t *__restrict__ data, u
 
 // ---- measurement kernels -----------------------------------------------------------------------------------------
 // dependent fe_mul chain entirely in registers: 2 independent chains per thread
-__global__ __launch_bounds__(kBlock) void k_bench_modmul(uint64_t *__restrict__ out, int iters, FieldParams P, Fe seed) {
+__global__ __launch_bounds__(kBlock) void k_bench_modmul(uint64_t *__restrict__ out, int iters, FieldParams P, Fe seed, Mul29 c29,
+                                                         int variant) {
     Fe a = seed, b = seed;
     a.v[0] ^= threadIdx.x;
-    b.v[1] ^= blockIdx.x;
+    b.v[1] ^= blockIdx.x + 7u * threadIdx.x;   // both chains per-lane (a uniform chain would be scalarised)
     a = fe_from_canonical(fe_to_canonical(a, P), P);
-    for (int i = 0; i < iters; ++i) {
-        a = fe_mul(a, b, P);
-        b = fe_mul(b, a, P);
+    if (variant == 0) {          // saturated Montgomery product of two variable operands
+        for (int i = 0; i < iters; ++i) {
+            a = fe_mul(a, b, P);
+            b = fe_mul(b, a, P);
+        }
+    } else {                     // unsaturated product by a prepared (wave-uniform) operand
+        for (int i = 0; i < iters; ++i) {
+            a = fe_mul29(a, c29, P);
+            b = fe_mul29(b, c29, P);
+        }
     }
     if (a.v[0] == 0x12345678u && b.v[3] == 0x9abcdef0u) fe_store(out, 0, a);   // keep the chain live
 }

@@ -54,12 +54,8 @@ __global__ __launch_bounds__(kBlock) void k_round(FactorPtrs fp, int k, uint64_t
                                                   const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials) {
     constexpr int NS = D + 1;
     // the previous round's challenge is produced on the device by k_round_tail (no host round trip)
-    Fe r = fe_zero();
-    if (FUSED) {
-        r = fe_load(rptr, 0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r.v[i] = __builtin_amdgcn_readfirstlane(r.v[i]);   // wave-uniform -> SGPRs
-    }
+    Mul29 r = {};
+    if (FUSED) r = load_challenge29(rptr);
     Fe sum[NS];
     WideAcc acc[NS];
 #pragma unroll
@@ -76,8 +72,8 @@ __global__ __launch_bounds__(kBlock) void k_round(FactorPtrs fp, int k, uint64_t
             if (FUSED) {
                 const Fe a0 = fe_load(fp.in[f], j), a1 = fe_load(fp.in[f], j + q);
                 const Fe a2 = fe_load(fp.in[f], j + 2 * q), a3 = fe_load(fp.in[f], j + 3 * q);
-                lo = fe_sub(a0, fe_mul(r, fe_sub(a0, a2, P), P), P);
-                hi = fe_sub(a1, fe_mul(r, fe_sub(a1, a3, P), P), P);
+                lo = fe_sub(a0, fe_mul29(fe_sub(a0, a2, P), r, P), P);
+                hi = fe_sub(a1, fe_mul29(fe_sub(a1, a3, P), r, P), P);
                 fe_store(fp.out[f], j, lo);
                 fe_store(fp.out[f], j + q, hi);
             } else {
@@ -130,12 +126,12 @@ struct RoundRegs {
 };
 template <int F, int K, int D, bool FUSED>
 ZK_D void round_factor(RoundRegs<K, D, FUSED> &R, const FactorPtrs &fp, uint64_t j, uint64_t jn, bool more, uint64_t q,
-                       const Fe &r, const FieldParams &P) {
+                       const Mul29 &r, const FieldParams &P) {
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
     Fe lo, hi;
     if (FUSED) {
-        lo = fe_sub(R.cur[F][0], fe_mul(r, fe_sub(R.cur[F][0], R.cur[F][2], P), P), P);
-        hi = fe_sub(R.cur[F][1], fe_mul(r, fe_sub(R.cur[F][1], R.cur[F][3], P), P), P);
+        lo = fe_sub(R.cur[F][0], fe_mul29(fe_sub(R.cur[F][0], R.cur[F][2], P), r, P), P);
+        hi = fe_sub(R.cur[F][1], fe_mul29(fe_sub(R.cur[F][1], R.cur[F][3], P), r, P), P);
         fe_store(fp.out[F], j, lo);
         fe_store(fp.out[F], j + q, hi);
     } else {
@@ -163,12 +159,8 @@ template <int K, int D, bool FUSED>
 __global__ __launch_bounds__(kBlock, (K <= 2 ? 2 : 1)) void k_round_kd(FactorPtrs fp, uint64_t q, FieldParams P,
                                                         const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials) {
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
-    Fe r = fe_zero();
-    if (FUSED) {
-        r = fe_load(rptr, 0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r.v[i] = __builtin_amdgcn_readfirstlane(r.v[i]);
-    }
+    Mul29 r = {};
+    if (FUSED) r = load_challenge29(rptr);
     RoundRegs<K, D, FUSED> R;
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
