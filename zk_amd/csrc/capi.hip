@@ -796,6 +796,54 @@ static int32_t round_enqueue(RoundState &st, uint64_t *lanes) {
     return rc;
 }
 
+// ---- finisher: every remaining round in one single-workgroup launch (k_finish) ----
+template <int K, int D>
+static int32_t launch_finish(zk_ctx *c, const FactorPtrs &fp, uint32_t m_in, int pending, uint64_t *d_challenge, WordSponge *sp,
+                             uint64_t *out_rp, uint64_t *out_ch) {
+    const uint32_t m = pending ? m_in - 1 : m_in;
+    const size_t lds = (size_t)K * ((size_t)32 << m) + (kBlock / 64) * (D + 1) * 32 + (D + 1) * 32 + 48;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_finish<K, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_finish<K, D><<<1, kBlock, lds, c->stream>>>(fp, m_in, pending, c->fi->P, d_challenge, sp, out_rp, out_ch);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+static bool finish_shape_ok(uint64_t k, uint32_t D) {
+    const int shape = (int)k * 10 + (int)D;
+    return shape == 11 || shape == 12 || shape == 21 || shape == 22 || shape == 23 || shape == 32 || shape == 33;
+}
+// Runs rounds st.round .. (st.round + remaining - 1) where remaining = variables left after the pending fold.
+static int32_t finish_enqueue(RoundState &st) {
+    zk_ctx *c = st.c;
+    FactorPtrs fp = {};
+    for (uint64_t i = 0; i < st.k; ++i) fp.in[i] = st.cur[i];
+    const int pending = st.pending_fold ? 1 : 0;
+    const uint32_t m_in = (uint32_t)st.vars_left;
+    const uint64_t remaining = pending ? st.vars_left - 1 : st.vars_left;
+    uint64_t *out_rp = st.ps.d_rp + st.round * (st.D + 1) * 4, *out_ch = st.ps.d_ch + st.round * 4;
+    int32_t rc = ZK_ERR_UNSUPPORTED;
+    switch ((int)st.k * 10 + (int)st.D) {
+        case 11: rc = launch_finish<1, 1>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch); break;
+        case 12: rc = launch_finish<1, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch); break;
+        case 21: rc = launch_finish<2, 1>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch); break;
+        case 22: rc = launch_finish<2, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch); break;
+        case 23: rc = launch_finish<2, 3>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch); break;
+        case 32: rc = launch_finish<3, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch); break;
+        case 33: rc = launch_finish<3, 3>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch); break;
+        default: break;
+    }
+    if (rc == ZK_OK) {
+        st.round += remaining;
+        st.vars_left = 0;
+        st.pending_fold = false;
+    }
+    return rc;
+}
+static inline bool finish_applies(const RoundState &st) {
+    if (!finish_shape_ok(st.k, st.D)) return false;
+    const uint64_t after = st.pending_fold ? st.vars_left - 1 : st.vars_left;
+    return after >= 1 && after <= (uint64_t)kFinishVars;
+}
+
 // host byte sponge (table + claimed sum absorbed) -> device word sponge
 static int32_t sponge_to_device(zk_ctx *c, const Sponge &host, WordSponge *d_sponge) {
     WordSponge *w = reinterpret_cast<WordSponge *>(c->h_pinned);
@@ -821,7 +869,14 @@ extern "C" int32_t zk_sumcheck_prove(zk_ctx *c, zk_mle *const *f, uint64_t k, ui
     RoundState st;
     ZKCHK(round_state_init(st, c, f, k, D, consume != 0, n));
     int32_t rc = sponge_to_device(c, sp, st.ps.d_sponge);
-    for (; st.round < n && rc == ZK_OK; ++st.round) rc = round_enqueue(st, nullptr);   // prover.rs:44-68, all on device
+    while (st.round < n && rc == ZK_OK) {                                // prover.rs:44-68, all on device
+        if (finish_applies(st)) {
+            rc = finish_enqueue(st);                                     // all remaining rounds in one launch
+        } else {
+            rc = round_enqueue(st, nullptr);
+            ++st.round;
+        }
+    }
     // prover.rs:64 after the LAST round folds to a 0-variable polynomial the reference drops: not computed.
     if (rc == ZK_OK) {
         if (hipMemcpyAsync(out_rp, st.ps.d_rp, (size_t)n * (D + 1) * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -983,7 +1038,14 @@ extern "C" int32_t zk_shard_prover_tail_rounds(zk_shard_prover *sp, const void *
     st.first_out_of_place = false;
     st.vars_left = sp->total_rounds - sp->local_rounds;
     int32_t rc = ZK_OK;
-    for (; st.round < sp->total_rounds && rc == ZK_OK; ++st.round) rc = round_enqueue(st, nullptr);
+    while (st.round < sp->total_rounds && rc == ZK_OK) {
+        if (finish_applies(st)) {
+            rc = finish_enqueue(st);
+        } else {
+            rc = round_enqueue(st, nullptr);
+            ++st.round;
+        }
+    }
     return rc;
 }
 // download what has been proven so far (synchronises): total_rounds*(D+1) and total_rounds elements

@@ -200,13 +200,18 @@ ZK_D void lane_absorb_word(LaneSponge &sp, uint64_t w, const LaneKeccak &L) {   
 
 // One transcript step on one wave (all 64 lanes execute it; lanes >= 25 idle along):
 // absorb the round polynomial as 32-byte big-endian canonical elements (sumcheck/src/lib.rs:23-29), squeeze the
-// challenge (transcript/src/lib.rs:20-30) and publish it in Montgomery form for the next round's fused fold.
-ZK_D void transcript_round(WordSponge *gsp, const Fe *sums, uint32_t ns, uint64_t *d_challenge, uint64_t *out_ch,
-                           const FieldParams &P) {
-    const LaneKeccak L = lane_keccak_init();
+// challenge (transcript/src/lib.rs:20-30) and return it in Montgomery form (wave-uniform).
+ZK_D LaneSponge lane_sponge_load(const WordSponge *gsp, const LaneKeccak &L) {
     LaneSponge sp;
     sp.a = (L.lane < 25) ? gsp->s[L.lane] : 0ull;
     sp.pos = __builtin_amdgcn_readfirstlane(gsp->pos);
+    return sp;
+}
+ZK_D void lane_sponge_store(WordSponge *gsp, const LaneSponge &sp, const LaneKeccak &L) {
+    if (L.lane < 25) gsp->s[L.lane] = sp.a;
+    if (L.lane == 0) gsp->pos = sp.pos;
+}
+ZK_D Fe transcript_step(LaneSponge &sp, const LaneKeccak &L, const Fe *sums, uint32_t ns, const FieldParams &P) {
     for (uint32_t base = 0; base < ns; base += 64) {
         // lane t converts sum (base + t): Montgomery -> canonical, in parallel across lanes
         const uint32_t mine = base + (uint32_t)L.lane < ns ? base + (uint32_t)L.lane : ns - 1;
@@ -239,17 +244,25 @@ ZK_D void transcript_round(WordSponge *gsp, const Fe *sums, uint32_t ns, uint64_
         x[2 * i] = (uint32_t)h[i];
         x[2 * i + 1] = (uint32_t)(h[i] >> 32);
     }
-    const Fe ch = fe_from_canonical(fe_reduce_u256(x, P), P);
-    const Mul29 ch29 = mul29_prepare(ch, P);   // the form the next round's fused fold multiplies by (fe_mul29)
-    if (L.lane == 0) {
+    return fe_from_canonical(fe_reduce_u256(x, P), P);
+}
+// publish a challenge for the next round's fused fold: [Fe r][Mul29 of r] (common.cuh, kChallengeBytes)
+ZK_D void publish_challenge(uint64_t *d_challenge, uint64_t *out_ch, const Fe &ch, const Mul29 &ch29, int lane) {
+    if (lane == 0) {
         fe_store(d_challenge, 0, ch);
-        uint32_t *rec = reinterpret_cast<uint32_t *>(d_challenge) + 8;   // challenge record: [Fe r][Mul29 r*2^5]
+        uint32_t *rec = reinterpret_cast<uint32_t *>(d_challenge) + 8;
 #pragma unroll
         for (int i = 0; i < 9; ++i) rec[i] = ch29.l[i];
         if (out_ch) fe_store(out_ch, 0, ch);
-        gsp->pos = sp.pos;
     }
-    if (L.lane < 25) gsp->s[L.lane] = sp.a;
+}
+ZK_D void transcript_round(WordSponge *gsp, const Fe *sums, uint32_t ns, uint64_t *d_challenge, uint64_t *out_ch,
+                           const FieldParams &P) {
+    const LaneKeccak L = lane_keccak_init();
+    LaneSponge sp = lane_sponge_load(gsp, L);
+    const Fe ch = transcript_step(sp, L, sums, ns, P);
+    publish_challenge(d_challenge, out_ch, ch, mul29_prepare(ch, P), L.lane);
+    lane_sponge_store(gsp, sp, L);
 }
 
 // Second stage of a round: one workgroup adds the per-block partials -> ns sums (Montgomery form); then, on lane 0,
@@ -301,6 +314,136 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
         }
     }
     if (sponge && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) transcript_round(sponge, fin, ns, d_challenge, out_ch, P);
+}
+
+// ---- finisher: all remaining rounds of the prover in ONE launch, once the tables are small ---------------------------
+// A round on a tiny table is pure latency (two launches, a trip through HBM for 96 bytes of sums, the serial transcript).
+// One workgroup keeps the K tables (<= 2^kFinishVars elements each) in LDS and the sponge in the registers of wave 0 and
+// loops: sums -> workgroup reduction -> transcript step -> fold in LDS (prover.rs:44-68, unchanged semantics).
+//   pending != 0: the tables in HBM still need the previous challenge applied (prover.rs:64) while they are loaded.
+constexpr int kFinishVars = 9;
+template <int K, int D>
+__global__ __launch_bounds__(kBlock) void k_finish(FactorPtrs fp, uint32_t m_in, int pending, FieldParams P,
+                                                   uint64_t *d_challenge, WordSponge *gsponge, uint64_t *out_rp, uint64_t *out_ch) {
+    constexpr int NS = D + 1;
+    // all LDS is carved from the dynamic region at 16-byte aligned offsets (no static __shared__ in front of it)
+    extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool wave0 = __builtin_amdgcn_readfirstlane(wave) == 0;
+    uint32_t m = pending ? m_in - 1 : m_in;       // variables of the tables held in LDS
+    const uint32_t n_elems = 1u << m;
+    uint64_t *tab = reinterpret_cast<uint64_t *>(fin_smem);                 // K tables of 2^m elements, 4 u64 each
+    unsigned char *carve = fin_smem + (size_t)K * n_elems * 32;
+    uint32_t(*red)[NS][8] = reinterpret_cast<uint32_t(*)[NS][8]>(carve);    // [waves][NS][8]
+    Fe *fin = reinterpret_cast<Fe *>(carve + (kBlock / 64) * NS * 32);
+    Mul29 *sh_r29p = reinterpret_cast<Mul29 *>(carve + (kBlock / 64) * NS * 32 + NS * 32);
+    // ---- load (and fold when pending) ----
+    if (pending) {
+        const Mul29 r = load_challenge29(d_challenge);
+#pragma unroll
+        for (int f = 0; f < K; ++f)
+            for (uint32_t j = tid; j < n_elems; j += kBlock) {
+                const Fe lo = fe_load(fp.in[f], j), hi = fe_load(fp.in[f], j + n_elems);
+                fe_store(tab + (size_t)f * n_elems * 4, j, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P));
+            }
+    } else {
+#pragma unroll
+        for (int f = 0; f < K; ++f)
+            for (uint32_t j = tid; j < n_elems; j += kBlock) fe_store(tab + (size_t)f * n_elems * 4, j, fe_load(fp.in[f], j));
+    }
+    LaneKeccak L = lane_keccak_init();
+    LaneSponge sp = {0, 0};
+    if (wave0) sp = lane_sponge_load(gsponge, L);
+    __syncthreads();
+    uint32_t round = 0;
+    while (m >= 1) {
+        const uint32_t q = 1u << (m - 1);
+        // ---- sums over the pairs (j, j+q) ----
+        Fe sum[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) sum[t] = fe_zero();
+        for (uint32_t j = tid; j < q; j += kBlock) {
+            Fe prod[NS];
+#pragma unroll
+            for (int f = 0; f < K; ++f) {
+                const uint64_t *T = tab + (size_t)f * n_elems * 4;
+                const Fe lo = fe_load(T, j), hi = fe_load(T, j + q);
+                const Fe diff = fe_sub(hi, lo, P);
+                Fe v = lo;
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+                    if (t == 1) v = hi;
+                    else if (t > 1) v = fe_add(v, diff, P);
+                    prod[t] = (f == 0) ? v : fe_mul(prod[t], v, P);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NS; ++t) sum[t] = fe_add(sum[t], prod[t], P);
+        }
+        // ---- workgroup reduction -> fin[] ----
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                if ((uint32_t)off < q || off < 2) {   // lanes >= q hold zero: skip empty levels (uniform condition)
+                    Fe o;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o.v[i] = __shfl_xor(sum[t].v[i], off, 64);
+                    sum[t] = fe_add(sum[t], o, P);
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) red[wave][t][i] = sum[t].v[i];
+            }
+        }
+        __syncthreads();
+        if (tid < NS) {
+            Fe acc;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc.v[i] = red[0][tid][i];
+            if (q > 64) {
+                for (int w = 1; w < kBlock / 64; ++w) {
+                    Fe o;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o.v[i] = red[w][tid][i];
+                    acc = fe_add(acc, o, P);
+                }
+            }
+            fin[tid] = acc;
+            fe_store(out_rp, (uint64_t)round * NS + tid, acc);
+        }
+        __syncthreads();
+        // ---- transcript step on wave 0, challenge to everyone through LDS ----
+        if (wave0) {
+            const Fe ch = transcript_step(sp, L, fin, NS, P);
+            const Mul29 ch29 = mul29_prepare(ch, P);
+            if (lane == 0) {
+                fe_store(out_ch, round, ch);
+                *sh_r29p = ch29;
+            }
+            if (m == 1) publish_challenge(d_challenge, nullptr, ch, ch29, (int)lane);   // last one: for the sharded tail
+        }
+        __syncthreads();
+        // ---- fold at the challenge, in LDS (prover.rs:64); the fold after the last round is dropped by the reference
+        if (m > 1) {
+            Mul29 r;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) r.l[i] = __builtin_amdgcn_readfirstlane(sh_r29p->l[i]);
+#pragma unroll
+            for (int f = 0; f < K; ++f) {
+                uint64_t *T = tab + (size_t)f * n_elems * 4;
+                for (uint32_t j = tid; j < q; j += kBlock) {
+                    const Fe lo = fe_load(T, j), hi = fe_load(T, j + q);
+                    fe_store(T, j, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P));
+                }
+            }
+            __syncthreads();
+        }
+        --m;
+        ++round;
+    }
+    if (wave0) lane_sponge_store(gsponge, sp, L);
 }
 
 // Sharded prover, after the all-reduce: lanes hold sums over ranks of 32-bit digits.  Carry-propagate, reduce mod p
