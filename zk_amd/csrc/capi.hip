@@ -1188,12 +1188,14 @@ static void ntt_make_plan(uint32_t log_n, NttPlan &pl) {
     const uint32_t base = log_n / pl.n_pass, rem = log_n % pl.n_pass;
     for (uint32_t p = 0; p < 4; ++p) pl.l[p] = p < pl.n_pass ? base + (p < rem ? 1 : 0) : 0;
     pl.lo_bits = log_n < 12 ? log_n : 12;
-    pl.w_lo = pl.w_hi = nullptr;
+    pl.w_lo = nullptr;
+    pl.w_hi = nullptr;
 }
 static int32_t ntt_build_tables(zk_ctx *c, NttPlan &pl, const Fe &omega) {
     const uint32_t hi_bits = pl.log_n - pl.lo_bits;
-    uint64_t *lo = nullptr, *hi = nullptr;
-    HIPCHK(hipMalloc(&lo, (size_t)32 << pl.lo_bits));
+    uint32_t *lo = nullptr;
+    uint64_t *hi = nullptr;
+    HIPCHK(hipMalloc(&lo, ((size_t)kTw29Words * 4) << pl.lo_bits));
     if (hipMalloc(&hi, (size_t)32 << hi_bits) != hipSuccess) {
         (void)hipFree(lo);
         return ZK_ERR_ALLOC;
@@ -1208,38 +1210,51 @@ static int32_t ntt_build_tables(zk_ctx *c, NttPlan &pl, const Fe &omega) {
     pl.w_hi = hi;
     return ZK_OK;
 }
+template <int L>
+static hipError_t ntt_launch_l(const NttPlan &pl, uint32_t p, bool last, uint32_t tiles, size_t lds, hipStream_t st, const uint64_t *src,
+                               uint64_t *dst, const FieldParams &P, const Mul29 &scale, int do_scale) {
+    hipError_t e;
+    if (!last) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_pass<L, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        k_ntt_pass<L, false><<<tiles, kNttThreads, lds, st>>>(src, dst, pl, p, P, scale, 0);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_pass<L, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        k_ntt_pass<L, true><<<tiles, kNttThreads, lds, st>>>(src, dst, pl, p, P, scale, do_scale);
+    }
+    return hipGetLastError();
+}
+static hipError_t ntt_launch_pass(const NttPlan &pl, uint32_t p, bool last, uint32_t tiles, size_t lds, hipStream_t st,
+                                  const uint64_t *src, uint64_t *dst, const FieldParams &P, const Mul29 &scale, int do_scale) {
+    switch (pl.l[p]) {
+        case 4: return ntt_launch_l<4>(pl, p, last, tiles, lds, st, src, dst, P, scale, do_scale);
+        case 5: return ntt_launch_l<5>(pl, p, last, tiles, lds, st, src, dst, P, scale, do_scale);
+        case 6: return ntt_launch_l<6>(pl, p, last, tiles, lds, st, src, dst, P, scale, do_scale);
+        case 7: return ntt_launch_l<7>(pl, p, last, tiles, lds, st, src, dst, P, scale, do_scale);
+        case 8: return ntt_launch_l<8>(pl, p, last, tiles, lds, st, src, dst, P, scale, do_scale);
+        default: return hipErrorInvalidValue;
+    }
+}
 static int32_t ntt_run_plan(zk_ctx *c, const NttPlan &pl, const uint64_t *in, uint64_t *out, bool inverse) {
     const FieldParams &P = c->fi->P;
     const uint64_t n = 1ull << pl.log_n;
     uint64_t *scratch = nullptr;
     ZKCHK(pool_alloc(c, (size_t)n * 32, (void **)&scratch));
-    Fe scale = fe_one(P);
+    Mul29 scale = {};
     if (inverse) {                                                               // fft/src/lib.rs:17: * F::from(n).inverse()
         const uint64_t nl[4] = {n, 0, 0, 0};
-        scale = fe_inverse(fe_from_canonical(fe_from_u64limbs(nl), P), P);
+        scale = mul29_prepare(fe_inverse(fe_from_canonical(fe_from_u64limbs(nl), P), P), P);
     }
     int32_t rc = ZK_OK;
     const uint64_t *src = in;
     for (uint32_t p = 0; p < pl.n_pass && rc == ZK_OK; ++p) {
         const uint32_t R = 1u << pl.l[p];
-        const size_t lds = 2 * (size_t)R * kNttRowBytes + (size_t)(R / 2) * 32;
+        const size_t lds = 2 * (size_t)R * kNttRowBytes + (size_t)(R / 2) * kTw29Words * 4;
         const uint32_t tiles = (uint32_t)(n / ((uint64_t)R * kNttCols));
         const bool last = p + 1 == pl.n_pass;
-        hipError_t e;
-        if (!last) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_pass<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) {
-                k_ntt_pass<false><<<tiles, kNttThreads, lds, c->stream>>>(src, scratch, pl, p, P, scale, 0);
-                e = hipGetLastError();
-            }
-            src = scratch;   // middle passes keep their addresses: later ones run in place on scratch
-        } else {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_pass<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) {
-                k_ntt_pass<true><<<tiles, kNttThreads, lds, c->stream>>>(src, out, pl, p, P, scale, inverse ? 1 : 0);
-                e = hipGetLastError();
-            }
-        }
+        hipError_t e = ntt_launch_pass(pl, p, last, tiles, lds, c->stream, src, last ? out : scratch, P, scale, (last && inverse) ? 1 : 0);
+        if (!last) src = scratch;   // middle passes keep their addresses: later ones run in place on scratch
         if (e != hipSuccess) {
             g_hip_err = std::string("ntt pass: ") + hipGetErrorString(e);
             rc = ZK_ERR_HIP;

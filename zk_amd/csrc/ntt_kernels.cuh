@@ -29,21 +29,42 @@ constexpr int kNttRowBytes = 272;     // 16 slots * 16 B + 16 B pad
 constexpr int kNttThreads = 512;
 constexpr int kNttMaxLog = 8;         // R <= 256
 
+// Twiddles are stored ready for the carry-free multiplier (field.cuh fe_mul29): every multiplication of the transform
+// has a table value as one operand, so the tables hold omega^e * 2^5 mod p -- the low table already split into nine
+// 29-bit limbs (Mul29, 64-byte records), the high table as a plain element so that two levels compose with one more
+// fe_mul29:  hi' (x) lo' = (w_hi 2^5)(w_lo 2^5) 2^-261 = (w_hi w_lo) 2^5, again a prepared value.
+constexpr int kTw29Words = 16;   // record stride of a stored Mul29 (9 words used)
 struct NttPlan {
     uint32_t log_n;
     uint32_t n_pass;
     uint32_t l[4];          // log2 radix of each pass
-    uint32_t lo_bits;       // two-level twiddle table: w_lo[i] = omega^i (i < 2^lo_bits), w_hi[i] = omega^(i << lo_bits)
-    const uint64_t *w_lo;
-    const uint64_t *w_hi;
+    uint32_t lo_bits;       // two-level table: w_lo[i] ~ omega^i (i < 2^lo_bits), w_hi[i] ~ omega^(i << lo_bits)
+    const uint32_t *w_lo;   // Mul29 records of omega^i
+    const uint64_t *w_hi;   // elements omega^(i << lo_bits) * 2^5 mod p
 };
-
-// omega^e from the two-level table (e < n)
-ZK_D Fe ntt_twiddle(const NttPlan &pl, uint64_t e, const FieldParams &P) {
+ZK_D Mul29 load_mul29(const uint32_t *rec) {
+    const uint4 a = *reinterpret_cast<const uint4 *>(rec), b = *reinterpret_cast<const uint4 *>(rec + 4);
+    Mul29 m = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, rec[8]}};
+    return m;
+}
+ZK_D void store_mul29(uint32_t *rec, const Mul29 &m) {
+    *reinterpret_cast<uint4 *>(rec) = make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]);
+    *reinterpret_cast<uint4 *>(rec + 4) = make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]);
+    rec[8] = m.l[8];
+}
+// prepared multiplier for omega^e (e < n)
+ZK_D Mul29 ntt_twiddle(const NttPlan &pl, uint64_t e, const FieldParams &P) {
     const uint64_t lo = e & ((1ull << pl.lo_bits) - 1), hi = e >> pl.lo_bits;
-    if (hi == 0) return fe_load(pl.w_lo, lo);
-    if (lo == 0) return fe_load(pl.w_hi, hi);
-    return fe_mul(fe_load(pl.w_hi, hi), fe_load(pl.w_lo, lo), P);
+    if (hi == 0) return load_mul29(pl.w_lo + lo * kTw29Words);
+    const Fe h = fe_load(pl.w_hi, hi);
+    Mul29 m;
+    if (lo == 0) {
+        split29(h.v, m.l);
+        return m;
+    }
+    const Fe c = fe_mul29(h, load_mul29(pl.w_lo + lo * kTw29Words), P);
+    split29(c.v, m.l);
+    return m;
 }
 
 ZK_D uint32_t lds_off(uint32_t row, uint32_t col) { return row * kNttRowBytes + col * 16; }
@@ -58,16 +79,55 @@ ZK_D void lds_put(unsigned char *lo_plane, unsigned char *hi_plane, uint32_t row
     *reinterpret_cast<uint4 *>(hi_plane + lds_off(row, col)) = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
 }
 
-// LAST = false: pass p < P (strided axis, inter-pass twiddle, same addresses in and out)
-// LAST = true : pass P (contiguous axis, transposing store, optional scaling by n^-1 for the inverse transform)
-template <bool LAST>
+// ---- stage groups -----------------------------------------------------------------------------------------------------
+// The l radix-2 DIF stages of a tile are run in groups of up to 3 stages: a thread holds the 2^g rows (one column) that
+// interact inside the group in REGISTERS and does the g stages there; tiles cross LDS only between groups (l = 8: groups
+// 3+3+2 -> two exchanges instead of eight), the first group is fed straight from HBM and the last one stores straight to
+// HBM.  Rows of a group covering stages s_hi..s_lo: r = (pre << (s_hi+1)) | (u << s_lo) | post, u = 0..2^g-1.
+// DIF butterfly at stage s (half h = 2^s): (x_r, x_(r+h)) <- (x_r + x_(r+h), (x_r - x_(r+h)) * omega_R^((r mod h) * R/(2h))).
+template <int L>
+struct NttGroups {   // group sizes from the top stage down
+    static constexpr int n = L <= 3 ? 1 : (L <= 6 ? 2 : 3);
+    static constexpr int g0 = (L + n - 1) / n;
+    static constexpr int g1 = n > 1 ? (L - g0 + (n - 1) - 1) / (n - 1) : 0;
+    static constexpr int g2 = n > 2 ? L - g0 - g1 : 0;
+};
+// compile-time recursion over (stage within the group SU, butterfly B): every x[] index is a constant, so the group
+// stays in registers (a runtime-indexed array would go to scratch)
+template <int L, int S_LO, int G, int SU, int B>
+ZK_D void ntt_bfly(Fe (&x)[1 << G], uint32_t post, const uint32_t *tws, const FieldParams &P) {
+    constexpr uint32_t hu = 1u << SU;
+    constexpr uint32_t ua = (uint32_t)((B >> SU) << (SU + 1)) | (B & (hu - 1)), ub = ua + hu;
+    constexpr int s = S_LO + SU;             // global stage
+    const Fe a0 = x[ua], a1 = x[ub];
+    Fe d = fe_sub(a0, a1, P);
+    if constexpr (s > 0) {                   // the s = 0 stage has unit twiddles
+        const uint32_t j = ((ua & (hu - 1)) << S_LO) | post;              // r mod 2^s
+        d = fe_mul29(d, load_mul29(tws + ((size_t)j << (L - 1 - s)) * kTw29Words), P);
+    }
+    x[ua] = fe_add(a0, a1, P);
+    x[ub] = d;
+    if constexpr (B + 1 < (1 << (G - 1))) ntt_bfly<L, S_LO, G, SU, B + 1>(x, post, tws, P);
+    else if constexpr (SU > 0) ntt_bfly<L, S_LO, G, SU - 1, 0>(x, post, tws, P);
+}
+template <int L, int S_HI, int S_LO>
+ZK_D void ntt_group_stages(Fe (&x)[1 << (S_HI - S_LO + 1)], uint32_t post, const uint32_t *tws, const FieldParams &P) {
+    constexpr int G = S_HI - S_LO + 1;
+    ntt_bfly<L, S_LO, G, G - 1, 0>(x, post, tws, P);
+}
+
+// One pass over one tile.  LAST = false: pass p < P (strided axis, inter-pass twiddle, same addresses in and out);
+// LAST = true: pass P (contiguous axis, transposing store, optional scaling by n^-1 for the inverse transform).
+template <int L, bool LAST>
 __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
-                                                          NttPlan pl, uint32_t pass, FieldParams P, Fe scale, int do_scale) {
+                                                          NttPlan pl, uint32_t pass, FieldParams P, Mul29 scale, int do_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t l = pl.l[pass], R = 1u << l;
+    constexpr uint32_t l = L, R = 1u << L;
+    using GR = NttGroups<L>;
+    constexpr int G0 = GR::g0, G1 = GR::g1, G2 = GR::g2;
     unsigned char *lo_plane = smem;
     unsigned char *hi_plane = smem + (size_t)R * kNttRowBytes;
-    uint64_t *tws = reinterpret_cast<uint64_t *>(smem + 2 * (size_t)R * kNttRowBytes);   // omega_R^j, j < R/2
+    uint32_t *tws = reinterpret_cast<uint32_t *>(smem + 2 * (size_t)R * kNttRowBytes);   // prepared omega_R^j, j < R/2
 
     uint32_t lo_sum = 0;   // log2 O_p
     for (uint32_t p = 0; p < pass; ++p) lo_sum += pl.l[p];
@@ -75,12 +135,12 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
     const uint64_t inner = 1ull << log_inner;
     const uint32_t tid = threadIdx.x;
 
-    // sub-DFT twiddles omega_R^j = omega_N^(j * N/R)
-    for (uint32_t j = tid; j < R / 2; j += kNttThreads) fe_store(tws, j, ntt_twiddle(pl, (uint64_t)j << (pl.log_n - l), P));
+    // sub-DFT twiddles omega_R^j = omega_N^(j * N/R), prepared form
+    for (uint32_t j = tid; j < R / 2; j += kNttThreads) store_mul29(tws + j * kTw29Words, ntt_twiddle(pl, (uint64_t)j << (pl.log_n - l), P));
 
     // ---- tile coordinates ----
-    uint64_t base_in = 0, base_out = 0, tw_i0 = 0;
-    uint64_t out_stride_a = 0;
+    uint64_t base_in = 0, base_out = 0, tw_i0 = 0, out_stride_a = 0;
+    uint32_t t_shift = 0;
     if (!LAST) {
         const uint64_t tiles_per_outer = inner / kNttCols;
         const uint64_t o = blockIdx.x / tiles_per_outer, i0 = (blockIdx.x % tiles_per_outer) * kNttCols;
@@ -92,6 +152,7 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
         const uint32_t log_q = lo_sum - l1;                         // log2 of the `rest` range
         const uint64_t rest = blockIdx.x & ((1ull << log_q) - 1), k1_0 = (blockIdx.x >> log_q) * kNttCols;
         base_in = ((k1_0 << log_q) + rest) << l;                    // + (t << (log_q + l)) + a
+        t_shift = log_q + l;
         // output digit reversal of `rest` = (k_2, .., k_(P-1)), k_2 most significant: sum_j k_j * (R_1 .. R_(j-1))
         uint64_t rev = 0, weight = 1ull << l1;
         uint32_t shift = log_q;
@@ -104,64 +165,88 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
         base_out = k1_0 + rev;                                      // + t + a' * O_P
         out_stride_a = 1ull << lo_sum;
     }
+    __syncthreads();   // tws ready
 
-    // ---- load tile into LDS in natural row order (the stages below are decimation in frequency) ----
-    if (!LAST) {
-        for (uint32_t e = tid; e < R * kNttCols; e += kNttThreads) {
-            const uint32_t t = e & (kNttCols - 1), a = e >> 4;
-            const Fe v = fe_load(in, base_in + ((uint64_t)a << log_inner) + t);
-            lds_put(lo_plane, hi_plane, a, t, v);
-        }
-    } else {
-        const uint32_t l1 = pl.n_pass > 1 ? pl.l[0] : 0;
-        const uint32_t t_shift = (lo_sum - l1) + l;
-        for (uint32_t e = tid; e < R * kNttCols; e += kNttThreads) {
-            const uint32_t a = e & (R - 1), t = e >> l;
-            const Fe v = fe_load(in, base_in + ((uint64_t)t << t_shift) + a);
-            lds_put(lo_plane, hi_plane, a, t, v);
+    // ---- group 0: stages l-1 .. l-G0, rows (u << (l-G0)) | post, straight from HBM ----
+    // thread -> (post, t).  MID: t fastest (512-B runs along the contiguous axis); LAST: post fastest (runs along the DFT axis)
+    constexpr uint32_t items0 = (R >> G0) * kNttCols;
+    {
+        constexpr int S_LO = L - G0;
+        for (uint32_t it = tid; it < items0; it += kNttThreads) {
+            uint32_t t, post;
+            if (!LAST) {
+                t = it & (kNttCols - 1);
+                post = it >> 4;
+            } else {
+                post = it & ((1u << S_LO) - 1);
+                t = it >> S_LO;
+            }
+            Fe x[1 << G0];
+#pragma unroll
+            for (int u = 0; u < (1 << G0); ++u) {
+                const uint32_t a = ((uint32_t)u << S_LO) | post;
+                x[u] = LAST ? fe_load(in, base_in + ((uint64_t)t << t_shift) + a) : fe_load(in, base_in + ((uint64_t)a << log_inner) + t);
+            }
+            ntt_group_stages<L, L - 1, S_LO>(x, post, tws, P);
+#pragma unroll
+            for (int u = 0; u < (1 << G0); ++u) lds_put(lo_plane, hi_plane, ((uint32_t)u << S_LO) | post, t, x[u]);
         }
     }
     __syncthreads();
-
-    // ---- l radix-2 DIF stages, h = R/2 .. 1: (x_j, x_(j+h)) <- (x_j + x_(j+h), (x_j - x_(j+h)) * omega_(2h)^j) ----
-    // natural-order rows in, bit-reversed rows out: frequency k ends up in row bitrev_l(k).  16 lanes share a butterfly
-    // row pair, so every LDS access is one conflict-free 256-B row segment per 16-lane group.
-    for (int s = (int)l - 1; s >= 0; --s) {
-        const uint32_t h = 1u << s;
-        for (uint32_t e = tid; e < (R / 2) * kNttCols; e += kNttThreads) {
-            const uint32_t t = e & (kNttCols - 1), b = e >> 4;
-            const uint32_t j = b & (h - 1), r0 = ((b >> s) << (s + 1)) + j, r1 = r0 + h;
-            const Fe u = lds_get(lo_plane, hi_plane, r0, t);
-            const Fe v = lds_get(lo_plane, hi_plane, r1, t);
-            Fe d = fe_sub(u, v, P);
-            if (s) d = fe_mul(d, fe_load(tws, (uint64_t)j << (l - 1 - s)), P);   // the h = 1 stage has unit twiddles
-            lds_put(lo_plane, hi_plane, r0, t, fe_add(u, v, P));
-            lds_put(lo_plane, hi_plane, r1, t, d);
-        }
-        __syncthreads();
-    }
-
-    // ---- store ----
-    if (!LAST) {
-        const uint64_t tw_scale_log = lo_sum;   // exponent = O_p * i * k
-        for (uint32_t e = tid; e < R * kNttCols; e += kNttThreads) {
-            const uint32_t t = e & (kNttCols - 1), k = e >> 4;
-            Fe v = lds_get(lo_plane, hi_plane, __brev(k) >> (32 - l), t);
-            if (k) v = fe_mul(v, ntt_twiddle(pl, ((tw_i0 + t) * k) << tw_scale_log, P), P);
+    // ---- group 1 (and 2): in registers between LDS exchanges; the LAST group of the tile stores to HBM ----
+    auto store_out = [&](uint32_t row, uint32_t t, Fe v) {
+        const uint32_t k = __brev(row) >> (32 - l);   // DIF leaves frequency k in row bitrev(k)
+        if (!LAST) {
+            if (k) v = fe_mul29(v, ntt_twiddle(pl, ((tw_i0 + t) * k) << lo_sum, P), P);   // omega_N^(O_p * i * k)
             fe_store(out, base_out + ((uint64_t)k << log_inner) + t, v);
+        } else {
+            if (do_scale) v = fe_mul29(v, scale, P);
+            fe_store(out, base_out + t + (uint64_t)k * out_stride_a, v);
+        }
+    };
+    if constexpr (GR::n == 1) {
+        // (L <= 3 is never planned; kept for completeness)
+    } else if constexpr (GR::n == 2) {
+        constexpr int S_HI = L - G0 - 1;   // group 1 covers S_HI .. 0
+        constexpr uint32_t items1 = (R >> G1) * kNttCols;
+        for (uint32_t it = tid; it < items1; it += kNttThreads) {
+            const uint32_t t = it & (kNttCols - 1), pre = it >> 4;
+            Fe x[1 << G1];
+#pragma unroll
+            for (int u = 0; u < (1 << G1); ++u) x[u] = lds_get(lo_plane, hi_plane, (pre << G1) | u, t);
+            ntt_group_stages<L, S_HI, 0>(x, 0, tws, P);
+#pragma unroll
+            for (int u = 0; u < (1 << G1); ++u) store_out((pre << G1) | u, t, x[u]);
         }
     } else {
-        for (uint32_t e = tid; e < R * kNttCols; e += kNttThreads) {
-            const uint32_t t = e & (kNttCols - 1), k = e >> 4;
-            Fe v = lds_get(lo_plane, hi_plane, __brev(k) >> (32 - l), t);
-            if (do_scale) v = fe_mul(v, scale, P);
-            fe_store(out, base_out + t + (uint64_t)k * out_stride_a, v);
+        constexpr int S_HI1 = L - G0 - 1, S_LO1 = S_HI1 - G1 + 1;   // group 1: S_HI1 .. S_LO1, group 2: S_LO1-1 .. 0
+        constexpr uint32_t items1 = (R >> G1) * kNttCols;
+        for (uint32_t it = tid; it < items1; it += kNttThreads) {
+            const uint32_t t = it & (kNttCols - 1), rr = it >> 4;
+            const uint32_t post = rr & ((1u << S_LO1) - 1), pre = rr >> S_LO1;
+            Fe x[1 << G1];
+#pragma unroll
+            for (int u = 0; u < (1 << G1); ++u) x[u] = lds_get(lo_plane, hi_plane, (pre << (S_HI1 + 1)) | ((uint32_t)u << S_LO1) | post, t);
+            ntt_group_stages<L, S_HI1, S_LO1>(x, post, tws, P);
+#pragma unroll
+            for (int u = 0; u < (1 << G1); ++u) lds_put(lo_plane, hi_plane, (pre << (S_HI1 + 1)) | ((uint32_t)u << S_LO1) | post, t, x[u]);
+        }
+        __syncthreads();
+        constexpr uint32_t items2 = (R >> G2) * kNttCols;
+        for (uint32_t it = tid; it < items2; it += kNttThreads) {
+            const uint32_t t = it & (kNttCols - 1), pre = it >> 4;
+            Fe x[1 << G2];
+#pragma unroll
+            for (int u = 0; u < (1 << G2); ++u) x[u] = lds_get(lo_plane, hi_plane, (pre << G2) | u, t);
+            ntt_group_stages<L, G2 - 1, 0>(x, 0, tws, P);
+#pragma unroll
+            for (int u = 0; u < (1 << G2); ++u) store_out((pre << G2) | u, t, x[u]);
         }
     }
 }
 
-// two-level twiddle table: w_lo[i] = omega^i for i < 2^lo_bits; w_hi[i] = (omega^(2^lo_bits))^i for i < 2^hi_bits
-__global__ __launch_bounds__(kBlock) void k_ntt_tables(uint64_t *__restrict__ w_lo, uint64_t *__restrict__ w_hi, uint32_t lo_bits,
+// two-level prepared twiddle table: w_lo[i] = Mul29(omega^i), i < 2^lo_bits; w_hi[i] = omega^(i << lo_bits) * 2^5 mod p
+__global__ __launch_bounds__(kBlock) void k_ntt_tables(uint32_t *__restrict__ w_lo, uint64_t *__restrict__ w_hi, uint32_t lo_bits,
                                                        uint32_t hi_bits, Fe omega, FieldParams P) {
     const uint64_t n_lo = 1ull << lo_bits, n_hi = 1ull << hi_bits, total = n_lo + n_hi;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
@@ -176,7 +261,13 @@ __global__ __launch_bounds__(kBlock) void k_ntt_tables(uint64_t *__restrict__ w_
             base = fe_sqr(base, P);
             e >>= 1;
         }
-        fe_store(is_hi ? w_hi : w_lo, is_hi ? idx - n_lo : idx, acc);
+        if (is_hi) {
+#pragma unroll
+            for (int d = 0; d < 5; ++d) acc = fe_add(acc, acc, P);
+            fe_store(w_hi, idx - n_lo, acc);
+        } else {
+            store_mul29(w_lo + idx * kTw29Words, mul29_prepare(acc, P));
+        }
     }
 }
 
