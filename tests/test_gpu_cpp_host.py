@@ -27,3 +27,10 @@ def test_cpp_host_mirror_compiles_and_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     r = subprocess.run([BIN], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "no CPU fallback" in r.stdout
+
+
+def test_carry_free_multiplier_equals_saturated_on_host():
+    """field.cuh on the CPU: fe_mul29(a, prepare(c)) == fe_mul(a, c) for 3 x 200k random + edge pairs"""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "test_field_host"], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_field_host")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all equal" in r.stdout, r.stdout + r.stderr
