@@ -1,8 +1,8 @@
 // Host-side check of the product's field arithmetic (zk_amd/csrc/field.cuh compiled for the CPU, no GPU needed):
 // the carry-free 9x29-bit multiplier fe_mul29(a, prepare(c)) must equal the saturated Montgomery product fe_mul(a, c)
-// bit for bit -- random and edge inputs, all three fields -- and fe_mul itself must agree with plain big-int arithmetic
-// done here with unsigned __int128 schoolbook reduction (independent of both).  Built with clang++ (field.cuh uses
-// __builtin_addc).  Driven by tests/test_abi_and_host.py.
+// bit for bit -- 200k random pairs plus edge values (0, 1, 2, p-1) per field, all three fields.  (fe_mul itself is pinned
+// against the oracle through the C ABI host helpers and every GPU parity test.)  Built with clang++ (field.cuh uses
+// __builtin_addc).  Driven by tests/test_gpu_cpp_host.py.
 #include <cstdio>
 #include <cstdlib>
 #include "../../zk_amd/csrc/host_field.hpp"
