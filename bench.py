@@ -174,6 +174,25 @@ def main():
                     ts.append(time.perf_counter() - t1)
                 extra[f"sumcheck_prove_partial_ms_n{n}_k2_d2"] = sorted(ts)[len(ts) // 2] * 1e3
                 A.free(); B.free()
+            # config[3]: GKR-shaped load -- no gkr crate exists in the reference; what it would call is
+            # prove_partial on one ProductPoly per layer: depth 8, width 2^20, product of 3 MLEs, degree 3
+            layers = []
+            for layer in range(8):
+                layers.append(zk_amd.ProductPoly.new([zk_amd.MultiLinearPolynomial.random(ctx, 20, 0x6000 + 16 * layer + f, 0)
+                                                      for f in range(3)]))
+            claimed = zk_amd.fe_from_int(field, 7)   # timing only
+            p3 = zk_amd.SumcheckProver(3)
+            for pp in layers[:2]:
+                p3.prove_partial(pp, claimed)
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            for pp in layers:
+                p3.prove_partial(pp, claimed)
+            ctx.synchronize()
+            extra["gkr_shaped_depth8_width2p20_k3_d3_ms"] = (time.perf_counter() - t1) * 1e3
+            for pp in layers:
+                for q in pp.polynomials:
+                    q.free()
             # config[4]: 2^24-point NTT (3 LDS-staged passes), device resident
             x = zk_amd.MultiLinearPolynomial.random(ctx, 24, 0x5EED0005, 0)
             y = zk_amd.MultiLinearPolynomial.alloc(ctx, 24)

@@ -359,6 +359,23 @@ def test_config2_20var_fold_and_sumcheck_properties():
     assert np.array_equal(pp.evaluate(ch), sub.sum)
 
 
+def test_config4_gkr_shaped_layers_verify():
+    """config[3]: the reference has no gkr crate; its building block is prove_partial / verify_partial on a
+    ProductPoly per layer.  Depth 8, width 2^14 here (2^20 in bench.py), 3 factors, degree 3: every layer's proof must
+    pass the restated verifier and its subclaim must equal the product evaluated at the challenges."""
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    n = 14
+    for layer in range(8):
+        pp = ProductPoly.new([MLE.random(c, n, 0x7000 + 16 * layer + f, 0) for f in range(3)])
+        s = pp.round_sums(3)
+        claimed = orc.add(field, s[0], s[1])
+        proof, ch = SumcheckProver(3).prove_partial(pp, claimed)
+        sub = SumcheckVerifier.verify_partial(field, proof)
+        assert np.array_equal(sub.challenges, ch)
+        assert np.array_equal(pp.evaluate(ch), sub.sum)
+
+
 def test_config_24var_fold_properties():
     """metric config: 2^24-element BN254 table.  Size-independent checks: (a) evaluate(T, [r, rest]) ==
     evaluate(fold(T, r), rest); (b) linearity of the fold in r on a strided sample vs the oracle's field ops."""
