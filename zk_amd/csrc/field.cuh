@@ -34,6 +34,8 @@ struct FieldParams {
     uint32_t bits;    // bit length of p
     uint32_t p29[9];  // the modulus in nine 29-bit limbs (unsaturated multiplier, see fe_mul29)
     uint32_t inv29;   // -p^-1 mod 2^29
+    uint32_t r2_29[9];   // prepared multiplier of R^2       (fe_mul29(x, .) = x*R: canonical -> Montgomery)
+    uint32_t r2s_29[9];  // prepared multiplier of R^2 * 2^5 (fe_mul29(x, .) = x*R*2^5: canonical -> prepared form)
 };
 
 struct Fe {

@@ -97,6 +97,16 @@ inline const FieldInfo *field_info(int field) {
     // 29-bit limb view of p and -p^-1 mod 2^29 for the unsaturated multiplier
     split29(P.p, P.p29);
     P.inv29 = P.inv & ((1u << 29) - 1);
+    {
+        Fe r2;
+        memcpy(r2.v, P.r2, 32);
+        const Mul29 k0 = mul29_prepare(r2, P);
+        Fe r2s = r2;
+        for (int i = 0; i < 5; ++i) r2s = fe_add(r2s, r2s, P);
+        const Mul29 k1 = mul29_prepare(r2s, P);
+        memcpy(P.r2_29, k0.l, sizeof k0.l);
+        memcpy(P.r2s_29, k1.l, sizeof k1.l);
+    }
     I.two_adicity = adicity[field];
     I.generator = gen[field];
     // TWO_ADIC_ROOT_OF_UNITY = g^t with p - 1 = 2^s * t

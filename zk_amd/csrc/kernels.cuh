@@ -123,43 +123,56 @@ __global__ __launch_bounds__(kBlock) void k_prod_reduce(FactorPtrs fp, int k, ui
 // ---- device-side Fiat-Shamir step (sumcheck/src/prover.rs:59-62 on one GPU lane) --------------------------------------
 // absorb the round polynomial (32-byte BE canonical elements, sumcheck/src/lib.rs:23-29), squeeze the challenge
 // (transcript/src/lib.rs:20-30) and publish it in Montgomery form for the next round's fused fold.
-// Lane-parallel sponge: lane i = x + 5y of one wave holds Keccak state word A[x][y]; one permutation round is 9 cross-lane
-// moves (ds_bpermute) + ~30 VALU ops for the whole state instead of ~190 serial 64-bit ops.  The 24-round permutation
-// is the latency floor of every sumcheck round (prover.rs:59-62 is inherently serial), so it is built for latency.
+// Lane-parallel sponge.  State word A[x][y] lives on lane 8y + x + 1 of one wave: each plane (fixed y) occupies an
+// 8-lane group whose slots 1..5 are the primaries x = 0..4, slot 0 mirrors x = 4 and slots 6, 7 mirror x = 0, 1, so the
+// row neighbours x-1, x+1, x+2 that theta and chi need are plain DPP row shifts (VALU latency) instead of ds_bpermute
+// round trips.  Only the column parity (5 planes) and the pi permutation cross lanes through ds_bpermute, and their
+// source indices always name PRIMARY lanes, so the mirrors are recomputed from good data every time they are read:
+// 2 dependent LDS-crossbar stages per Keccak round instead of 4.  The 24-round permutation is the latency floor of every
+// sumcheck round (prover.rs:59-62 is inherently serial), so it is built for latency, not throughput.
 struct LaneKeccak {
-    int lane, up1, up2, up3, up4, xm1, xp1, xp2, src_pi;
+    int lane, index;                 // index = x + 5y for primary lanes, -1 otherwise
+    int up1, up2, up3, up4, src_pi;  // byte-less lane numbers for ds_bpermute (primaries of other planes / pi source)
     uint32_t rot;
 };
 ZK_D uint64_t shfl64(uint64_t v, int src) {
     const uint32_t lo = __shfl((uint32_t)v, src, 64), hi = __shfl((uint32_t)(v >> 32), src, 64);
     return ((uint64_t)hi << 32) | lo;
 }
+template <int CTRL>
+ZK_D uint64_t dpp64(uint64_t v) {   // row_shl:n = 0x100 + n (lane i reads lane i+n), row_shr:n = 0x110 + n (reads lane i-n)
+    const uint32_t lo = __builtin_amdgcn_update_dpp(0u, (uint32_t)v, CTRL, 0xF, 0xF, true);
+    const uint32_t hi = __builtin_amdgcn_update_dpp(0u, (uint32_t)(v >> 32), CTRL, 0xF, 0xF, true);
+    return ((uint64_t)hi << 32) | lo;
+}
+ZK_D int keccak_lane_of(int x, int y) { return 8 * y + x + 1; }
 ZK_D LaneKeccak lane_keccak_init() {
     // rho offsets indexed by x + 5y
     constexpr uint8_t kRho[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
     LaneKeccak L;
     const int lane = threadIdx.x & 63;
     L.lane = lane;
-    if (lane < 25) {
-        const int x = lane % 5, y = lane / 5;
-        L.up1 = x + 5 * ((y + 1) % 5);
-        L.up2 = x + 5 * ((y + 2) % 5);
-        L.up3 = x + 5 * ((y + 3) % 5);
-        L.up4 = x + 5 * ((y + 4) % 5);
-        L.xm1 = (x + 4) % 5 + 5 * y;
-        L.xp1 = (x + 1) % 5 + 5 * y;
-        L.xp2 = (x + 2) % 5 + 5 * y;
-        // pi: B[y'][2x'+3y'] = A[x'][y'], i.e. destination (X, Y) = (y', 2x'+3y').  For destination (x, y) the source is
-        // x' = (x + 3y) mod 5, y' = x.
+    const int slot = lane & 7, y = lane >> 3;
+    if (y < 5) {
+        const int x = slot == 0 ? 4 : (slot >= 6 ? slot - 6 : slot - 1);   // mirrors carry their primary's x
+        L.index = (slot >= 1 && slot <= 5) ? x + 5 * y : -1;
+        L.up1 = keccak_lane_of(x, (y + 1) % 5);
+        L.up2 = keccak_lane_of(x, (y + 2) % 5);
+        L.up3 = keccak_lane_of(x, (y + 3) % 5);
+        L.up4 = keccak_lane_of(x, (y + 4) % 5);
+        // pi: B[y'][2x'+3y'] = A[x'][y'], i.e. destination (X, Y) = (y', 2x'+3y'); for destination (x, y) the source is
+        // x' = (x + 3y) mod 5, y' = x
         const int sx = (x + 3 * y) % 5, sy = x;
-        L.src_pi = sx + 5 * sy;
+        L.src_pi = keccak_lane_of(sx, sy);
         uint32_t rot = 0;
+        const int idx = x + 5 * y;
 #pragma unroll
         for (int i = 0; i < 25; ++i)
-            if (i == lane) rot = kRho[i];
+            if (i == idx) rot = kRho[i];
         L.rot = rot;
     } else {
-        L.up1 = L.up2 = L.up3 = L.up4 = L.xm1 = L.xp1 = L.xp2 = L.src_pi = lane;
+        L.index = -1;
+        L.up1 = L.up2 = L.up3 = L.up4 = L.src_pi = lane;
         L.rot = 0;
     }
     return L;
@@ -173,25 +186,27 @@ ZK_D uint64_t lane_keccak_f1600(uint64_t a, const LaneKeccak &L) {
         0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
         0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
     for (int round = 0; round < 24; ++round) {
-        // theta: column parity of my column, then D = C[x-1] ^ rotl(C[x+1], 1)
-        const uint64_t c = a ^ shfl64(a, L.up1) ^ shfl64(a, L.up2) ^ shfl64(a, L.up3) ^ shfl64(a, L.up4);
-        const uint64_t cp = shfl64(c, L.xp1);
-        a ^= shfl64(c, L.xm1) ^ ((cp << 1) | (cp >> 63));
-        // rho (rotate my word) + pi (fetch the word that lands here)
+        // theta: column parity (every lane, mirrors included, reads the primaries of its own column) ...
+        const uint64_t c = shfl64(a, L.lane < 40 ? (L.lane & 7) == 0 ? L.lane + 5 : ((L.lane & 7) >= 6 ? L.lane - 5 : L.lane) : L.lane) ^
+                           shfl64(a, L.up1) ^ shfl64(a, L.up2) ^ shfl64(a, L.up3) ^ shfl64(a, L.up4);
+        // ... then D = C[x-1] ^ rotl(C[x+1], 1) from the row neighbours (DPP: slot s reads slots s-1 and s+1)
+        const uint64_t cm = dpp64<0x111>(c), cp = dpp64<0x101>(c);
+        a ^= cm ^ ((cp << 1) | (cp >> 63));
+        // rho (rotate my word) + pi (fetch the word that lands here, always from a primary lane)
         const uint64_t rr = (a << L.rot) | (a >> ((64 - L.rot) & 63));
         const uint64_t b = shfl64(rr, L.src_pi);
-        // chi + iota
-        a = b ^ (~shfl64(b, L.xp1) & shfl64(b, L.xp2));
-        if (L.lane == 0) a ^= RC[round];
+        // chi + iota: row neighbours x+1, x+2 are slots s+1, s+2
+        a = b ^ (~dpp64<0x101>(b) & dpp64<0x102>(b));
+        if (L.index == 0) a ^= RC[round];
     }
     return a;
 }
-struct LaneSponge {   // word-cursor sponge (see WordSponge) spread over lanes 0..24
+struct LaneSponge {   // word-cursor sponge (see WordSponge) spread over the primary lanes
     uint64_t a;
     uint32_t pos;
 };
 ZK_D void lane_absorb_word(LaneSponge &sp, uint64_t w, const LaneKeccak &L) {   // w wave-uniform
-    if ((uint32_t)L.lane == sp.pos) sp.a ^= w;
+    if ((uint32_t)L.index == sp.pos) sp.a ^= w;
     if (++sp.pos == 17) {
         sp.a = lane_keccak_f1600(sp.a, L);
         sp.pos = 0;
@@ -203,15 +218,15 @@ ZK_D void lane_absorb_word(LaneSponge &sp, uint64_t w, const LaneKeccak &L) {   
 // challenge (transcript/src/lib.rs:20-30) and return it in Montgomery form (wave-uniform).
 ZK_D LaneSponge lane_sponge_load(const WordSponge *gsp, const LaneKeccak &L) {
     LaneSponge sp;
-    sp.a = (L.lane < 25) ? gsp->s[L.lane] : 0ull;
+    sp.a = (L.index >= 0) ? gsp->s[L.index] : 0ull;
     sp.pos = __builtin_amdgcn_readfirstlane(gsp->pos);
     return sp;
 }
 ZK_D void lane_sponge_store(WordSponge *gsp, const LaneSponge &sp, const LaneKeccak &L) {
-    if (L.lane < 25) gsp->s[L.lane] = sp.a;
+    if (L.index >= 0) gsp->s[L.index] = sp.a;
     if (L.lane == 0) gsp->pos = sp.pos;
 }
-ZK_D Fe transcript_step(LaneSponge &sp, const LaneKeccak &L, const Fe *sums, uint32_t ns, const FieldParams &P) {
+ZK_D Fe transcript_step(LaneSponge &sp, const LaneKeccak &L, const Fe *sums, uint32_t ns, const FieldParams &P, Mul29 &ch29) {
     for (uint32_t base = 0; base < ns; base += 64) {
         // lane t converts sum (base + t): Montgomery -> canonical, in parallel across lanes
         const uint32_t mine = base + (uint32_t)L.lane < ns ? base + (uint32_t)L.lane : ns - 1;
@@ -223,20 +238,37 @@ ZK_D Fe transcript_step(LaneSponge &sp, const LaneKeccak &L, const Fe *sums, uin
             w[k] = WordSponge::bswap64(limb);
         }
         const uint32_t cnt = ns - base < 64 ? ns - base : 64;
-        for (uint32_t t = 0; t < cnt; ++t) {
+        if (sp.pos + 4 * cnt <= 17) {
+            // the whole batch fits the current block: state word i receives message word (i - pos) = word k of sum t,
+            // one gather per k instead of 4*cnt dependent absorb steps
+            const int rel = L.index - (int)sp.pos;
+            const int t = rel >= 0 ? rel >> 2 : 0, k = rel & 3;
+            const uint64_t g0 = shfl64(w[0], t), g1 = shfl64(w[1], t), g2 = shfl64(w[2], t), g3 = shfl64(w[3], t);
+            const uint64_t g = k == 0 ? g0 : (k == 1 ? g1 : (k == 2 ? g2 : g3));
+            if (L.index >= 0 && rel >= 0 && rel < (int)(4 * cnt)) sp.a ^= g;
+            sp.pos += 4 * cnt;
+            if (sp.pos == 17) {
+                sp.a = lane_keccak_f1600(sp.a, L);
+                sp.pos = 0;
+            }
+        } else {
+            for (uint32_t t = 0; t < cnt; ++t) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) lane_absorb_word(sp, shfl64(w[k], (int)t), L);
+                for (int k = 0; k < 4; ++k) lane_absorb_word(sp, shfl64(w[k], (int)t), L);
+            }
         }
     }
     // squeeze: pad10*1 with Keccak's 0x01 domain byte, permute, digest = words 0..3
-    if ((uint32_t)L.lane == sp.pos) sp.a ^= 0x01ull;
-    if (L.lane == 16) sp.a ^= 0x8000000000000000ull;
+    if ((uint32_t)L.index == sp.pos) sp.a ^= 0x01ull;
+    if (L.index == 16) sp.a ^= 0x8000000000000000ull;
     sp.a = lane_keccak_f1600(sp.a, L);
-    const uint64_t d0 = shfl64(sp.a, 0), d1 = shfl64(sp.a, 1), d2 = shfl64(sp.a, 2), d3 = shfl64(sp.a, 3);
+    const uint64_t d0 = shfl64(sp.a, keccak_lane_of(0, 0)), d1 = shfl64(sp.a, keccak_lane_of(1, 0));
+    const uint64_t d2 = shfl64(sp.a, keccak_lane_of(2, 0)), d3 = shfl64(sp.a, keccak_lane_of(3, 0));
     // finalize_reset + update(digest) (transcript/src/lib.rs:22-23): state = digest words, cursor 4
-    sp.a = (L.lane < 4) ? sp.a : 0ull;
+    sp.a = (L.index >= 0 && L.index < 4) ? sp.a : 0ull;
     sp.pos = 4;
-    // int(digest, big endian) mod p -> Montgomery (transcript/src/lib.rs:29)
+    // int(digest, big endian) mod p (transcript/src/lib.rs:29), then two independent carry-free multiplies by prepared
+    // constants give the challenge in Montgomery form (x * R) and its multiplier form (x * R * 2^5, split into 29-bit limbs)
     const uint64_t h[4] = {WordSponge::bswap64(d3), WordSponge::bswap64(d2), WordSponge::bswap64(d1), WordSponge::bswap64(d0)};
     uint32_t x[8];
 #pragma unroll
@@ -244,7 +276,17 @@ ZK_D Fe transcript_step(LaneSponge &sp, const LaneKeccak &L, const Fe *sums, uin
         x[2 * i] = (uint32_t)h[i];
         x[2 * i + 1] = (uint32_t)(h[i] >> 32);
     }
-    return fe_from_canonical(fe_reduce_u256(x, P), P);
+    const Fe xr = fe_reduce_u256(x, P);
+    Mul29 k0, k1;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        k0.l[i] = P.r2_29[i];       // prepare(R^2):        fe_mul29(x, k0) = x * R^2 * 2^-256       = x * R
+        k1.l[i] = P.r2s_29[i];      // prepare(R^2 * 2^5):  fe_mul29(x, k1) = x * R^2 * 2^5 * 2^-256 = (x * R) * 2^5
+    }
+    const Fe ch = fe_mul29(xr, k0, P);
+    const Fe chs = fe_mul29(xr, k1, P);
+    split29(chs.v, ch29.l);
+    return ch;
 }
 // publish a challenge for the next round's fused fold: [Fe r][Mul29 of r] (common.cuh, kChallengeBytes)
 ZK_D void publish_challenge(uint64_t *d_challenge, uint64_t *out_ch, const Fe &ch, const Mul29 &ch29, int lane) {
@@ -260,8 +302,9 @@ ZK_D void transcript_round(WordSponge *gsp, const Fe *sums, uint32_t ns, uint64_
                            const FieldParams &P) {
     const LaneKeccak L = lane_keccak_init();
     LaneSponge sp = lane_sponge_load(gsp, L);
-    const Fe ch = transcript_step(sp, L, sums, ns, P);
-    publish_challenge(d_challenge, out_ch, ch, mul29_prepare(ch, P), L.lane);
+    Mul29 ch29;
+    const Fe ch = transcript_step(sp, L, sums, ns, P, ch29);
+    publish_challenge(d_challenge, out_ch, ch, ch29, L.lane);
     lane_sponge_store(gsp, sp, L);
 }
 
@@ -416,8 +459,8 @@ __global__ __launch_bounds__(kBlock) void k_finish(FactorPtrs fp, uint32_t m_in,
         __syncthreads();
         // ---- transcript step on wave 0, challenge to everyone through LDS ----
         if (wave0) {
-            const Fe ch = transcript_step(sp, L, fin, NS, P);
-            const Mul29 ch29 = mul29_prepare(ch, P);
+            Mul29 ch29;
+            const Fe ch = transcript_step(sp, L, fin, NS, P, ch29);
             if (lane == 0) {
                 fe_store(out_ch, round, ch);
                 *sh_r29p = ch29;
