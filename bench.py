@@ -46,6 +46,12 @@ def cpu_baseline(field):
             break
     dt = time.perf_counter() - t0
     ops = 3 * (1 << (n - 1)) * reps
+    # the other half of the metric on the CPU: reference-faithful prover ((D+2)*k folds + (D+1) prod_reduce per round)
+    ns = 16
+    tabs = [orc.fill_random(field, 0x5EED0000 + ns + f, 1 << ns) for f in range(2)]
+    t1 = time.perf_counter()
+    orc.sumcheck_prove(field, ns, tabs, 2, orc.fill_random(field, 5, 1)[0], False)
+    cpu_prove_ms = (time.perf_counter() - t1) * 1e3
     return {
         "value": ops / dt,
         "unit": "field-ops/s",
@@ -53,6 +59,7 @@ def cpu_baseline(field):
         "kind": "port",
         "sample": f"{reps} folds of a 2^{n}-element BN254-Fr table (clone + fold + copy as evaluation_form.rs:49-79), "
                   f"{dt:.1f} s, single thread (the reference is single-threaded)",
+        "sumcheck_prove_partial_ms_n16_k2_d2": cpu_prove_ms,
     }, out
 
 
@@ -174,6 +181,11 @@ def main():
                     ts.append(time.perf_counter() - t1)
                 extra[f"sumcheck_prove_partial_ms_n{n}_k2_d2"] = sorted(ts)[len(ts) // 2] * 1e3
                 A.free(); B.free()
+            # config[1]: the 2^20 fold (32 MiB table: Infinity-Cache resident, not an HBM measurement)
+            t20 = zk_amd.MultiLinearPolynomial.random(ctx, 20, 0x5EED0014, 0)
+            o20 = zk_amd.MultiLinearPolynomial.alloc(ctx, 19)
+            extra["fold_2p20_us"] = t20.bench_fold(r, o20, 50) * 1e3
+            t20.free(); o20.free()
             # config[3]: GKR-shaped load -- no gkr crate exists in the reference; what it would call is
             # prove_partial on one ProductPoly per layer: depth 8, width 2^20, product of 3 MLEs, degree 3
             layers = []
