@@ -234,6 +234,8 @@ extern "C" int32_t zk_ctx_destroy(zk_ctx *c) {
     for (auto &kv : c->ntt_plans) {
         (void)hipFree((void *)kv.second.w_lo);
         (void)hipFree((void *)kv.second.w_hi);
+        for (int p = 0; p < 4; ++p)
+            if (kv.second.w_full[p]) (void)hipFree((void *)kv.second.w_full[p]);
     }
     for (auto &kv : c->pool)
         for (void *q : kv.second) (void)hipFree(q);
@@ -1190,6 +1192,7 @@ static void ntt_make_plan(uint32_t log_n, NttPlan &pl) {
     pl.lo_bits = log_n < 12 ? log_n : 12;
     pl.w_lo = nullptr;
     pl.w_hi = nullptr;
+    for (int p = 0; p < 4; ++p) pl.w_full[p] = nullptr;
 }
 static int32_t ntt_build_tables(zk_ctx *c, NttPlan &pl, const Fe &omega) {
     const uint32_t hi_bits = pl.log_n - pl.lo_bits;
@@ -1208,7 +1211,29 @@ static int32_t ntt_build_tables(zk_ctx *c, NttPlan &pl, const Fe &omega) {
     }
     pl.w_lo = lo;
     pl.w_hi = hi;
+    // full inter-pass tables for the middle passes while they stay <= 2^24 entries (512 MiB)
+    uint32_t lo_sum = 0;
+    for (uint32_t p = 0; p + 1 < pl.n_pass; ++p) {
+        const uint32_t log_entries = pl.log_n - lo_sum;   // R_p * I_p = n / O_p
+        if (log_entries <= 24) {
+            uint64_t *t = nullptr;
+            if (hipMalloc(&t, (size_t)32 << log_entries) == hipSuccess) {
+                k_ntt_full_table<<<grid_for(1ull << log_entries), kBlock, 0, c->stream>>>(t, pl, log_entries - pl.l[p], pl.l[p], lo_sum, c->fi->P);
+                if (hipGetLastError() == hipSuccess) pl.w_full[p] = t;
+                else (void)hipFree(t);
+            }
+        }
+        lo_sum += pl.l[p];
+    }
     return ZK_OK;
+}
+static void ntt_free_tables(NttPlan &pl) {
+    if (pl.w_lo) (void)hipFree((void *)pl.w_lo);
+    if (pl.w_hi) (void)hipFree((void *)pl.w_hi);
+    for (int p = 0; p < 4; ++p)
+        if (pl.w_full[p]) (void)hipFree((void *)pl.w_full[p]);
+    pl.w_lo = nullptr;
+    pl.w_hi = nullptr;
 }
 template <int L>
 static hipError_t ntt_launch_l(const NttPlan &pl, uint32_t p, bool last, uint32_t tiles, size_t lds, hipStream_t st, const uint64_t *src,
@@ -1321,8 +1346,7 @@ static int32_t fft_host_common(zk_ctx *c, const uint64_t *in, uint64_t n, uint64
             rc = ntt_build_tables(c, pl, fe_from_u64limbs(omega_user));
             if (rc == ZK_OK) rc = ntt_run_plan(c, pl, a->d, b->d, false);
             if (hipStreamSynchronize(c->stream) != hipSuccess && rc == ZK_OK) rc = ZK_ERR_HIP;
-            if (pl.w_lo) (void)hipFree((void *)pl.w_lo);
-            if (pl.w_hi) (void)hipFree((void *)pl.w_hi);
+            ntt_free_tables(pl);
         } else if (mode == 2) {
             uint64_t *tw = nullptr;
             rc = make_twiddles(c, log_n, fe_from_u64limbs(omega_user), &tw);

@@ -41,6 +41,10 @@ struct NttPlan {
     uint32_t lo_bits;       // two-level table: w_lo[i] ~ omega^i (i < 2^lo_bits), w_hi[i] ~ omega^(i << lo_bits)
     const uint32_t *w_lo;   // Mul29 records of omega^i
     const uint64_t *w_hi;   // elements omega^(i << lo_bits) * 2^5 mod p
+    // optional full inter-pass twiddle table of pass p < P: element (k, i) at [k * I_p + i] = omega^(O_p * i * k) * 2^5 mod p,
+    // R_p * I_p = n / O_p entries (the whole vector for pass 0, n / R_1 for pass 1, ...).  Trades the compose multiply
+    // for a 32-byte read in a pass that is bound by VALU issue, not HBM.  Null: compose from the two-level table.
+    const uint64_t *w_full[4];
 };
 ZK_D Mul29 load_mul29(const uint32_t *rec) {
     const uint4 a = *reinterpret_cast<const uint4 *>(rec), b = *reinterpret_cast<const uint4 *>(rec + 4);
@@ -101,7 +105,8 @@ ZK_D void ntt_bfly(Fe (&x)[1 << G], uint32_t post, const uint32_t *tws, const Fi
     constexpr int s = S_LO + SU;             // global stage
     const Fe a0 = x[ua], a1 = x[ub];
     Fe d = fe_sub(a0, a1, P);
-    if constexpr (s > 0) {                   // the s = 0 stage has unit twiddles
+    // unit twiddles are skipped when known at compile time: the s = 0 stage, and j = 0 butterflies of the last group
+    if constexpr (s > 0 && !(S_LO == 0 && (ua & (hu - 1)) == 0)) {
         const uint32_t j = ((ua & (hu - 1)) << S_LO) | post;              // r mod 2^s
         d = fe_mul29(d, load_mul29(tws + ((size_t)j << (L - 1 - s)) * kTw29Words), P);
     }
@@ -165,6 +170,7 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
         base_out = k1_0 + rev;                                      // + t + a' * O_P
         out_stride_a = 1ull << lo_sum;
     }
+    const uint64_t *w_full = LAST ? nullptr : pl.w_full[pass];
     __syncthreads();   // tws ready
 
     // ---- group 0: stages l-1 .. l-G0, rows (u << (l-G0)) | post, straight from HBM ----
@@ -197,7 +203,16 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
     auto store_out = [&](uint32_t row, uint32_t t, Fe v) {
         const uint32_t k = __brev(row) >> (32 - l);   // DIF leaves frequency k in row bitrev(k)
         if (!LAST) {
-            if (k) v = fe_mul29(v, ntt_twiddle(pl, ((tw_i0 + t) * k) << lo_sum, P), P);   // omega_N^(O_p * i * k)
+            if (k) {                                                                       // omega_N^(O_p * i * k)
+                Mul29 tw;
+                if (w_full) {
+                    const Fe f = fe_load(w_full, ((uint64_t)k << log_inner) + tw_i0 + t);
+                    split29(f.v, tw.l);
+                } else {
+                    tw = ntt_twiddle(pl, ((tw_i0 + t) * k) << lo_sum, P);
+                }
+                v = fe_mul29(v, tw, P);
+            }
             fe_store(out, base_out + ((uint64_t)k << log_inner) + t, v);
         } else {
             if (do_scale) v = fe_mul29(v, scale, P);
@@ -242,6 +257,41 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
 #pragma unroll
             for (int u = 0; u < (1 << G2); ++u) store_out((pre << G2) | u, t, x[u]);
         }
+    }
+}
+
+// full inter-pass table of one middle pass: out[k * inner + i] = omega^(scale * i * k) * 2^5 mod p
+__global__ __launch_bounds__(kBlock) void k_ntt_full_table(uint64_t *__restrict__ out, NttPlan pl, uint32_t log_inner, uint32_t log_r,
+                                                           uint32_t log_scale, FieldParams P) {
+    const uint64_t total = 1ull << (log_inner + log_r), stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += stride) {
+        const uint64_t k = idx >> log_inner, i = idx & ((1ull << log_inner) - 1);
+        const uint64_t e = (i * k) << log_scale;
+        const uint64_t lo = e & ((1ull << pl.lo_bits) - 1), hi = e >> pl.lo_bits;
+        // omega^e * 2^5 as a plain element: hi-table entries carry the factor already; a lo-only value is rebuilt from its limbs
+        Fe v;
+        if (lo == 0) {
+            v = fe_load(pl.w_hi, hi);
+        } else {
+            const Mul29 m = load_mul29(pl.w_lo + lo * kTw29Words);
+            if (hi == 0) {
+                // merge the 29-bit limbs of the prepared value back into an element (value < p)
+                uint32_t w[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    const int bit = 32 * x, li = bit / 29, sh = bit - 29 * li;
+                    uint32_t t = m.l[li] >> sh;
+                    t |= m.l[li + 1] << (29 - sh);
+                    if (29 - sh + 29 < 32 && li + 2 < 9) t |= m.l[li + 2] << (58 - sh);
+                    w[x] = t;
+                }
+#pragma unroll
+                for (int x = 0; x < 8; ++x) v.v[x] = w[x];
+            } else {
+                v = fe_mul29(fe_load(pl.w_hi, hi), m, P);
+            }
+        }
+        fe_store(out, idx, v);
     }
 }
 
