@@ -48,6 +48,7 @@ typedef enum zk_status {
     ZK_ERR_FFT_NO_ROOT = -7,    /* reference panics: get_root_of_unity(..).unwrap()      fft/src/lib.rs:6,14   */
     ZK_ERR_VERIFY_ROUNDS = -8,  /* "invalid proof: require 1 round poly for each variable in poly" verifier.rs:18 */
     ZK_ERR_VERIFY_SUM = -9,     /* "verifier check failed: claimed_sum != p(0) + p(1)"   verifier.rs:64        */
+    ZK_ERR_COEFF_RANGE = -10,   /* "coefficient map represents more than specificed number of variables" coefficient_form.rs:184 */
     ZK_ERR_BAD_ARG = -20,
     ZK_ERR_BAD_FIELD = -21,
     ZK_ERR_NO_DEVICE = -22,     /* no gfx950 device / HIP runtime failure at context creation */
@@ -109,6 +110,14 @@ int32_t zk_mle_to_bytes(zk_ctx *ctx, const zk_mle *t, uint8_t *out_bytes);
 int32_t zk_mle_partial_evaluate_host(zk_ctx *ctx, uint64_t n_vars, const uint64_t *evals, uint64_t len,
                                      uint64_t initial_var, const uint64_t *assignments, uint64_t n_assign,
                                      uint64_t *out_evals /* 2^(n_vars-n_assign) elements */);
+
+/* ---- the step before the path: CoeffMultilinearPolynomial::to_evaluation_form (coefficient_form.rs:340-347) ------------
+ * Sparse coefficient form {key -> coefficient} (key bit v <-> variable v, selector_to_index :418-430; the BTreeMap of
+ * coefficient_form.rs:27-30 passed as parallel arrays, duplicate keys are summed like ::new :164-171) -> the dense
+ * evaluation table in hypercube order, resident on the device.  key >= 2^n_vars -> ZK_ERR_COEFF_RANGE (:183-186).
+ * n_vars == 0 -> ZK_ERR_EVAL_LEN (the reference returns an empty vector there, which cannot be a table). */
+int32_t zk_coeff_to_evaluation(zk_ctx *ctx, uint64_t n_vars, const uint64_t *keys, const uint64_t *coeffs, uint64_t n_terms,
+                               zk_mle **out);
 
 /* ---- ProductPoly  (polynomial/src/product_poly.rs) ---------------------------------------------------------- */
 /* ::new :14-32 -- k == 0 -> ZK_ERR_EMPTY_PRODUCT, unequal arity -> ZK_ERR_ARITY_MISMATCH.  Validation only:

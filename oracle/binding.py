@@ -24,6 +24,7 @@ ERRORS = {
     -7: "reference panics: no root of unity (unwrap on None)",
     -8: "invalid proof: require 1 round poly for each variable in poly",
     -9: "verifier check failed: claimed_sum != p(0) + p(1)",
+    -10: "coefficient map represents more than specificed number of variables",
 }
 
 
@@ -223,6 +224,14 @@ def mle_to_bytes(field, n_vars, evals):
     out = np.zeros(32 << n_vars, dtype=np.uint8)
     _lib.orc_mle_to_bytes(field, _c.c_uint64(n_vars), _p(evals), out.ctypes.data_as(_u8p))
     return out.tobytes()
+
+
+def coeff_to_evaluation(field, n_vars, keys, coeffs):
+    keys = np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1)
+    coeffs = _arr(coeffs).reshape(-1, 4)
+    out = np.zeros(((1 << n_vars) if n_vars else 0, 4), dtype=np.uint64)
+    _check(_lib.orc_coeff_to_evaluation(field, _c.c_uint64(n_vars), _p(keys), _p(coeffs), _c.c_uint64(keys.size), _p(out)))
+    return out
 
 
 # ---------------- product ----------------

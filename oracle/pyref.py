@@ -85,6 +85,24 @@ class MLE:
         return b"".join(e.to_bytes(32, "big") for e in self.evals)
 
 
+# ---- coefficient_form.rs:340-347 (to_evaluation_form) over boolean_hypercube.rs:27-45 ----
+def coeff_to_evaluation(field, n_vars, terms):
+    """terms: {key: coeff}, key bit v <-> variable v (selector_to_index, coefficient_form.rs:418-430)."""
+    pm = modulus(field)
+    out = []
+    for idx in range(1 << n_vars if n_vars else 0):
+        point = [int(ch) for ch in format(idx, "0%db" % n_vars)]          # binary_string(index, n): variable 0 first
+        acc = 0
+        for key, cf in terms.items():
+            term = cf
+            for v in range(n_vars):
+                if (key >> v) & 1:
+                    term = term * point[v] % pm
+            acc = (acc + term) % pm
+        out.append(acc)
+    return out
+
+
 # ---- product_poly.rs ----
 class Product:
     def __init__(self, polys):  # :14-32

@@ -348,6 +348,32 @@ void orc_mle_to_bytes(int field, u64 n_vars, const u64 *evals, uint8_t *out) {  
 }
 
 /* ------------------------------------------------------------------------------------------
+ * polynomial/src/multilinear/coefficient_form.rs:340-347 (to_evaluation_form)
+ * ---------------------------------------------------------------------------------------- */
+/* For every hypercube point in BooleanHyperCube order (boolean_hypercube.rs:27-45: binary_string(index, n), first char
+ * = variable 0) push evaluate_slice(point) (coefficient_form.rs:39-68).  At a 0/1 point a term c * prod_{v in key} x_v
+ * (key bit v <-> variable v, :418-430) contributes c exactly when every variable of the key is 1. */
+int orc_coeff_to_evaluation(int field, u64 n_vars, const u64 *keys, const u64 *coeffs, u64 n_terms, u64 *out) {
+    const fparams *F = field_get(field);
+    if (!F) return ORC_ERR_BAD_FIELD;
+    if (n_vars >= 64) return ORC_ERR_EVAL_LEN;
+    for (u64 t = 0; t < n_terms; ++t)
+        if (keys[t] >> n_vars) return ORC_ERR_COEFF_RANGE;                           /* :183-186 */
+    if (n_vars == 0) return ORC_OK;   /* the hypercube iterator yields nothing for bit_size 0 (:31): empty vector */
+    u64 len = 1ULL << n_vars;
+    for (u64 idx = 0; idx < len; ++idx) {
+        u64 mask = 0;                  /* variables set to one at this point: char v of the binary string = bit (n-1-v) */
+        for (u64 v = 0; v < n_vars; ++v)
+            if ((idx >> (n_vars - 1 - v)) & 1) mask |= 1ULL << v;
+        u64 acc[4] = {0, 0, 0, 0};
+        for (u64 t = 0; t < n_terms; ++t)
+            if ((keys[t] & mask) == keys[t]) f_add(F, acc, coeffs + 4 * t, acc);
+        memcpy(out + 4 * idx, acc, 32);
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
  * polynomial/src/product_poly.rs
  * ---------------------------------------------------------------------------------------- */
 int orc_product_new_check(u64 k, const u64 *n_vars_each) {                          /* :14-32 */

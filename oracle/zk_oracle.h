@@ -44,6 +44,7 @@ enum {
     ORC_ERR_FFT_NO_ROOT = -7,    /* fft/src/lib.rs:6 unwrap on None */
     ORC_ERR_VERIFY_ROUNDS = -8,  /* verifier.rs:18 */
     ORC_ERR_VERIFY_SUM = -9,     /* verifier.rs:64 */
+    ORC_ERR_COEFF_RANGE = -10,   /* coefficient_form.rs:184 */
     ORC_ERR_BAD_FIELD = -20,
     ORC_ERR_ALLOC = -21
 };
@@ -78,6 +79,12 @@ int orc_mle_partial_evaluate(int field, uint64_t n_vars, const uint64_t *evals,
 int orc_mle_evaluate(int field, uint64_t n_vars, const uint64_t *evals,
                      const uint64_t *point, uint64_t n_point, uint64_t out[4]); /* :83-89 */
 void orc_mle_to_bytes(int field, uint64_t n_vars, const uint64_t *evals, uint8_t *out); /* :97-103 */
+
+/* ---- polynomial/src/multilinear/coefficient_form.rs:340-347 + boolean_hypercube.rs:27-45 (the step before the path) ----
+ * to_evaluation_form of the sparse coefficient-form polynomial {key -> coeff}, key bit v <-> variable v
+ * (selector_to_index :418-430).  out: 2^n_vars elements in hypercube order (binary strings, variable 0 first = MSB). */
+int orc_coeff_to_evaluation(int field, uint64_t n_vars, const uint64_t *keys, const uint64_t *coeffs, uint64_t n_terms,
+                            uint64_t *out);
 
 /* ---- polynomial/src/product_poly.rs ---- */
 int orc_product_new_check(uint64_t k, const uint64_t *n_vars_each);           /* :14-32 */

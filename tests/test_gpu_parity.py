@@ -178,6 +178,48 @@ def test_fill_random_matches_oracle_generator(field):
     assert np.array_equal(t.evaluation_slice(), orc.fill_random(field, 0x5EED0002, 1 << 10, first_index=12345))
 
 
+# ------------------------------------------------------------------ coefficient form -> evaluation form (the step before the path)
+@pytest.mark.parametrize("field", FIELDS)
+def test_ref_to_evaluation_form_kat_and_random(field):
+    c = ctx_for(field)
+    p2ab3bc = zk_amd.CoeffMultilinearPolynomial.new(field, 3, [(zk_amd.fe_from_int(field, 2), [True, True, False]),
+                                                               (zk_amd.fe_from_int(field, 3), [False, True, True])])
+    assert ints(field, p2ab3bc.to_evaluation_form(c).evaluation_slice()) == [0, 0, 0, 3, 0, 0, 2, 5]   # coefficient_form.rs:1322-1347
+    with pytest.raises(ZkError, match="selector array len"):
+        zk_amd.CoeffMultilinearPolynomial.new(field, 3, [(zk_amd.fe_from_int(field, 2), [True, True])])
+    with pytest.raises(ZkError, match="more than specificed number of variables"):
+        zk_amd.CoeffMultilinearPolynomial.new_with_coefficient(field, 2, {4: zk_amd.fe_from_int(field, 1)})
+    # duplicate selectors are summed by ::new (:164-171)
+    dup = zk_amd.CoeffMultilinearPolynomial.new(field, 2, [(zk_amd.fe_from_int(field, 2), [True, False]),
+                                                           (zk_amd.fe_from_int(field, 5), [True, False])])
+    assert ints(field, dup.to_evaluation_form(c).evaluation_slice()) == [0, 0, 7, 7]
+    rng = random.Random(field)
+    for n_vars, n_terms in [(1, 2), (4, 9), (9, 300), (13, 2000), (16, 65536)]:
+        keys = sorted(rng.sample(range(1 << n_vars), min(n_terms, 1 << n_vars)))
+        coeffs = orc.fill_random(field, 2600 + n_vars, len(keys))
+        poly = zk_amd.CoeffMultilinearPolynomial.new_with_coefficient(field, n_vars, {k: coeffs[i] for i, k in enumerate(keys)})
+        got = poly.to_evaluation_form(c).evaluation_slice()
+        if n_vars <= 13:
+            assert np.array_equal(got, orc.coeff_to_evaluation(field, n_vars, keys, coeffs))
+        else:   # dense 2^16: check through the MLE property instead of the O(4^n) oracle
+            pt = orc.fill_random(field, 17, n_vars)
+            ev = MLE.new(c, n_vars, got).evaluate(pt)
+            acc = 0
+            pm = zk_amd.modulus(field)
+            rp = zk_amd.fe_to_ints(field, pt)
+            cf = zk_amd.fe_to_ints(field, coeffs)
+            # the table is the MLE of the polynomial: its value at a random point is sum_S c_S prod_{v in S} r_v
+            for i, k in enumerate(keys):
+                t, kk, v = cf[i], k, 0
+                while kk:
+                    if kk & 1:
+                        t = t * rp[v] % pm
+                    kk >>= 1
+                    v += 1
+                acc = (acc + t) % pm
+            assert zk_amd.fe_to_int(field, ev) == acc
+
+
 # ------------------------------------------------------------------ product / round sums vs oracle
 @pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k", [1, 2, 3, 5])

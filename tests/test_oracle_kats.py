@@ -132,6 +132,18 @@ def test_table_order_2ab_3bc():
     assert table == [0, 0, 0, 3, 0, 0, 2, 5]
 
 
+# ---- coefficient_form.rs:1322-1347 (to_evaluation_form KAT; the reference runs it on a toy field mod 17) ----
+@pytest.mark.parametrize("field", FIELDS)
+def test_to_evaluation_form_kat(field):
+    # p = 2ab + 3bc: selectors [t,t,f] -> key 0b011 = 3, [f,t,t] -> key 0b110 = 6 (selector_to_index :418-430)
+    keys, coeffs = [3, 6], F(field, [2, 3])
+    assert ints(field, orc.coeff_to_evaluation(field, 3, keys, coeffs)) == [0, 0, 0, 3, 0, 0, 2, 5]
+    assert pyref.coeff_to_evaluation(field, 3, {3: 2, 6: 3}) == [0, 0, 0, 3, 0, 0, 2, 5]
+    with pytest.raises(orc.OracleError, match="more than specificed number of variables"):
+        orc.coeff_to_evaluation(field, 3, [8], F(field, [1]))                   # new_with_coefficient :183-186
+    assert orc.coeff_to_evaluation(field, 0, [0], F(field, [7])).shape == (0, 4)  # bit_size 0: the hypercube yields nothing
+
+
 # ---- sumcheck/src/lib.rs:53-122 (prover <-> verifier; accept / reject only) ----
 @pytest.mark.parametrize("field", FIELDS)
 def test_sumcheck_correct_sum_multilinear(field):

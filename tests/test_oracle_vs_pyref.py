@@ -116,6 +116,29 @@ def test_sumcheck_transcript_matches_model(field, k, D, n_vars, absorb):
 
 
 @pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("n_vars,n_terms", [(1, 2), (3, 5), (6, 20), (8, 256)])
+def test_coeff_to_evaluation_matches_model(field, n_vars, n_terms):
+    rng = random.Random(n_vars * 31 + field)
+    p = orc.modulus(field)
+    terms = {}
+    while len(terms) < min(n_terms, 1 << n_vars):
+        terms[rng.randrange(1 << n_vars)] = rng.randrange(p)
+    keys = sorted(terms)
+    got = orc.to_ints(field, orc.coeff_to_evaluation(field, n_vars, keys, orc.from_ints(field, [terms[k] for k in keys])))
+    assert got == pyref.coeff_to_evaluation(field, n_vars, terms)
+    # the table it produces is the MLE of the polynomial: evaluating it at a random point equals sum c_S prod_{v in S} r_v
+    r = [rng.randrange(p) for _ in range(n_vars)]
+    want = 0
+    for key, cf in terms.items():
+        t = cf
+        for v in range(n_vars):
+            if (key >> v) & 1:
+                t = t * r[v] % p
+        want = (want + t) % p
+    assert pyref.MLE(field, n_vars, got).evaluate(r) == want
+
+
+@pytest.mark.parametrize("field", FIELDS)
 def test_fft_values_match_model(field):
     for lg in range(0, 7):
         n = 1 << lg

@@ -93,6 +93,7 @@ _sig = {
     "zk_mle_evaluate": [c.c_void_p, c.c_void_p, u64p, c.c_uint64, u64p],
     "zk_mle_to_bytes": [c.c_void_p, c.c_void_p, u8p],
     "zk_mle_partial_evaluate_host": [c.c_void_p, c.c_uint64, u64p, c.c_uint64, c.c_uint64, u64p, c.c_uint64, u64p],
+    "zk_coeff_to_evaluation": [c.c_void_p, c.c_uint64, u64p, u64p, c.c_uint64, vpp],
     "zk_product_check": [vpp, c.c_uint64],
     "zk_prod_reduce": [c.c_void_p, vpp, c.c_uint64, vpp],
     "zk_product_evaluate": [c.c_void_p, vpp, c.c_uint64, u64p, c.c_uint64, u64p],

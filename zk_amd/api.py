@@ -245,6 +245,44 @@ class MultiLinearPolynomial:
                 and np.array_equal(self.evaluation_slice(), other.evaluation_slice()))
 
 
+class CoeffMultilinearPolynomial:
+    """polynomial::multilinear::coefficient_form::CoeffMultilinearPolynomial (coefficient_form.rs:27-30), only as the
+    producer of evaluation tables: ::new (:158-176), ::new_with_coefficient (:178-193), ::to_evaluation_form (:340-347,
+    computed on the GPU and left resident as a MultiLinearPolynomial)."""
+
+    def __init__(self, field, n_vars, coefficients):
+        self.field, self._n_vars, self.coefficients = field, n_vars, coefficients   # {key: element}, key bit v <-> variable v
+
+    @classmethod
+    def new(cls, field, number_of_variables, terms):
+        """terms: [(coefficient element, [bool] * n_vars)]; duplicate selectors are summed (:164-171)."""
+        p = modulus(field)
+        acc = {}
+        for coeff, selector in terms:
+            if len(selector) != number_of_variables:
+                raise ZkError(-20, "the selector array len should be the same as the number of variables")
+            key = sum(1 << v for v, present in enumerate(selector) if present)          # selector_to_index :418-430
+            acc[key] = (acc.get(key, 0) + fe_to_int(field, coeff)) % p
+        return cls(field, number_of_variables, {k: fe_from_int(field, v) for k, v in acc.items()})
+
+    @classmethod
+    def new_with_coefficient(cls, field, number_of_variables, coefficients):
+        if coefficients and max(coefficients) >= (1 << number_of_variables):
+            raise ZkError(-10, "coefficient map represents more than specificed number of variables")
+        return cls(field, number_of_variables, dict(coefficients))
+
+    def n_vars(self):
+        return self._n_vars
+
+    def to_evaluation_form(self, ctx):
+        keys = np.array(sorted(self.coefficients), dtype=np.uint64)
+        coeffs = (np.stack([self.coefficients[int(k)] for k in keys]) if len(keys) else np.zeros((0, 4), dtype=np.uint64))
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        h = c.c_void_p()
+        check(lib.zk_coeff_to_evaluation(ctx._h, self._n_vars, _p(keys), _p(coeffs), len(keys), c.byref(h)))
+        return MultiLinearPolynomial(ctx, h)
+
+
 class ProductPoly:
     """P(x) = A(x).B(x).C(x) (product_poly.rs:7-10)."""
 
@@ -388,7 +426,7 @@ def bench_ntt(ctx, vec_in, vec_out, inverse=False, reps=5):
 
 
 __all__ = [
-    "BN254_FR", "BLS12_381_FR", "BLS12_377_FR", "Context", "MultiLinearPolynomial", "ProductPoly", "SumcheckProof",
+    "BN254_FR", "BLS12_381_FR", "BLS12_377_FR", "Context", "MultiLinearPolynomial", "CoeffMultilinearPolynomial", "ProductPoly", "SumcheckProof",
     "SubClaim", "SumcheckProver", "SumcheckVerifier", "Transcript", "ZkError", "fft", "ifft", "fft_internal", "ntt", "bench_ntt",
     "fe_from_int", "fe_from_ints", "fe_to_int", "fe_to_ints", "keccak256", "modulus", "two_adicity",
 ]

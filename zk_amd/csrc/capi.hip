@@ -131,6 +131,7 @@ extern "C" const char *zk_strerror(int32_t s) {
         case ZK_ERR_FFT_NO_ROOT: return "reference panics: get_root_of_unity returned None";
         case ZK_ERR_VERIFY_ROUNDS: return "invalid proof: require 1 round poly for each variable in poly";
         case ZK_ERR_VERIFY_SUM: return "verifier check failed: claimed_sum != p(0) + p(1)";
+        case ZK_ERR_COEFF_RANGE: return "coefficient map represents more than specificed number of variables";
         case ZK_ERR_BAD_ARG: return "bad argument";
         case ZK_ERR_BAD_FIELD: return "unknown field id";
         case ZK_ERR_NO_DEVICE: return "no usable gfx950 device (libzk_amd has no CPU fallback)";
@@ -485,6 +486,64 @@ extern "C" int32_t zk_mle_partial_evaluate_host(zk_ctx *c, uint64_t n_vars, cons
     (void)zk_mle_free(c, t);
     (void)zk_mle_free(c, o);
     return rc;
+}
+
+// CoeffMultilinearPolynomial::to_evaluation_form (coefficient_form.rs:340-347): scatter + zeta transform on the device
+extern "C" int32_t zk_coeff_to_evaluation(zk_ctx *c, uint64_t n_vars, const uint64_t *keys, const uint64_t *coeffs, uint64_t n_terms,
+                                          zk_mle **out) {
+    if (!c || !out || (n_terms && (!keys || !coeffs))) return ZK_ERR_BAD_ARG;
+    if (n_vars == 0 || n_vars > kMaxVars) return ZK_ERR_EVAL_LEN;
+    for (uint64_t t = 0; t < n_terms; ++t)
+        if (keys[t] >> n_vars) return ZK_ERR_COEFF_RANGE;                            // coefficient_form.rs:183-186
+    ZKCHK(use_device(c));
+    // BTreeMap semantics: one entry per key, duplicate terms summed (coefficient_form.rs:164-171)
+    std::map<uint64_t, Fe> merged;
+    for (uint64_t t = 0; t < n_terms; ++t) {
+        const Fe v = fe_from_u64limbs(coeffs + 4 * t);
+        auto it = merged.find(keys[t]);
+        if (it == merged.end()) merged.emplace(keys[t], v);
+        else it->second = fe_add(it->second, v, c->fi->P);
+    }
+    std::vector<uint64_t> hk, hc;
+    for (auto &kv : merged) {
+        hk.push_back(kv.first);
+        uint64_t l[4];
+        fe_to_u64limbs(kv.second, l);
+        hc.insert(hc.end(), l, l + 4);
+    }
+    const uint64_t m = hk.size();
+    zk_mle *t = nullptr;
+    ZKCHK(mle_alloc(c, n_vars, &t));
+    uint64_t *d_keys = nullptr, *d_coeffs = nullptr;
+    int32_t rc = ZK_OK;
+    if (hipMemsetAsync(t->d, 0, (size_t)32 << n_vars, c->stream) != hipSuccess) rc = ZK_ERR_HIP;
+    if (rc == ZK_OK && m) {
+        rc = pool_alloc(c, m * 8, (void **)&d_keys);
+        if (rc == ZK_OK) rc = pool_alloc(c, m * 32, (void **)&d_coeffs);
+        if (rc == ZK_OK && (hipMemcpyAsync(d_keys, hk.data(), m * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                            hipMemcpyAsync(d_coeffs, hc.data(), m * 32, hipMemcpyHostToDevice, c->stream) != hipSuccess))
+            rc = ZK_ERR_HIP;
+        if (rc == ZK_OK) {
+            k_scatter_terms<<<grid_for(m), kBlock, 0, c->stream>>>(d_keys, d_coeffs, m, t->d, (uint32_t)n_vars);
+            if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+        }
+    }
+    for (uint32_t b = 0; b < n_vars && rc == ZK_OK; ++b) {
+        const uint64_t pairs = 1ull << (n_vars - 1);
+        uint64_t g = (pairs + kBlock - 1) / kBlock;
+        if (g > kMaxGridStream) g = kMaxGridStream;
+        k_zeta_pass<<<(uint32_t)g, kBlock, 0, c->stream>>>(t->d, pairs, b, c->fi->P);
+        if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == ZK_OK) rc = ZK_ERR_HIP;   // host staging vectors go out of scope
+    if (d_keys) pool_free(c, d_keys, m * 8);
+    if (d_coeffs) pool_free(c, d_coeffs, m * 32);
+    if (rc != ZK_OK) {
+        mle_release(t);
+        return rc;
+    }
+    *out = t;
+    return ZK_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------

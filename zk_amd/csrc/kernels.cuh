@@ -542,6 +542,24 @@ __global__ __launch_bounds__(kBlock) void k_to_bytes(const uint64_t *__restrict_
     }
 }
 
+// ---- CoeffMultilinearPolynomial::to_evaluation_form (coefficient_form.rs:340-347) ---------------------------------------
+// eval[idx] = sum over keys that are subsets of the point's variable set.  With key bit v <-> variable v and table index
+// bit (n-1-v) <-> variable v, that is a zeta (subset-sum) transform of the coefficient vector placed at bit-reversed
+// positions: scatter, then one in-place pass per variable: T[x | b] += T[x].
+__global__ __launch_bounds__(kBlock) void k_scatter_terms(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ coeffs,
+                                                          uint64_t n_terms, uint64_t *__restrict__ table, uint32_t n_vars) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < n_terms; t += stride)
+        fe_store(table, __brevll(keys[t]) >> (64 - n_vars), fe_load(coeffs, t));   // keys are unique (merged on the host)
+}
+__global__ __launch_bounds__(kBlock) void k_zeta_pass(uint64_t *table, uint64_t pairs, uint32_t pos, FieldParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < pairs; j += stride) {
+        const uint64_t lo = insert_zero_bit(j, pos), hi = lo | (1ull << pos);
+        fe_store(table, hi, fe_add(fe_load(table, hi), fe_load(table, lo), P));
+    }
+}
+
 // ---- synthetic inputs: element i = first hash(seed, i, attempt) < p, stored in Montgomery form --------
 ZK_D uint64_t splitmix64(uint64_t x) {
     uint64_t z = x + 0x9E3779B97F4A7C15ull;
