@@ -264,7 +264,7 @@ def test_round_sums_lazy_reduction_worst_case():
 # ------------------------------------------------------------------ prover vs oracle (bit-exact transcript)
 @pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k,D,n_vars", [(1, 1, 12), (2, 2, 12), (3, 3, 10), (2, 1, 7), (1, 3, 6), (4, 4, 8), (2, 2, 1),
-                                        (2, 2, 2), (2, 5, 6), (1, 0, 4), (2, 3, 9)])
+                                        (2, 2, 2), (2, 5, 6), (1, 0, 4), (2, 3, 9), (5, 2, 6), (8, 8, 4), (3, 2, 11), (1, 2, 12)])
 @pytest.mark.parametrize("absorb", [False, True])
 def test_sumcheck_matches_oracle(field, k, D, n_vars, absorb):
     c = ctx_for(field)
@@ -416,6 +416,24 @@ def test_config4_gkr_shaped_layers_verify():
         sub = SumcheckVerifier.verify_partial(field, proof)
         assert np.array_equal(sub.challenges, ch)
         assert np.array_equal(pp.evaluate(ch), sub.sum)
+
+
+def test_25var_prover_beyond_the_capped_grid():
+    """2^25-element table: the round kernel needs more than 2048 workgroups to keep <= 16 pairs per thread (lazy
+    reduction bound).  k = 1, D = 1: the proof must verify and its subclaim must equal the table evaluated at the
+    challenges (size-independent property; the faithful oracle would take minutes here)."""
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    n = 25
+    A = MLE.random(c, n, 0x5EED0000 + 25, 0)
+    pp = ProductPoly.new([A])
+    s = pp.round_sums(1)
+    claimed = orc.add(field, s[0], s[1])
+    proof, ch = SumcheckProver(1).prove_partial(pp, claimed)
+    sub = SumcheckVerifier.verify_partial(field, proof)
+    assert np.array_equal(sub.challenges, ch)
+    assert np.array_equal(A.evaluate(ch), sub.sum)
+    A.free()
 
 
 def test_config_24var_fold_properties():
