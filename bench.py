@@ -220,7 +220,20 @@ def main():
 
     if dist is not None and not args.no_extra:
         # the prover over a table sharded by index mod world: every rank holds a 2^22-element shard per
-        # factor; one all-reduce of (D+1)*8 int64 lanes per round, one all-gather for the tail
+        # factor; one all-reduce of (D+1)*8 int64 lanes per round, one all-gather for the tail.
+        # This secondary measurement must never cost the headline line: if it stalls (a collective waiting on a rank
+        # that failed), a watchdog prints the line without it and ends every rank.
+        import threading
+
+        def _bail():
+            if rank == 0:
+                result.setdefault("extra", {})["sharded_error"] = "sharded-prover extra timed out (watchdog)"
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(120.0, _bail)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             from zk_amd.distributed import GpuShardBackend, ShardedSumcheckProver
 
@@ -252,6 +265,8 @@ def main():
         except Exception as e:
             if rank == 0:
                 result.setdefault("extra", {})["sharded_error"] = repr(e)
+        finally:
+            watchdog.cancel()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, _ = cpu_baseline(field)
