@@ -337,6 +337,20 @@ def test_fft_lds_passes_vs_oracle_fast(lg):
         assert np.array_equal(zk_amd.ifft(c, f), v)
 
 
+@pytest.mark.parametrize("lg", [8, 10, 13])
+def test_fft_internal_user_omega_on_the_multipass_plan(lg):
+    """fft_internal(values, omega) (fft/src/lib.rs:21-46) with a primitive root other than get_root_of_unity's, at sizes
+    that run the LDS multi-pass plan with tables built for that omega; the oracle's faithful recursion is the checker."""
+    field = zk_amd.BLS12_377_FR
+    c = ctx_for(field)
+    n = 1 << lg
+    w = orc.pow_(field, orc.root_of_unity(field, n), 5)      # still a primitive n-th root (5 is odd)
+    v = orc.fill_random(field, 900 + lg, n)
+    want = np.zeros_like(v)
+    orc._check(orc._lib.orc_fft_internal(field, orc._p(v), orc._c.c_uint64(n), orc._p(w), orc._p(want)))
+    assert np.array_equal(zk_amd.fft_internal(c, v, w), want)
+
+
 def test_config5_ntt_2_24_properties():
     """config[4]: 2^24-point NTT on one GPU.  (a) ifft(fft(x)) == x on the device-resident vector; (b) two output
     coefficients against the definition X[k] = sum_j x[j] w^(jk): X[0] = sum x[j] and X[n/2] = sum (-1)^j x[j]
