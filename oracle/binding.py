@@ -226,6 +226,14 @@ def mle_to_bytes(field, n_vars, evals):
     return out.tobytes()
 
 
+def fold_msb_parallel(field, n_vars, evals, r, threads=0):
+    evals = _arr(evals, 1 << n_vars)
+    r = _arr(r, 1)
+    out = np.zeros((1 << (n_vars - 1), 4), dtype=np.uint64)
+    used = _check(_lib.orc_fold_msb_parallel(field, _c.c_uint64(n_vars), _p(evals), _p(r), _p(out), int(threads)))
+    return out, used
+
+
 def coeff_to_evaluation(field, n_vars, keys, coeffs):
     keys = np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1)
     coeffs = _arr(coeffs).reshape(-1, 4)

@@ -11,6 +11,9 @@
 
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef uint64_t u64;
 typedef unsigned __int128 u128;
@@ -331,6 +334,27 @@ int orc_mle_partial_evaluate(int field, u64 n_vars, const u64 *evals, u64 initia
     memcpy(out, w, (1ULL << (n_vars - n_assign)) * 32); /* :76-79 */
     free(w);
     return ORC_OK;
+}
+
+/* optimised-CPU baseline: out[j] = lo - r*(lo - hi), j < 2^(n-1), all cores (evaluation_form.rs:68 only) */
+int orc_fold_msb_parallel(int field, u64 n_vars, const u64 *evals, const u64 r[4], u64 *out, int threads) {
+    const fparams *F = field_get(field);
+    if (!F || n_vars == 0) return ORC_ERR_BAD_FIELD;
+    const long half = (long)(1ULL << (n_vars - 1));
+    int used = 1;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    used = omp_get_max_threads();
+#endif
+    (void)threads;
+#pragma omp parallel for schedule(static)
+    for (long j = 0; j < half; ++j) {
+        u64 d[4], m[4];
+        f_sub(F, evals + 4 * j, evals + 4 * (j + half), d);
+        f_mul(F, r, d, m);
+        f_sub(F, evals + 4 * j, m, out + 4 * j);
+    }
+    return used;
 }
 
 int orc_mle_evaluate(int field, u64 n_vars, const u64 *evals, const u64 *point, u64 n_point, u64 out[4]) { /* :83-89 */

@@ -80,6 +80,10 @@ int orc_mle_evaluate(int field, uint64_t n_vars, const uint64_t *evals,
                      const uint64_t *point, uint64_t n_point, uint64_t out[4]); /* :83-89 */
 void orc_mle_to_bytes(int field, uint64_t n_vars, const uint64_t *evals, uint8_t *out); /* :97-103 */
 
+/* "optimised CPU" baseline row: the same single-variable MSB fold, out of place, no clone / copy,
+ * OpenMP across `threads` cores.  Same values as orc_mle_partial_evaluate(.., 0, [r]); returns the thread count used. */
+int orc_fold_msb_parallel(int field, uint64_t n_vars, const uint64_t *evals, const uint64_t r[4], uint64_t *out, int threads);
+
 /* ---- polynomial/src/multilinear/coefficient_form.rs:340-347 + boolean_hypercube.rs:27-45 (the step before the path) ----
  * to_evaluation_form of the sparse coefficient-form polynomial {key -> coeff}, key bit v <-> variable v
  * (selector_to_index :418-430).  out: 2^n_vars elements in hypercube order (binary strings, variable 0 first = MSB). */

@@ -161,6 +161,14 @@ def test_ntt_fast_equals_faithful_fft(field, lg):
     assert np.array_equal(orc.ifft(field, f), v)
 
 
+def test_parallel_fold_baseline_equals_faithful_fold():
+    for field in FIELDS:
+        tab = orc.fill_random(field, 4321, 1 << 12)
+        r = orc.fill_random(field, 9, 1)
+        got, used = orc.fold_msb_parallel(field, 12, tab, r[0], threads=4)
+        assert used >= 1 and np.array_equal(got, orc.mle_partial_evaluate(field, 12, tab, 0, r))
+
+
 def test_transcript_chain_matches_model():
     t, m = orc.Transcript(), pyref.Transcript()
     for chunk in (b"", b"abc", bytes(range(200)), b"\x00" * 136):
