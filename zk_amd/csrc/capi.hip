@@ -426,23 +426,50 @@ extern "C" int32_t zk_mle_fold_into(zk_ctx *c, const zk_mle *t, const uint64_t r
     return launch_fold(c, t->d, out->d, t->n_vars, 0, fe_from_u64limbs(r));
 }
 
-// evaluate (evaluation_form.rs:83-89): n MSB folds; the first out of place into scratch, the rest in place there
+// evaluate (evaluation_form.rs:83-89): MSB folds -- the first out of place into scratch, the next ones in place there,
+// and the last <= kEvalTailVars variables in one single-workgroup launch (k_evaluate_tail)
 static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point, uint64_t *d_out_elem) {
     const uint64_t n = t->n_vars;
     if (n == 0) {
         HIPCHK(hipMemcpyAsync(d_out_elem, t->d, 32, hipMemcpyDeviceToDevice, c->stream));
         return ZK_OK;
     }
+    const FieldParams &P = c->fi->P;
+    const uint64_t tail_vars = n < (uint64_t)kEvalTailVars ? n : (uint64_t)kEvalTailVars;
+    const uint64_t big = n - tail_vars;                    // folds done as full launches
     uint64_t *scratch = nullptr;
-    ZKCHK(pool_alloc(c, (size_t)32 << (n - 1), (void **)&scratch));
+    size_t scratch_bytes = 0;
+    if (big) {
+        scratch_bytes = (size_t)32 << (n - 1);
+        ZKCHK(pool_alloc(c, scratch_bytes, (void **)&scratch));
+    }
+    uint32_t *d_ch = nullptr;
+    int32_t rc = pool_alloc(c, (size_t)kEvalTailVars * kEvalChWords * 4, (void **)&d_ch);
     const uint64_t *src = t->d;
-    int32_t rc = ZK_OK;
-    for (uint64_t i = 0; i < n && rc == ZK_OK; ++i) {
+    for (uint64_t i = 0; i < big && rc == ZK_OK; ++i) {
         rc = launch_fold(c, src, scratch, n - i, 0, fe_from_u64limbs(point + 4 * i));
         src = scratch;
     }
-    if (rc == ZK_OK && hipMemcpyAsync(d_out_elem, scratch, 32, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = ZK_ERR_HIP;
-    pool_free(c, scratch, (size_t)32 << (n - 1));
+    if (rc == ZK_OK) {
+        // the remaining assignments in prepared form, staged through pinned memory
+        HIPCHK(hipStreamSynchronize(c->stream));           // h_pinned may still be in flight from an earlier call
+        uint32_t *h = reinterpret_cast<uint32_t *>(c->h_pinned);
+        for (uint64_t v = 0; v < tail_vars; ++v) {
+            const Mul29 r = mul29_prepare(fe_from_u64limbs(point + 4 * (big + v)), P);
+            for (int i = 0; i < 9; ++i) h[v * kEvalChWords + i] = r.l[i];
+        }
+        if (hipMemcpyAsync(d_ch, h, (size_t)tail_vars * kEvalChWords * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_ERR_HIP;
+        const size_t lds = (size_t)32 << (tail_vars - 1);
+        if (rc == ZK_OK && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_evaluate_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds) != hipSuccess)
+            rc = ZK_ERR_HIP;
+        if (rc == ZK_OK) {
+            k_evaluate_tail<<<1, kEvalTailThreads, lds, c->stream>>>(src, (uint32_t)tail_vars, d_ch, P, d_out_elem);
+            if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+        }
+    }
+    if (scratch) pool_free(c, scratch, scratch_bytes);
+    pool_free(c, d_ch, (size_t)kEvalTailVars * kEvalChWords * 4);
     return rc;
 }
 extern "C" int32_t zk_mle_evaluate(zk_ctx *c, const zk_mle *t, const uint64_t *point, uint64_t n_point, uint64_t out[4]) {

@@ -109,6 +109,47 @@ __global__ __launch_bounds__(kBlock) void k_fold_dev(const uint64_t *in, uint64_
     }
 }
 
+// ---- MultiLinearPolynomial::evaluate, tail (evaluation_form.rs:83-89) -----------------------------------------------------
+// Once the table is small every further fold is launch latency.  One 1024-thread workgroup finishes the last m <= 12
+// variables: the first of them is folded while the 2^m elements are read from HBM (so 2^(m-1) elements = 64 KiB of LDS at
+// m = 12), the rest in place in LDS with one barrier per variable.  ch29: the m remaining assignments, prepared on the
+// host (Mul29 records of kEvalChWords words).
+constexpr int kEvalTailVars = 12;
+constexpr int kEvalTailThreads = 1024;
+constexpr int kEvalChWords = 16;
+__global__ __launch_bounds__(kEvalTailThreads) void k_evaluate_tail(const uint64_t *__restrict__ in, uint32_t m,
+                                                                    const uint32_t *__restrict__ ch29, FieldParams P,
+                                                                    uint64_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ev_smem[];
+    uint64_t *T = reinterpret_cast<uint64_t *>(ev_smem);
+    const uint32_t tid = threadIdx.x;
+    auto load_r = [&](uint32_t v) {
+        Mul29 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.l[i] = __builtin_amdgcn_readfirstlane(ch29[v * kEvalChWords + i]);
+        return r;
+    };
+    uint32_t q = 1u << (m - 1);
+    {
+        const Mul29 r = load_r(0);
+        for (uint32_t j = tid; j < q; j += kEvalTailThreads) {
+            const Fe lo = fe_load(in, j), hi = fe_load(in, j + q);
+            fe_store(T, j, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P));
+        }
+    }
+    __syncthreads();
+    for (uint32_t v = 1; v < m; ++v) {
+        q >>= 1;
+        const Mul29 r = load_r(v);
+        for (uint32_t j = tid; j < q; j += kEvalTailThreads) {
+            const Fe lo = fe_load(T, j), hi = fe_load(T, j + q);
+            fe_store(T, j, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P));   // in place: j and j+q belong to this thread
+        }
+        __syncthreads();
+    }
+    if (tid == 0) fe_store(out, 0, fe_load(T, 0));
+}
+
 // ---- ProductPoly::prod_reduce (product_poly.rs:66-74) --------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_prod_reduce(FactorPtrs fp, int k, uint64_t n, uint64_t *__restrict__ out,
                                                         FieldParams P) {
