@@ -166,8 +166,10 @@ int32_t zk_sumcheck_prove_host(zk_ctx *ctx, const uint64_t *const *tables, uint6
  *                 cannot overflow and carry exactly the field sum (RCCL has no mod-p reduction).
  *   round_finish: carry-propagate + reduce the summed lanes mod p, absorb the round polynomial, squeeze the challenge
  *                 (identical on every rank: same transcript, same bytes).
- * After the local rounds: tail_ptr gives this rank's k fully folded elements; the caller all-gathers them rank-major
- * into [world][k] and tail_rounds finishes the last log2 world rounds on every rank (world-element tables).
+ * At any point after a round_finish (typically once the local tables are <= 2^10 elements, and at the latest after the
+ * last local round): tail_ptr applies the pending challenge and exposes this rank's k shard tables as one device buffer
+ * [k][2^s]; the caller all-gathers them rank-major into [world][k][2^s] and tail_rounds rebuilds the (s + log2 world)-
+ * variable tables and runs ALL remaining rounds on every rank redundantly -- no further collective.
  * results downloads the proof (total_rounds = n rounds).  `sum` is the GLOBAL claimed sum (prover.rs:42). */
 typedef struct zk_shard_prover zk_shard_prover;
 int32_t zk_shard_prover_create(zk_ctx *ctx, zk_mle *const *factors, uint64_t k, uint32_t max_var_degree,
@@ -178,7 +180,7 @@ int32_t zk_shard_prover_lanes_ptr(zk_shard_prover *sp, void **out_device_ptr, ui
 int32_t zk_shard_prover_round_begin(zk_shard_prover *sp);
 int32_t zk_shard_prover_round_finish(zk_shard_prover *sp);
 int32_t zk_shard_prover_tail_ptr(zk_shard_prover *sp, void **out_device_ptr, uint64_t *out_n_elems);
-int32_t zk_shard_prover_tail_rounds(zk_shard_prover *sp, const void *gathered_device /* [world][k] elements */);
+int32_t zk_shard_prover_tail_rounds(zk_shard_prover *sp, const void *gathered_device /* [world][k][2^s] elements */);
 int32_t zk_shard_prover_results(zk_shard_prover *sp, uint64_t *out_round_polys, uint64_t *out_challenges);
 /* raw device buffers on the context (pooled) and synchronous copies: for hosts that drive the exchange themselves */
 int32_t zk_ctx_device_alloc(zk_ctx *ctx, uint64_t bytes, void **out_device_ptr);

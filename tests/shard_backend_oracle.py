@@ -38,6 +38,9 @@ class OracleShardBackend:
             out.append(acc)
         return np.stack(out)
 
+    def local_vars_left(self):
+        return self.local_rounds - len(self.rp)
+
     def round_begin(self):
         self._apply_pending()
         sums = self._local_sums()                                    # (D+1, 4) u64 Montgomery limbs
@@ -62,13 +65,17 @@ class OracleShardBackend:
 
     def tail(self):
         self._apply_pending()
-        elems = np.stack([t[0] for t in self.cur])                   # (k, 4)
+        self.tail_s = self.vars_left
+        elems = np.stack(self.cur)                                   # (k, 2^s, 4)
         return torch.from_numpy(elems.view(np.int64).reshape(-1).copy())
 
     def tail_rounds(self, gathered):
-        g = gathered.numpy().view(np.uint64).reshape(self.world, self.k, 4)
-        self.cur = [np.ascontiguousarray(g[:, f, :]) for f in range(self.k)]
-        self.vars_left = int(np.log2(self.world))
+        n_local = 1 << self.tail_s
+        g = gathered.numpy().view(np.uint64).reshape(self.world, self.k, n_local, 4)
+        # table_f[local * world + rank] = g[rank][f][local]
+        self.cur = [np.ascontiguousarray(np.transpose(g[:, f, :, :], (1, 0, 2)).reshape(n_local * self.world, 4))
+                    for f in range(self.k)]
+        self.vars_left = self.tail_s + int(np.log2(self.world))
         while self.vars_left > 0:
             self._apply_pending()
             if self.vars_left == 0:

@@ -23,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, field, k, D, n_vars, out_dir):
+def _worker(rank, world, port, field, k, D, n_vars, out_dir, gather_below=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -37,21 +37,24 @@ def _worker(rank, world, port, field, k, D, n_vars, out_dir):
         for e in orc.prod_reduce(field, n_vars, tabs):
             claimed = orc.add(field, claimed, e)
         backend = OracleShardBackend(field, [shard_of(t, rank, world) for t in tabs], D, claimed, world)
-        rp, ch = ShardedSumcheckProver(backend).prove_partial()
+        rp, ch = ShardedSumcheckProver(backend, gather_below=gather_below).prove_partial()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rp=rp, ch=ch)
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 4])
-@pytest.mark.parametrize("field,k,D,n_vars", [(0, 2, 2, 6), (1, 1, 1, 5), (0, 3, 3, 4), (2, 2, 2, 2)])
-def test_sharded_prover_matches_single_process_oracle(tmp_path, world, field, k, D, n_vars):
+@pytest.mark.parametrize("field,k,D,n_vars,gather_below", [(0, 2, 2, 6, 0), (1, 1, 1, 5, 0), (0, 3, 3, 4, 0), (2, 2, 2, 2, 0),
+                                                           (0, 2, 2, 6, 2), (1, 2, 1, 5, 10)])
+def test_sharded_prover_matches_single_process_oracle(tmp_path, world, field, k, D, n_vars, gather_below):
+    """gather_below = 0: a collective in every local round, gather only the final elements; 2: stop exchanging when the
+    local tables have 4 elements; 10: gather at once (no per-round collective at all)."""
     if (1 << n_vars) < world:
         pytest.skip("table smaller than the world")
     from oracle import binding as orc
 
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, field, k, D, n_vars, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, field, k, D, n_vars, str(tmp_path), gather_below), nprocs=world, join=True)
     tabs = [orc.fill_random(field, 900 + f, 1 << n_vars) for f in range(k)]
     claimed = np.zeros(4, dtype=np.uint64)
     for e in orc.prod_reduce(field, n_vars, tabs):

@@ -22,9 +22,10 @@ def claimed_sum(field, n, tabs):
 
 
 @pytest.mark.parametrize("field", [zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR])
+@pytest.mark.parametrize("gather_below", [0, 3, 12])
 @pytest.mark.parametrize("world,k,D,n_vars", [(1, 2, 2, 8), (2, 2, 2, 8), (4, 1, 1, 7), (8, 2, 2, 10), (8, 3, 3, 6), (4, 2, 2, 2),
                                                (2, 2, 5, 6), (8, 2, 2, 3)])
-def test_shard_provers_match_unsharded_oracle(field, world, k, D, n_vars):
+def test_shard_provers_match_unsharded_oracle(field, world, k, D, n_vars, gather_below):
     import torch
 
     ctx = zk_amd.Context(field, 0)
@@ -36,7 +37,7 @@ def test_shard_provers_match_unsharded_oracle(field, world, k, D, n_vars):
     for g in range(world):
         poly = ProductPoly.new([MLE.new(ctx, n_vars - w, shard_of(t, g, world)) for t in tabs])
         backends.append(GpuShardBackend(poly, D, claimed, world))
-    for _ in range(backends[0].local_rounds):
+    while backends[0].local_vars_left() > gather_below:   # 0: exchange every local round; 12: gather at once
         lanes = [b.round_begin() for b in backends]
         total = torch.stack(lanes).sum(dim=0)          # what all_reduce(SUM) leaves on every rank
         for b, l in zip(backends, lanes):

@@ -1000,7 +1000,9 @@ struct zk_shard_prover {
     uint32_t world;
     uint64_t local_rounds, total_rounds;
     uint64_t *d_lanes;    // (D+1)*8 u64 lanes
-    uint64_t *d_tail;     // k elements: this rank's fully folded factors
+    uint64_t *d_tail;     // k * 2^tail_s elements: this rank's shard tables at the moment of the gather
+    size_t tail_bytes;
+    uint32_t tail_s;      // variables left in the local tables when gathered
     bool tail_done;
 };
 extern "C" int32_t zk_shard_prover_create(zk_ctx *c, zk_mle *const *f, uint64_t k, uint32_t D, const uint64_t sum[4],
@@ -1017,10 +1019,11 @@ extern "C" int32_t zk_shard_prover_create(zk_ctx *c, zk_mle *const *f, uint64_t 
     sp->local_rounds = f[0]->n_vars;
     sp->total_rounds = f[0]->n_vars + lw;
     sp->d_lanes = sp->d_tail = nullptr;
+    sp->tail_bytes = 0;
+    sp->tail_s = 0;
     sp->tail_done = false;
     int32_t rc = round_state_init(sp->st, c, f, k, D, /*consume=*/true, sp->total_rounds);
     if (rc == ZK_OK) rc = pool_alloc(c, (size_t)kMaxSums * 8 * sizeof(uint64_t), (void **)&sp->d_lanes);
-    if (rc == ZK_OK) rc = pool_alloc(c, (size_t)kMaxFactors * 32, (void **)&sp->d_tail);
     if (rc == ZK_OK) {
         Sponge host;
         host.init();
@@ -1040,7 +1043,7 @@ extern "C" int32_t zk_shard_prover_destroy(zk_shard_prover *sp) {
     (void)hipSetDevice(c->device);
     round_state_release(sp->st);
     pool_free(c, sp->d_lanes, (size_t)kMaxSums * 8 * sizeof(uint64_t));
-    pool_free(c, sp->d_tail, (size_t)kMaxFactors * 32);
+    pool_free(c, sp->d_tail, sp->tail_bytes);
     delete sp;
     return ZK_OK;
 }
@@ -1078,53 +1081,68 @@ extern "C" int32_t zk_shard_prover_round_finish(zk_shard_prover *sp) {
     ++st.round;
     return ZK_OK;
 }
-// after the last local round: apply the last challenge -> one element per factor (device, k elements) for the all-gather
+// Stop exchanging per round: apply the pending challenge and expose this rank's k shard tables (2^s elements each,
+// s = local variables still unfolded; s = 0 after the last local round) as one device buffer [k][2^s] for the all-gather.
+// May be called after any number of local rounds: once shards are tiny a collective per round costs more than finishing
+// redundantly on every rank.
 extern "C" int32_t zk_shard_prover_tail_ptr(zk_shard_prover *sp, void **out_ptr, uint64_t *out_elems) {
     if (!sp || !out_ptr || !out_elems) return ZK_ERR_BAD_ARG;
     RoundState &st = sp->st;
     zk_ctx *c = st.c;
-    if (st.round != sp->local_rounds) return ZK_ERR_BAD_ARG;
+    if (st.round > sp->local_rounds) return ZK_ERR_BAD_ARG;
     ZKCHK(use_device(c));
     if (!sp->tail_done) {
+        const uint64_t s = st.pending_fold ? st.vars_left - 1 : st.vars_left;
+        sp->tail_s = (uint32_t)s;
+        sp->tail_bytes = (size_t)st.k * ((size_t)32 << s);
+        ZKCHK(pool_alloc(c, sp->tail_bytes, (void **)&sp->d_tail));
         for (uint64_t i = 0; i < st.k; ++i) {
-            if (st.pending_fold) {   // vars_left == 1: fold the last two elements
-                k_fold_dev<<<1, kBlock, 0, c->stream>>>(st.cur[i], sp->d_tail + 4 * i, 1, 0, c->fi->P, st.ps.d_challenge);
+            uint64_t *dst = sp->d_tail + ((uint64_t)i << s) * 4;
+            if (st.pending_fold) {
+                const uint64_t pairs = 1ull << s;
+                k_fold_dev<<<grid_for(pairs), kBlock, 0, c->stream>>>(st.cur[i], dst, pairs, (uint32_t)(s + 1), c->fi->P, st.ps.d_challenge);
                 HIPCHK(hipGetLastError());
-            } else {                 // 0 local variables: the element itself
-                HIPCHK(hipMemcpyAsync(sp->d_tail + 4 * i, st.cur[i], 32, hipMemcpyDeviceToDevice, c->stream));
+            } else {
+                HIPCHK(hipMemcpyAsync(dst, st.cur[i], (size_t)32 << s, hipMemcpyDeviceToDevice, c->stream));
             }
         }
+        st.pending_fold = false;
+        st.vars_left = s;
         sp->tail_done = true;
     }
     *out_ptr = sp->d_tail;
-    *out_elems = st.k;
+    *out_elems = (uint64_t)st.k << sp->tail_s;
     return ZK_OK;
 }
-// gathered: device array [world][k] elements (rank-major), identical on every rank.  Runs the remaining log2(world)
-// rounds on the world-element tables table_f[rank] -- the (log2 world)-variable remainder in the reference's index
-// order, because rank = the low index bits.  Asynchronous.
+// gathered: device array [world][k][2^s] elements (rank-major, the all-gather of every rank's tail buffer), identical
+// on every rank.  Builds the k tables of s + log2(world) variables -- global index = local * world + rank, i.e. the
+// reference's own index order -- and runs ALL remaining rounds locally (no further collective).  Asynchronous.
 extern "C" int32_t zk_shard_prover_tail_rounds(zk_shard_prover *sp, const void *gathered) {
     if (!sp || !gathered) return ZK_ERR_BAD_ARG;
     RoundState &st = sp->st;
     zk_ctx *c = st.c;
-    if (st.round != sp->local_rounds || !sp->tail_done) return ZK_ERR_BAD_ARG;
+    if (!sp->tail_done) return ZK_ERR_BAD_ARG;
     ZKCHK(use_device(c));
-    if (sp->world == 1) return ZK_OK;
+    uint32_t lw = 0;
+    while ((1u << lw) < sp->world) ++lw;
+    const uint64_t vars = (uint64_t)sp->tail_s + lw;
+    if (st.round + vars != sp->total_rounds) return ZK_ERR_BAD_ARG;
+    if (vars == 0) return ZK_OK;
     FactorPtrs fp = {};
     for (uint64_t i = 0; i < st.k; ++i) {
         if (st.scratch[i]) pool_free(c, st.scratch[i], st.scratch_bytes[i]);
-        st.scratch_bytes[i] = (size_t)sp->world * 32;
+        st.scratch_bytes[i] = (size_t)32 << vars;
         st.scratch[i] = nullptr;
         ZKCHK(pool_alloc(c, st.scratch_bytes[i], (void **)&st.scratch[i]));
         fp.out[i] = st.scratch[i];
         st.cur[i] = st.scratch[i];
     }
-    const uint32_t items = (uint32_t)st.k * sp->world;
-    k_gather_to_tables<<<(items + 255) / 256, 256, 0, c->stream>>>((const uint64_t *)gathered, fp, (uint32_t)st.k, sp->world);
+    const uint64_t items = ((uint64_t)st.k << sp->tail_s) * sp->world;
+    k_gather_to_tables<<<grid_for(items), kBlock, 0, c->stream>>>((const uint64_t *)gathered, fp, (uint32_t)st.k, sp->world, sp->tail_s);
     HIPCHK(hipGetLastError());
     st.pending_fold = false;
     st.first_out_of_place = false;
-    st.vars_left = sp->total_rounds - sp->local_rounds;
+    st.vars_left = vars;
     int32_t rc = ZK_OK;
     while (st.round < sp->total_rounds && rc == ZK_OK) {
         if (finish_applies(st)) {

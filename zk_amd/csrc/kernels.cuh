@@ -560,12 +560,16 @@ __global__ void k_lanes_transcript(const uint64_t *__restrict__ lanes, uint32_t 
     transcript_round(sponge, fin, ns, d_challenge, out_ch, P);
 }
 
-// transpose the all-gathered tail elements [rank][factor] into k tables of `world` elements (table_f[rank])
-__global__ void k_gather_to_tables(const uint64_t *__restrict__ gathered, FactorPtrs fp, uint32_t k, uint32_t world) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < k * world) {
-        const uint32_t rank = i / k, f = i % k;
-        fe_store(fp.out[f], rank, fe_load(gathered, i));
+// interleave the all-gathered shard tables [rank][factor][2^s] into k tables of world * 2^s elements:
+// table_f[local * world + rank] = gathered[rank][f][local]  (global index = local * world + rank)
+__global__ __launch_bounds__(kBlock) void k_gather_to_tables(const uint64_t *__restrict__ gathered, FactorPtrs fp, uint32_t k,
+                                                             uint32_t world, uint32_t s) {
+    const uint64_t per_rank = (uint64_t)k << s, total = per_rank * world, stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        const uint64_t rank = i / per_rank, rem = i % per_rank;
+        const uint32_t f = (uint32_t)(rem >> s);
+        const uint64_t local = rem & ((1ull << s) - 1);
+        fe_store(fp.out[f], local * world + rank, fe_load(gathered, i));
     }
 }
 

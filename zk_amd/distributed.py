@@ -67,6 +67,12 @@ class GpuShardBackend:
     def __del__(self):
         self.close()
 
+    def local_vars_left(self):
+        """variables of the local shard tables that no completed round has consumed yet"""
+        loc, done = c.c_uint64(), c.c_uint64()
+        check(lib.zk_shard_prover_rounds(self._h, c.byref(loc), None, c.byref(done)))
+        return loc.value - done.value
+
     def round_begin(self):
         check(lib.zk_shard_prover_round_begin(self._h))
         return self.lanes
@@ -93,20 +99,24 @@ class GpuShardBackend:
 class ShardedSumcheckProver:
     """SumcheckProver::prove_partial (prover.rs:24-30) for a table sharded over the ranks of `group`.
 
-    backend: an object with local_rounds, total_rounds, round_begin() -> int64 lane tensor, round_finish(), tail() ->
-    int64 tensor of k*4, tail_rounds(gathered), results().  Every rank returns the same
-    (round_polys, challenges) as the single-process prover on the unsharded table.
+    backend: an object with local_rounds, total_rounds, local_vars_left(), round_begin() -> int64 lane tensor,
+    round_finish(), tail() -> int64 tensor (k * 2^s elements), tail_rounds(gathered), results().  Every rank returns the
+    same (round_polys, challenges) as the single-process prover on the unsharded table.
+
+    gather_below: once the local shard tables have at most 2^gather_below elements, stop exchanging per round: one
+    all-gather of the shard tables, then every rank finishes redundantly (a collective per round costs tens of
+    microseconds, a round on a 2^10-element table less than that -- SURVEY 8e).
     """
 
-    def __init__(self, backend, group=None):
-        self.backend, self.group = backend, group
+    def __init__(self, backend, group=None, gather_below=10):
+        self.backend, self.group, self.gather_below = backend, group, gather_below
 
     def prove_partial(self):
         import torch.distributed as dist
 
         b = self.backend
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
-        for _ in range(b.local_rounds):
+        while b.local_vars_left() > self.gather_below:
             lanes = b.round_begin()
             if multi:
                 dist.all_reduce(lanes, op=dist.ReduceOp.SUM, group=self.group)   # the round's one collective
