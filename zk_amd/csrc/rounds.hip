@@ -1,4 +1,6 @@
 // rounds.hip -- instantiations + launch logic of the sumcheck round kernels.
+#include <cstdlib>
+
 #include "launch.hpp"
 #include "round_kernels.cuh"
 
@@ -6,12 +8,22 @@ namespace zk {
 
 static constexpr uint32_t kCapGrid = 2048;   // 8 workgroups per CU on 256 CUs
 
-// every thread handles at most kMaxLazy pairs (the lazy accumulators of k_round_kd are reduced once, after the loop)
+// Grid of a specialised round kernel.  Every thread pays a fixed epilogue (Montgomery-reduce the unreduced accumulators,
+// then the workgroup's modular reduction tree: ~1600 instructions) on top of ~800-2200 instructions per pair index, so
+// the cheapest grid is the one with the FEWEST waves that still fills the machine: up to kMaxLazy pairs per thread, but
+// at least kMinBlocks workgroups (2 waves per SIMD on 256 CUs) while there is one pair per thread to give them.
+static uint32_t min_blocks() {
+    static const uint32_t v = [] {
+        const char *e = getenv("ZK_ROUND_MIN_BLOCKS");   // tuning override
+        return e ? (uint32_t)atoi(e) : 512u;
+    }();
+    return v;
+}
 static inline uint32_t round_grid(uint64_t q) {
-    uint64_t b = (q + kBlock - 1) / kBlock;
-    if (b > kCapGrid) b = kCapGrid;
-    const uint64_t need = (q + (uint64_t)kBlock * kMaxLazy - 1) / ((uint64_t)kBlock * kMaxLazy);
-    if (b < need) b = need;
+    uint64_t b = (q + (uint64_t)kBlock * kMaxLazy - 1) / ((uint64_t)kBlock * kMaxLazy);   // kMaxLazy pairs per thread
+    const uint64_t one_pair = (q + kBlock - 1) / kBlock;                                    // one pair per thread
+    const uint64_t floor_b = one_pair < min_blocks() ? one_pair : min_blocks();
+    if (b < floor_b) b = floor_b;
     return (uint32_t)(b ? b : 1);
 }
 static inline uint32_t capped_grid(uint64_t q) {
