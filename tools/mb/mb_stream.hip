@@ -83,25 +83,6 @@ __global__ __launch_bounds__(256) void fold_nomul(const uint64_t* in, uint64_t* 
 }
 // C: lane-pair coalesced access: a wave reads 128 consecutive elements as 4 fully coalesced 1-KiB loads per stream;
 // lanes 2i / 2i+1 exchange halves so that each lane ends up with 2 whole elements.
-ZK_D uint32_t xchg1(uint32_t v) { return __builtin_amdgcn_mov_dpp(v, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true); }
-// given chunk A (from load k) and chunk B (from load k+1) per lane, return the full element this lane owns:
-// even lane 2i owns element (32k + i): lo half = its A, hi half = A of lane 2i+1;
-// odd lane 2i+1 owns element (32(k+1) + i): lo half = B of lane 2i, hi half = its B.
-ZK_D Fe pair_gather(uint4 A, uint4 B, bool odd) {
-    uint4 send = odd ? A : B;      // what the neighbour needs from me
-    uint4 recv = make_uint4(xchg1(send.x), xchg1(send.y), xchg1(send.z), xchg1(send.w));
-    Fe r;
-    if (!odd) { r = {{A.x, A.y, A.z, A.w, recv.x, recv.y, recv.z, recv.w}}; }
-    else      { r = {{recv.x, recv.y, recv.z, recv.w, B.x, B.y, B.z, B.w}}; }
-    return r;
-}
-ZK_D void pair_scatter(const Fe& e, bool odd, uint4& A, uint4& B) {
-    // inverse of pair_gather
-    uint4 lo = make_uint4(e.v[0], e.v[1], e.v[2], e.v[3]), hi = make_uint4(e.v[4], e.v[5], e.v[6], e.v[7]);
-    uint4 send = odd ? lo : hi;
-    uint4 recv = make_uint4(xchg1(send.x), xchg1(send.y), xchg1(send.z), xchg1(send.w));
-    if (!odd) { A = lo; B = recv; } else { A = recv; B = hi; }
-}
 template <bool NT>
 __global__ __launch_bounds__(256) void fold_pair(const uint64_t* in, uint64_t* out, uint64_t half, FieldParams P, Fe r) {
     // each wave handles blocks of 64 elements: 2 loads of 1 KiB per stream -> each lane 1 element... (2 chunks -> 1 elem per lane)
@@ -124,6 +105,34 @@ __global__ __launch_bounds__(256) void fold_pair(const uint64_t* in, uint64_t* o
         pair_scatter(o, odd, oa, ob);
         if (NT) { nts(oa, out4 + c0); nts(ob, out4 + c0 + 64); }
         else { out4[c0] = oa; out4[c0 + 64] = ob; }
+    }
+}
+
+// product kernel structure (k_fold_msb) with the carry-free multiply, U runs of 64 elements in flight per wave
+template <int U, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fold_pair29(const uint64_t* in, uint64_t* out, uint64_t half, FieldParams P, Mul29 r) {
+    const uint32_t lane = threadIdx.x & 63;
+    const bool odd = lane & 1;
+    const uint64_t wave = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * BLOCK) >> 6;
+    const uint4* in4 = reinterpret_cast<const uint4*>(in);
+    uint4* out4 = reinterpret_cast<uint4*>(out);
+    for (uint64_t e0 = wave * 64 * U; e0 < half; e0 += nwaves * 64 * U) {
+        uint4 la[U], lb[U], ha[U], hb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t c0 = 2 * (e0 + 64 * u) + lane;
+            la[u] = ntl(in4 + c0); lb[u] = ntl(in4 + c0 + 64); ha[u] = ntl(in4 + c0 + 2 * half); hb[u] = ntl(in4 + c0 + 2 * half + 64);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t c0 = 2 * (e0 + 64 * u) + lane;
+            Fe lo = pair_gather(la[u], lb[u], odd), hi = pair_gather(ha[u], hb[u], odd);
+            Fe o = fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P);
+            uint4 oa, ob;
+            pair_scatter(o, odd, oa, ob);
+            nts(oa, out4 + c0); nts(ob, out4 + c0 + 64);
+        }
     }
 }
 
@@ -179,6 +188,20 @@ int main(int argc, char** argv) {
         if (memcmp(href.data(), hout.data(), half * 32)) printf("  !! %s MISMATCH\n", name);
         CK(hipMemset(out, 0, half * 32));
     };
+    {
+        const Mul29 r29 = mul29_prepare(r, P);
+        for (int rep = 0; rep < 2; ++rep) {
+            for (int grid : {4096, 8192, 16384, 32768}) {
+                double a1 = T.ms([&] { fold_pair29<1, 256><<<grid, 256>>>(in, out, half, P, r29); }, 30); check("p29_u1_256");
+                double a2 = T.ms([&] { fold_pair29<2, 256><<<grid, 256>>>(in, out, half, P, r29); }, 30); check("p29_u2_256");
+                double a3 = T.ms([&] { fold_pair29<1, 512><<<grid / 2, 512>>>(in, out, half, P, r29); }, 30); check("p29_u1_512");
+                double a4 = T.ms([&] { fold_pair29<2, 512><<<grid / 2, 512>>>(in, out, half, P, r29); }, 30); check("p29_u2_512");
+                double a5 = T.ms([&] { k_fold_msb<<<grid, 256>>>(in, out, half, P, r29); }, 30); check("k_fold_msb");
+                printf("pair29 grid %5d: u1_256 %.0f  u2_256 %.0f  u1_512 %.0f  u2_512 %.0f  product k_fold_msb %.0f GB/s\n", grid, fold_bytes / a1 / 1e6,
+                       fold_bytes / a2 / 1e6, fold_bytes / a3 / 1e6, fold_bytes / a4 / 1e6, fold_bytes / a5 / 1e6);
+            }
+        }
+    }
     for (int grid : {1024, 2048, 4096, 8192, 16384, 32768}) {
         double a = T.ms([&] { k_fold<<<grid, 256>>>(in, out, half, n - 1, P, mul29_prepare(r, P)); }, 20); check("k_fold");
         double b = T.ms([&] { fold_v<true, true, 1><<<grid, 256>>>(in, out, half, P, r); }, 20); check("nt");
