@@ -24,6 +24,45 @@ ZK_D Mul29 load_challenge29(const uint64_t *rptr) {
     for (int i = 0; i < 9; ++i) r.l[i] = __builtin_amdgcn_readfirstlane(w[i]);   // wave-uniform -> SGPRs
     return r;
 }
+// Sum of one field element per lane over a wave, entirely on the VALU: v_permlane32_swap / v_permlane16_swap (gfx950)
+// across wave halves and 16-lane rows, DPP row rotations inside a row -- no ds_bpermute round trips.  Lanes >= width
+// must hold zero (their levels are skipped; width is wave-uniform); the total is valid in lane 0, and in every lane when
+// width == 64.  Addition in F_p is commutative and exact, so the order of the levels does not change the result.
+template <int CTRL>
+ZK_D Fe fe_dpp(const Fe &s) {
+    Fe o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = __builtin_amdgcn_update_dpp(0u, s.v[i], CTRL, 0xF, 0xF, true);
+    return o;
+}
+ZK_D Fe fe_wave_sum(Fe s, const FieldParams &P, uint32_t width = 64) {
+    if (width > 32) {
+        Fe a, b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const auto r = __builtin_amdgcn_permlane32_swap(s.v[i], s.v[i], false, false);
+            a.v[i] = r[0];
+            b.v[i] = r[1];
+        }
+        s = fe_add(a, b, P);
+    }
+    if (width > 16) {
+        Fe a, b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const auto r = __builtin_amdgcn_permlane16_swap(s.v[i], s.v[i], false, false);
+            a.v[i] = r[0];
+            b.v[i] = r[1];
+        }
+        s = fe_add(a, b, P);
+    }
+    // row_ror:n makes lane i read lane (i - n) mod 16: rotate by 16 - k so that lane 0 reads lane k (matters when width < 16)
+    if (width > 8) s = fe_add(s, fe_dpp<0x128>(s), P);
+    if (width > 4) s = fe_add(s, fe_dpp<0x12C>(s), P);
+    if (width > 2) s = fe_add(s, fe_dpp<0x12E>(s), P);
+    if (width > 1) s = fe_add(s, fe_dpp<0x12F>(s), P);
+    return s;
+}
 #endif
 
 }  // namespace zk

@@ -166,41 +166,53 @@ __global__ __launch_bounds__(kBlock) void k_prod_reduce(FactorPtrs fp, int k, ui
 // (transcript/src/lib.rs:20-30) and publish it in Montgomery form for the next round's fused fold.
 // Lane-parallel sponge.  State word A[x][y] lives on lane 8y + x + 1 of one wave: each plane (fixed y) occupies an
 // 8-lane group whose slots 1..5 are the primaries x = 0..4, slot 0 mirrors x = 4 and slots 6, 7 mirror x = 0, 1, so the
-// row neighbours x-1, x+1, x+2 that theta and chi need are plain DPP row shifts (VALU latency) instead of ds_bpermute
-// round trips.  Only the column parity (5 planes) and the pi permutation cross lanes through ds_bpermute, and their
-// source indices always name PRIMARY lanes, so the mirrors are recomputed from good data every time they are read:
-// 2 dependent LDS-crossbar stages per Keccak round instead of 4.  The 24-round permutation is the latency floor of every
-// sumcheck round (prover.rs:59-62 is inherently serial), so it is built for latency, not throughput.
+// row neighbours that theta and chi need are DPP row shifts.  Planes (0,1), (2,3) and (4, zeros) share 16-lane rows, so
+// theta's column parity is a same-slot XOR over half-rows, rows and wave halves: row_ror:8, then v_permlane16_swap /
+// v_permlane32_swap (gfx950) -- all VALU, with the lo and hi words sharing the swaps (the first swap leaves the lo parity
+// in the even rows and the hi parity in the odd rows of ONE register).  Only pi crosses lanes through ds_bpermute, always
+// from PRIMARY lanes, so the mirrors are rebuilt every round (slot 0 stays valid through chi; slots 6, 7 are only read by
+// chi right after pi).  Lanes 40..63 hold zeros and keep them.  The 24-round permutation is the latency floor of every
+// sumcheck round (prover.rs:59-62 is inherently serial), so it is built for latency: ~40 VALU + 2 ds_bpermute per round,
+// 2.7 us per permutation (the all-ds_bpermute version it replaced: 4.9 us; tools/mb/mb_tail.hip).
 struct LaneKeccak {
-    int lane, index;                 // index = x + 5y for primary lanes, -1 otherwise
-    int up1, up2, up3, up4, src_pi;  // byte-less lane numbers for ds_bpermute (primaries of other planes / pi source)
-    uint32_t rot;
+    int lane, index;      // index = x + 5y for primary lanes, -1 otherwise
+    int src_pi;           // lane whose rotated word lands here (pi)
+    uint32_t rot;         // rho as a right-rotate by 32*swap + rot
+    uint32_t rc_lo, rc_hi;   // lane r < 24 holds the round constant RC[r]
+    bool swap, s0, s5, act;
 };
 ZK_D uint64_t shfl64(uint64_t v, int src) {
     const uint32_t lo = __shfl((uint32_t)v, src, 64), hi = __shfl((uint32_t)(v >> 32), src, 64);
     return ((uint64_t)hi << 32) | lo;
 }
 template <int CTRL>
-ZK_D uint64_t dpp64(uint64_t v) {   // row_shl:n = 0x100 + n (lane i reads lane i+n), row_shr:n = 0x110 + n (reads lane i-n)
-    const uint32_t lo = __builtin_amdgcn_update_dpp(0u, (uint32_t)v, CTRL, 0xF, 0xF, true);
-    const uint32_t hi = __builtin_amdgcn_update_dpp(0u, (uint32_t)(v >> 32), CTRL, 0xF, 0xF, true);
-    return ((uint64_t)hi << 32) | lo;
+ZK_D uint32_t dpp32(uint32_t v) {   // row_shl:n = 0x100 + n (lane i reads lane i+n), row_shr:n = 0x110 + n, row_ror:n = 0x120 + n
+    return __builtin_amdgcn_update_dpp(0u, v, CTRL, 0xF, 0xF, true);
 }
 ZK_D int keccak_lane_of(int x, int y) { return 8 * y + x + 1; }
 ZK_D LaneKeccak lane_keccak_init() {
     // rho offsets indexed by x + 5y
     constexpr uint8_t kRho[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    constexpr uint64_t RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
     LaneKeccak L;
     const int lane = threadIdx.x & 63;
     L.lane = lane;
+    const uint64_t rc = RC[lane < 24 ? lane : 0];
+    L.rc_lo = (uint32_t)rc;
+    L.rc_hi = (uint32_t)(rc >> 32);
     const int slot = lane & 7, y = lane >> 3;
+    L.act = y < 5;
+    L.s0 = slot == 0;
+    L.s5 = slot == 5 && y < 5;
     if (y < 5) {
         const int x = slot == 0 ? 4 : (slot >= 6 ? slot - 6 : slot - 1);   // mirrors carry their primary's x
         L.index = (slot >= 1 && slot <= 5) ? x + 5 * y : -1;
-        L.up1 = keccak_lane_of(x, (y + 1) % 5);
-        L.up2 = keccak_lane_of(x, (y + 2) % 5);
-        L.up3 = keccak_lane_of(x, (y + 3) % 5);
-        L.up4 = keccak_lane_of(x, (y + 4) % 5);
         // pi: B[y'][2x'+3y'] = A[x'][y'], i.e. destination (X, Y) = (y', 2x'+3y'); for destination (x, y) the source is
         // x' = (x + 3y) mod 5, y' = x
         const int sx = (x + 3 * y) % 5, sy = x;
@@ -210,37 +222,61 @@ ZK_D LaneKeccak lane_keccak_init() {
 #pragma unroll
         for (int i = 0; i < 25; ++i)
             if (i == idx) rot = kRho[i];
-        L.rot = rot;
+        const uint32_t q = (64 - rot) & 63;   // rotl by rot == rotr by q
+        L.swap = q >= 32;
+        L.rot = q & 31;
     } else {
         L.index = -1;
-        L.up1 = L.up2 = L.up3 = L.up4 = L.src_pi = lane;
+        L.src_pi = lane;
         L.rot = 0;
+        L.swap = false;
     }
     return L;
 }
 ZK_D uint64_t lane_keccak_f1600(uint64_t a, const LaneKeccak &L) {
-    constexpr uint64_t RC[24] = {
-        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
-        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
-        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
-        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
-        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
-        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-    for (int round = 0; round < 24; ++round) {
-        // theta: column parity (every lane, mirrors included, reads the primaries of its own column) ...
-        const uint64_t c = shfl64(a, L.lane < 40 ? (L.lane & 7) == 0 ? L.lane + 5 : ((L.lane & 7) >= 6 ? L.lane - 5 : L.lane) : L.lane) ^
-                           shfl64(a, L.up1) ^ shfl64(a, L.up2) ^ shfl64(a, L.up3) ^ shfl64(a, L.up4);
-        // ... then D = C[x-1] ^ rotl(C[x+1], 1) from the row neighbours (DPP: slot s reads slots s-1 and s+1)
-        const uint64_t cm = dpp64<0x111>(c), cp = dpp64<0x101>(c);
-        a ^= cm ^ ((cp << 1) | (cp >> 63));
-        // rho (rotate my word) + pi (fetch the word that lands here, always from a primary lane)
-        const uint64_t rr = (a << L.rot) | (a >> ((64 - L.rot) & 63));
-        const uint64_t b = shfl64(rr, L.src_pi);
-        // chi + iota: row neighbours x+1, x+2 are slots s+1, s+2
-        a = b ^ (~dpp64<0x101>(b) & dpp64<0x102>(b));
-        if (L.index == 0) a ^= RC[round];
+    uint32_t lo = (uint32_t)a, hi = (uint32_t)(a >> 32);
+    {   // callers maintain the primaries only: make slot 0 (mirror of x = 4, slot 5) valid on entry
+        const uint32_t ml = dpp32<0x105>(lo), mh = dpp32<0x105>(hi);
+        lo = L.s0 ? ml : lo;
+        hi = L.s0 ? mh : hi;
     }
-    return a;
+    for (int round = 0; round < 24; ++round) {
+        // theta: same-slot XOR over the 5 planes ...
+        uint32_t cl = lo ^ dpp32<0x128>(lo), ch = hi ^ dpp32<0x128>(hi);   // planes sharing a row (row_ror:8)
+        {
+            const auto r = __builtin_amdgcn_permlane16_swap(cl, ch, false, false);
+            const uint32_t z = r[0] ^ r[1];                                 // rows: [lo01, hi01, lo23, hi23]
+            const auto s = __builtin_amdgcn_permlane32_swap(z, z, false, false);
+            const uint32_t w = s[0] ^ s[1];                                 // rows: [lo, hi, lo, hi]
+            const auto e = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+            cl = e[0];                                                      // every row: C lo / C hi
+            ch = e[1];
+        }
+        // ... then D = C[x-1] ^ rotl(C[x+1], 1): slot s reads slots s-1 and s+1, except x = 4 (slot 5), whose x+1 = 0 is slot 1
+        const uint32_t ml = dpp32<0x111>(cl), mh = dpp32<0x111>(ch);
+        uint32_t pl = dpp32<0x101>(cl), ph = dpp32<0x101>(ch);
+        const uint32_t wl = dpp32<0x114>(cl), wh = dpp32<0x114>(ch);
+        pl = L.s5 ? wl : pl;
+        ph = L.s5 ? wh : ph;
+        const uint32_t dl = ml ^ __builtin_amdgcn_alignbit(pl, ph, 31), dh = mh ^ __builtin_amdgcn_alignbit(ph, pl, 31);
+        lo ^= L.act ? dl : 0u;
+        hi ^= L.act ? dh : 0u;
+        // rho (right-rotate my word by 32*swap + rot) + pi (fetch the word that lands here, always from a primary lane)
+        const uint32_t sl = L.swap ? hi : lo, sh = L.swap ? lo : hi;
+        const uint32_t rl = __builtin_amdgcn_alignbit(sh, sl, L.rot), rh = __builtin_amdgcn_alignbit(sl, sh, L.rot);
+        const uint32_t bl = __shfl(rl, L.src_pi, 64), bh = __shfl(rh, L.src_pi, 64);
+        // chi + iota: row neighbours x+1, x+2 are slots s+1, s+2
+        lo = bl ^ (~dpp32<0x101>(bl) & dpp32<0x102>(bl));
+        hi = bh ^ (~dpp32<0x101>(bh) & dpp32<0x102>(bh));
+        // iota: the round constant sits in lane `round` of L.rc_* (a scalar load here would share lgkmcnt with the
+        // ds_bpermute above and serialise on its latency)
+        const uint32_t rcl = __builtin_amdgcn_readlane(L.rc_lo, round), rch = __builtin_amdgcn_readlane(L.rc_hi, round);
+        if (L.index == 0) {
+            lo ^= rcl;
+            hi ^= rch;
+        }
+    }
+    return ((uint64_t)hi << 32) | lo;
 }
 struct LaneSponge {   // word-cursor sponge (see WordSponge) spread over the primary lanes
     uint64_t a;
@@ -358,46 +394,34 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
                                                        WordSponge *__restrict__ sponge, uint64_t *__restrict__ out_rp,
                                                        uint64_t *__restrict__ out_ch, uint64_t *__restrict__ d_challenge,
                                                        uint64_t *__restrict__ lanes, FieldParams P) {
-    __shared__ uint32_t red[kBlock / 64][8];
     __shared__ Fe fin[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t t = 0; t < ns; ++t) {
+    const bool wave0 = __builtin_amdgcn_readfirstlane(wave) == 0;
+    // wave 0 fetches the sponge first, so that load is in flight while the partials are reduced
+    const LaneKeccak L = lane_keccak_init();
+    LaneSponge sp = {0, 0};
+    if (sponge && wave0) sp = lane_sponge_load(sponge, L);
+    // wave w owns the sums t = w, w+4, ...: lanes stride over the blocks' partials, one VALU wave reduction, one barrier
+    for (uint32_t t = wave; t < ns; t += kBlock / 64) {
         Fe s = fe_zero();
-        for (uint32_t b = threadIdx.x; b < nblocks; b += kBlock) s = fe_add(s, fe_load(partials, (uint64_t)b * ns + t), P);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            Fe o;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o.v[i] = __shfl_xor(s.v[i], off, 64);
-            s = fe_add(s, o, P);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) red[wave][i] = s.v[i];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            Fe acc;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc.v[i] = red[0][i];
-            for (int w = 1; w < kBlock / 64; ++w) {
-                Fe o;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o.v[i] = red[w][i];
-                acc = fe_add(acc, o, P);
-            }
-            fin[t] = acc;
-        }
-        __syncthreads();
+        for (uint32_t b = lane; b < nblocks; b += 64) s = fe_add(s, fe_load(partials, (uint64_t)b * ns + t), P);
+        s = fe_wave_sum(s, P);
+        if (lane == 0) fin[t] = s;
     }
-    if (threadIdx.x == 0) {
+    __syncthreads();
+    if (threadIdx.x == kBlock - 64) {   // the last wave stores the round polynomial while wave 0 runs the transcript
         for (uint32_t t = 0; t < ns; ++t) {
             if (out_rp) fe_store(out_rp, t, fin[t]);
             if (lanes)
                 for (int i = 0; i < 8; ++i) lanes[8 * t + i] = (uint64_t)fin[t].v[i];
         }
     }
-    if (sponge && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) transcript_round(sponge, fin, ns, d_challenge, out_ch, P);
+    if (sponge && wave0) {
+        Mul29 ch29;
+        const Fe ch = transcript_step(sp, L, fin, ns, P, ch29);
+        publish_challenge(d_challenge, out_ch, ch, ch29, L.lane);
+        lane_sponge_store(sponge, sp, L);
+    }
 }
 
 // ---- finisher: all remaining rounds of the prover in ONE launch, once the tables are small ---------------------------
@@ -467,15 +491,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(FactorPtrs fp, uint32_t m_in,
         // ---- workgroup reduction -> fin[] ----
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                if ((uint32_t)off < q || off < 2) {   // lanes >= q hold zero: skip empty levels (uniform condition)
-                    Fe o;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) o.v[i] = __shfl_xor(sum[t].v[i], off, 64);
-                    sum[t] = fe_add(sum[t], o, P);
-                }
-            }
+            sum[t] = fe_wave_sum(sum[t], P, q < 64 ? q : 64);   // lanes >= q hold zero: empty levels are skipped
             if (lane == 0) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) red[wave][t][i] = sum[t].v[i];

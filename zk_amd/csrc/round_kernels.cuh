@@ -12,13 +12,7 @@ ZK_D void block_reduce_store(Fe (&sum)[NS], uint64_t *__restrict__ partials, con
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            Fe o;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o.v[i] = __shfl_xor(sum[t].v[i], off, 64);
-            sum[t] = fe_add(sum[t], o, P);
-        }
+        sum[t] = fe_wave_sum(sum[t], P);
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) red[wave][t][i] = sum[t].v[i];
