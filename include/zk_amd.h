@@ -55,7 +55,8 @@ typedef enum zk_status {
     ZK_ERR_HIP = -23,           /* a HIP call failed; zk_last_hip_error() has the text */
     ZK_ERR_ALLOC = -24,
     ZK_ERR_UNSUPPORTED = -25,
-    ZK_ERR_CONTEXT_MISMATCH = -26
+    ZK_ERR_CONTEXT_MISMATCH = -26,
+    ZK_ERR_GKR_REJECT = -27     /* GKR-shaped driver: a layer's wiring check or the input-layer check failed (no reference text) */
 } zk_status;
 
 typedef struct zk_ctx zk_ctx;               /* one device + stream + scratch */
@@ -187,6 +188,44 @@ int32_t zk_ctx_device_alloc(zk_ctx *ctx, uint64_t bytes, void **out_device_ptr);
 int32_t zk_ctx_device_free(zk_ctx *ctx, void *device_ptr, uint64_t bytes);
 int32_t zk_ctx_memcpy_dtoh(zk_ctx *ctx, void *dst_host, const void *src_device, uint64_t bytes);
 int32_t zk_ctx_memcpy_htod(zk_ctx *ctx, void *dst_device, const void *src_host, uint64_t bytes);
+
+/* ---- sum of products + GKR-shaped driver (NO reference crate; formats are this library's) ----
+ * The reference's building block for GKR is prove_partial / verify_partial (sumcheck/src/prover.rs:24-30,
+ * sumcheck/src/verifier.rs:38-41; intent: polynomial/src/multilinear/evaluation_form.rs:45-48).  A GKR layer polynomial is a
+ * SUM of products of MLEs, so prove_partial is offered on sum_i prod_{f in term i} T_f: factors listed flat, term after
+ * term, term_k[i] factors in term i (each <= max_var_degree, <= 4 terms, <= 8 factors in all, no table listed twice).
+ * Round polynomials, transcript and challenges are exactly prove_partial's (one term == zk_sumcheck_prove with
+ * absorb_table = 0).  out_final (optional, k*4 u64): every factor evaluated at the challenge point, i.e. the fold after
+ * the last round that the reference computes and drops (prover.rs:64). */
+int32_t zk_sumcheck_prove_terms(zk_ctx *ctx, zk_mle *const *factors, const uint64_t *term_k, uint64_t n_terms,
+                                uint32_t max_var_degree, const uint64_t sum[4], int32_t consume,
+                                uint64_t *out_round_polys, uint64_t *out_challenges, uint64_t *out_final);
+/* eq(point, .) as a table: out[idx] = prod_v (bit_v(idx) ? point[v] : 1 - point[v]), variable 0 = index MSB */
+int32_t zk_eq_table(zk_ctx *ctx, const uint64_t *point, uint64_t n_vars, zk_mle **out);
+
+/* Layered arithmetic circuit, fan-in 2.  Layers are appended from the OUTPUT layer (0) towards the inputs; layer i has
+ * 2^log_out gates over the 2^log_in values of layer i+1 (log_in of layer i == log_out of layer i+1; the last layer reads the
+ * input table).  Gate z = (op[z], left[z], right[z]), op 0 = add, 1 = mul; indices follow the MLE convention
+ * (variable 0 = index MSB).  1 <= log_in <= 30. */
+typedef struct zk_circuit zk_circuit;
+int32_t zk_circuit_create(zk_ctx *ctx, zk_circuit **out);
+int32_t zk_circuit_add_layer(zk_circuit *c, uint64_t log_out, uint64_t log_in, const uint8_t *op, const uint32_t *left,
+                             const uint32_t *right);
+int32_t zk_circuit_free(zk_circuit *c);
+int32_t zk_circuit_depth(const zk_circuit *c, uint64_t *out);
+int32_t zk_circuit_layer_dims(const zk_circuit *c, uint64_t layer, uint64_t *out_log_out, uint64_t *out_log_in);
+int32_t zk_circuit_proof_elems(const zk_circuit *c, uint64_t *out);   /* sum over layers of 6*log_in + 2 */
+/* evaluate the circuit on the device: new table of 2^log_out(0) outputs */
+int32_t zk_gkr_evaluate(const zk_circuit *c, const zk_mle *input, zk_mle **out_outputs);
+/* GKR prover: per layer two prove_partial calls (Libra's phase 1 over x, phase 2 over y), chained by their sub-claims;
+ * seed = 32 bytes binding the statement (the caller's digest of circuit / inputs / outputs), absorbed first by the
+ * driver's transcript (Transcript semantics of transcript/src/lib.rs).  out_proof: zk_circuit_proof_elems elements,
+ * per layer [round polys #1 (log_in*3) | round polys #2 (log_in*3) | W(u) | W(v)].  Returns the outputs table. */
+int32_t zk_gkr_prove(const zk_circuit *c, const zk_mle *input, const uint8_t seed[32], zk_mle **out_outputs,
+                     uint64_t *out_proof);
+/* ZK_OK = accept; ZK_ERR_VERIFY_SUM = a sumcheck round check failed; ZK_ERR_GKR_REJECT = wiring / input check failed */
+int32_t zk_gkr_verify(const zk_circuit *c, const zk_mle *input, const zk_mle *outputs, const uint8_t seed[32],
+                      const uint64_t *proof);
 
 /* ---- SumcheckVerifier  (sumcheck/src/verifier.rs) -- host-side protocol logic; oracle check on device ------------ */
 /* ::verify_partial :38-41 -> SubClaim{sum, challenges} */

@@ -1,0 +1,176 @@
+"""gkr_ref.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE: an independent big-int model of the GKR-shaped driver.
+
+The reference has no gkr crate, so there is nothing of the reference's to restate for the
+layered protocol itself: the circuit format, transcript schedule and proof layout are zk_amd's own (DESIGN.md section
+10) and this file is the *definition* the HIP path is checked against ("parity definitional, unpinned").  What it does
+take from the reference, through oracle/pyref.py, are the pieces the protocol is built from: the MLE fold and variable
+order (evaluation_form.rs:40-80), the prove_partial round loop (sumcheck/src/prover.rs:33-73) generalised from one
+product to a sum of products, verify_partial (sumcheck/src/verifier.rs:44-78) and the Keccak transcript
+(transcript/src/lib.rs:10-30).  Plain Python integers, naive sums over gates: small circuits only.
+"""
+from . import pyref
+
+ADD, MUL = 0, 1
+
+
+def eq_table(field, point):
+    """eq(point, .) with variable 0 = index MSB."""
+    p = pyref.modulus(field)
+    t = [1]
+    for g in point:
+        t = [v * f % p for v in t for f in ((1 - g) % p, g % p)]
+    return t
+
+
+def _fold(field, table, r):
+    p = pyref.modulus(field)
+    h = len(table) // 2
+    return [(table[j] - r * (table[j] - table[j + h])) % p for j in range(h)]
+
+
+def prove_partial_terms(field, terms, D, claimed_sum):
+    """prove_partial (prover.rs:24-30, :33-73) on sum_i prod_{f in terms[i]} table_f.  terms: list of lists of tables
+    (lists of ints).  Returns (round_polys, challenges, finals) with finals = every factor at the challenge point."""
+    p = pyref.modulus(field)
+    tr = pyref.Transcript()
+    tr.append((claimed_sum % p).to_bytes(32, "big"))
+    terms = [[list(t) for t in term] for term in terms]
+    n = len(terms[0][0]).bit_length() - 1
+    round_polys, challenges = [], []
+    for _ in range(n):
+        rp = []
+        for t in range(D + 1):
+            total = 0
+            for term in terms:
+                folded = [_fold(field, tab, t % p) for tab in term]
+                for j in range(len(folded[0])):
+                    prod = 1
+                    for tab in folded:
+                        prod = prod * tab[j] % p
+                    total += prod
+            rp.append(total % p)
+        tr.append(b"".join(v.to_bytes(32, "big") for v in rp))
+        c = tr.sample_field_element(field)
+        terms = [[_fold(field, tab, c) for tab in term] for term in terms]
+        round_polys.append(rp)
+        challenges.append(c)
+    finals = [tab[0] for term in terms for tab in term]
+    return round_polys, challenges, finals
+
+
+def evaluate_circuit(field, layers, inputs):
+    """layers[0] = output layer; each layer = (log_out, log_in, op[], left[], right[]).  -> values of every layer."""
+    p = pyref.modulus(field)
+    vals = [None] * (len(layers) + 1)
+    vals[len(layers)] = [v % p for v in inputs]
+    for i in range(len(layers) - 1, -1, -1):
+        _, _, op, left, right = layers[i]
+        w = vals[i + 1]
+        vals[i] = [(w[x] * w[y] if o == MUL else w[x] + w[y]) % p for o, x, y in zip(op, left, right)]
+    return vals
+
+
+def _mle_eval(field, table, point):
+    for r in point:
+        table = _fold(field, table, r)
+    return table[0]
+
+
+def _start(field, seed, log_out0):
+    tr = pyref.Transcript()
+    tr.append(bytes(seed))
+    g = [tr.sample_field_element(field) for _ in range(log_out0)]
+    return tr, g
+
+
+def _E(field, claim, log_out):
+    p = pyref.modulus(field)
+    e1 = eq_table(field, claim["g1"])
+    if claim["g2"] is None:
+        return [claim["alpha"] * a % p for a in e1]
+    e2 = eq_table(field, claim["g2"])
+    return [(claim["alpha"] * a + claim["beta"] * b) % p for a, b in zip(e1, e2)]
+
+
+def _next_claim(field, tr, layer_proof, u, v):
+    p = pyref.modulus(field)
+    tr.append(b"".join(x.to_bytes(32, "big") for x in layer_proof))
+    alpha = tr.sample_field_element(field)
+    beta = tr.sample_field_element(field)
+    wu, wv = layer_proof[-2], layer_proof[-1]
+    return {"g1": u, "g2": v, "alpha": alpha, "beta": beta, "c": (alpha * wu + beta * wv) % p}
+
+
+def gkr_prove(field, layers, inputs, seed):
+    """-> (outputs, proof) with proof a flat list of ints, per layer [rp1 (log_in*3) | rp2 (log_in*3) | W(u) | W(v)]."""
+    p = pyref.modulus(field)
+    vals = evaluate_circuit(field, layers, inputs)
+    tr, g = _start(field, seed, layers[0][0])
+    claim = {"g1": g, "g2": None, "alpha": 1, "beta": 0, "c": _mle_eval(field, vals[0], g)}
+    proof = []
+    for i, (log_out, log_in, op, left, right) in enumerate(layers):
+        W = vals[i + 1]
+        n_in = 1 << log_in
+        E = _E(field, claim, log_out)
+        H, B1 = [0] * n_in, [0] * n_in
+        for z, (o, x, y) in enumerate(zip(op, left, right)):
+            if o == MUL:
+                H[x] = (H[x] + E[z] * W[y]) % p
+            else:
+                H[x] = (H[x] + E[z]) % p
+                B1[x] = (B1[x] + E[z] * W[y]) % p
+        rp1, u, fin1 = prove_partial_terms(field, [[W, H], [B1]], 2, claim["c"])
+        wu = fin1[0]
+        sub1 = (fin1[0] * fin1[1] + fin1[2]) % p
+        equ = eq_table(field, u)
+        A2, M2 = [0] * n_in, [0] * n_in
+        for z, (o, x, y) in enumerate(zip(op, left, right)):
+            t = E[z] * equ[x] % p
+            if o == MUL:
+                M2[y] = (M2[y] + t) % p
+            else:
+                A2[y] = (A2[y] + t) % p
+        H2 = [(a + wu * m) % p for a, m in zip(A2, M2)]
+        C2 = [wu * a % p for a in A2]
+        rp2, v, fin2 = prove_partial_terms(field, [[W, H2], [C2]], 2, sub1)
+        wv = fin2[0]
+        layer_proof = [x for rp in rp1 for x in rp] + [x for rp in rp2 for x in rp] + [wu, wv]
+        proof += layer_proof
+        claim = _next_claim(field, tr, layer_proof, u, v)
+    return vals[0], proof
+
+
+def gkr_verify(field, layers, inputs, outputs, seed, proof):
+    """True = accept.  Independent of the prover above except for the shared transcript schedule."""
+    p = pyref.modulus(field)
+    tr, g = _start(field, seed, layers[0][0])
+    claim = {"g1": g, "g2": None, "alpha": 1, "beta": 0, "c": _mle_eval(field, [o % p for o in outputs], g)}
+    pos = 0
+    u = v = None
+    wu = wv = None
+    for log_out, log_in, op, left, right in layers:
+        s = log_in
+        layer_proof = proof[pos:pos + 6 * s + 2]
+        pos += 6 * s + 2
+        rp1 = [layer_proof[3 * r:3 * r + 3] for r in range(s)]
+        rp2 = [layer_proof[3 * s + 3 * r:3 * s + 3 * r + 3] for r in range(s)]
+        wu, wv = layer_proof[-2], layer_proof[-1]
+        try:
+            sub1, u = pyref.sumcheck_verify_partial(field, claim["c"], rp1)
+            sub2, v = pyref.sumcheck_verify_partial(field, sub1, rp2)
+        except ValueError:
+            return False
+        E = _E(field, claim, log_out)
+        equ, eqv = eq_table(field, u), eq_table(field, v)
+        add_e = mul_e = 0
+        for z, (o, x, y) in enumerate(zip(op, left, right)):
+            t = E[z] * equ[x] % p * eqv[y] % p
+            if o == MUL:
+                mul_e = (mul_e + t) % p
+            else:
+                add_e = (add_e + t) % p
+        if sub2 != (add_e * (wu + wv) + mul_e * wu * wv) % p:
+            return False
+        claim = _next_claim(field, tr, layer_proof, u, v)
+    ins = [x % p for x in inputs]
+    return wu == _mle_eval(field, ins, u) and wv == _mle_eval(field, ins, v)

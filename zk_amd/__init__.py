@@ -4,3 +4,4 @@
 (libzk_amd.so: hand-written HIP kernels + host protocol logic).  No CPU fallback exists.
 """
 from .api import *  # noqa: F401,F403
+from . import gkr  # noqa: F401,E402

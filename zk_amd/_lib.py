@@ -121,6 +121,17 @@ _sig = {
     "zk_ctx_memcpy_htod": [c.c_void_p, c.c_void_p, c.c_void_p, c.c_uint64],
     "zk_sumcheck_verify_partial": [c.c_int32, c.c_uint64, c.c_uint32, u64p, u64p, u64p, u64p],
     "zk_sumcheck_verify": [c.c_void_p, vpp, c.c_uint64, c.c_uint64, c.c_uint32, u64p, u64p, c.POINTER(c.c_int32)],
+    "zk_sumcheck_prove_terms": [c.c_void_p, vpp, u64p, c.c_uint64, c.c_uint32, u64p, c.c_int32, u64p, u64p, u64p],
+    "zk_eq_table": [c.c_void_p, u64p, c.c_uint64, vpp],
+    "zk_circuit_create": [c.c_void_p, vpp],
+    "zk_circuit_add_layer": [c.c_void_p, c.c_uint64, c.c_uint64, u8p, c.POINTER(c.c_uint32), c.POINTER(c.c_uint32)],
+    "zk_circuit_free": [c.c_void_p],
+    "zk_circuit_depth": [c.c_void_p, u64p],
+    "zk_circuit_layer_dims": [c.c_void_p, c.c_uint64, u64p, u64p],
+    "zk_circuit_proof_elems": [c.c_void_p, u64p],
+    "zk_gkr_evaluate": [c.c_void_p, c.c_void_p, vpp],
+    "zk_gkr_prove": [c.c_void_p, c.c_void_p, u8p, vpp, u64p],
+    "zk_gkr_verify": [c.c_void_p, c.c_void_p, c.c_void_p, u8p, u64p],
     "zk_ntt": [c.c_void_p, c.c_void_p, c.c_int32, c.c_void_p],
     "zk_fft_host": [c.c_void_p, u64p, c.c_uint64, u64p],
     "zk_ifft_host": [c.c_void_p, u64p, c.c_uint64, u64p],

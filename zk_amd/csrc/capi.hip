@@ -15,6 +15,7 @@
 #include "../../include/zk_amd.h"
 #include "host_field.hpp"
 #include "kernels.cuh"
+#include "gkr_kernels.cuh"
 #include "launch.hpp"
 #include "ntt_kernels.cuh"
 #include "keccak.hpp"
@@ -139,6 +140,7 @@ extern "C" const char *zk_strerror(int32_t s) {
         case ZK_ERR_ALLOC: return "allocation failed";
         case ZK_ERR_UNSUPPORTED: return "unsupported configuration";
         case ZK_ERR_CONTEXT_MISMATCH: return "handle belongs to a different context";
+        case ZK_ERR_GKR_REJECT: return "gkr verifier check failed: layer wiring / input claim mismatch";
         default: return "unknown status";
     }
 }
@@ -665,23 +667,50 @@ struct TailTargets {
     uint64_t *d_challenge;  // challenge for the next fused fold
     uint64_t *lanes;        // 32-bit digit lanes for the cross-GPU all-reduce, may be null
 };
-// sums of the current tables (already folded) -> targets.  Handles every degree.
-static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused, const uint64_t *d_r,
-                           const TailTargets &tt) {
+// A sum of products sum_i prod_{f in term i} T_f: the factors are listed flat, term after term.
+constexpr int kMaxTerms = 4;
+struct TermSpec {
+    int n_terms;
+    int term_k[kMaxTerms];
+};
+static inline TermSpec single_term(int k) {
+    TermSpec ts = {1, {k, 0, 0, 0}};
+    return ts;
+}
+// sums of the current tables (already folded) -> targets.  Handles every degree.  With several terms each term's round
+// kernel writes its own range of block partials and the one tail reduction adds them all (the sum over terms is free).
+static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, uint64_t q, uint32_t D, bool fused,
+                           const uint64_t *d_r, const TailTargets &tt) {
     const FieldParams &P = c->fi->P;
     if (fast_degree(D)) {
-        uint32_t g = 0;
-        const int lrc = launch_round(launch_ctx(c), fp, k, q, D, fused, d_r, &g);
-        if (lrc == kLaunchUnsupported) return ZK_ERR_UNSUPPORTED;
-        if (lrc != kLaunchOk) {
-            g_hip_err = "round kernel launch failed";
-            return ZK_ERR_HIP;
+        uint32_t total = 0;
+        int first = 0;
+        for (int i = 0; i < ts.n_terms; ++i) {
+            FactorPtrs sub = {};
+            for (int f = 0; f < ts.term_k[i]; ++f) {
+                sub.in[f] = fp.in[first + f];
+                sub.out[f] = fp.out[first + f];
+            }
+            RoundLaunchCtx lc = launch_ctx(c);
+            lc.d_partials += (size_t)total * (D + 1) * 4;
+            lc.capacity_elems -= (uint64_t)total * (D + 1);
+            uint32_t g = 0;
+            const int lrc = launch_round(lc, sub, ts.term_k[i], q, D, fused, d_r, &g);
+            if (lrc == kLaunchUnsupported) return ZK_ERR_UNSUPPORTED;
+            if (lrc != kLaunchOk) {
+                g_hip_err = "round kernel launch failed";
+                return ZK_ERR_HIP;
+            }
+            total += g;
+            first += ts.term_k[i];
         }
-        k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, g, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
+        k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, total, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
                                                   tt.lanes, P);
         HIPCHK(hipGetLastError());
         return ZK_OK;
     }
+    if (ts.n_terms != 1) return ZK_ERR_UNSUPPORTED;
+    const int k = ts.term_k[0];
     // any other degree (0, or > 4): one pass per evaluation point over tables that are already folded
     for (uint32_t t = 0; t <= D; ++t) {
         uint32_t g = 0;
@@ -707,7 +736,7 @@ extern "C" int32_t zk_round_sums(zk_ctx *c, const zk_mle *const *f, uint64_t k, 
     const uint64_t q = 1ull << (f[0]->n_vars - 1);
     uint64_t *d_out = c->d_sums + 4 * kMaxSums;   // second third of d_sums
     TailTargets tt = {nullptr, d_out, nullptr, nullptr, nullptr};
-    ZKCHK(launch_sums(c, fp, (int)k, q, D, false, nullptr, tt));
+    ZKCHK(launch_sums(c, fp, single_term((int)k), q, D, false, nullptr, tt));
     HIPCHK(hipMemcpyAsync(out, d_out, (size_t)(D + 1) * 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return ZK_OK;
@@ -808,6 +837,8 @@ struct RoundState {
     uint64_t *scratch[kMaxFactors];   // owned tables
     size_t scratch_bytes[kMaxFactors];
     ProverScratch ps;
+    TermSpec terms;                   // how the k flat factors group into products (one term = ProductPoly)
+    uint64_t *d_final;                // optional (owned): k elements, the factors at the challenge point
 };
 static void round_state_release(RoundState &st) {
     for (uint64_t i = 0; i < (uint64_t)kMaxFactors; ++i)
@@ -815,6 +846,10 @@ static void round_state_release(RoundState &st) {
             pool_free(st.c, st.scratch[i], st.scratch_bytes[i]);
             st.scratch[i] = nullptr;
         }
+    if (st.d_final) {
+        pool_free(st.c, st.d_final, kMaxFactors * 32);
+        st.d_final = nullptr;
+    }
     scratch_free(st.c, st.ps);
 }
 static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uint64_t k, uint32_t D, bool consume,
@@ -827,6 +862,8 @@ static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uin
     st.pending_fold = false;
     st.first_out_of_place = !consume;
     st.ps = {};
+    st.terms = single_term((int)k);
+    st.d_final = nullptr;
     for (uint64_t i = 0; i < (uint64_t)kMaxFactors; ++i) {
         st.cur[i] = i < k ? f[i]->d : nullptr;
         st.scratch[i] = nullptr;
@@ -872,9 +909,9 @@ static int32_t round_enqueue(RoundState &st, uint64_t *lanes) {
         }
         FactorPtrs g = {};
         for (uint64_t i = 0; i < st.k; ++i) g.in[i] = fp.out[i];
-        if (rc == ZK_OK) rc = launch_sums(c, g, (int)st.k, q, st.D, false, nullptr, tt);
+        if (rc == ZK_OK) rc = launch_sums(c, g, st.terms, q, st.D, false, nullptr, tt);
     } else {
-        rc = launch_sums(c, fp, (int)st.k, q, st.D, st.pending_fold, st.ps.d_challenge, tt);
+        rc = launch_sums(c, fp, st.terms, q, st.D, st.pending_fold, st.ps.d_challenge, tt);
     }
     if (st.pending_fold) {
         for (uint64_t i = 0; i < st.k; ++i) st.cur[i] = fp.out[i];
@@ -887,11 +924,11 @@ static int32_t round_enqueue(RoundState &st, uint64_t *lanes) {
 // ---- finisher: every remaining round in one single-workgroup launch (k_finish) ----
 template <int K, int D>
 static int32_t launch_finish(zk_ctx *c, const FactorPtrs &fp, uint32_t m_in, int pending, uint64_t *d_challenge, WordSponge *sp,
-                             uint64_t *out_rp, uint64_t *out_ch) {
+                             uint64_t *out_rp, uint64_t *out_ch, uint64_t *out_final) {
     const uint32_t m = pending ? m_in - 1 : m_in;
     const size_t lds = (size_t)K * ((size_t)32 << m) + (kBlock / 64) * (D + 1) * 32 + (D + 1) * 32 + 48;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_finish<K, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_finish<K, D><<<1, kBlock, lds, c->stream>>>(fp, m_in, pending, c->fi->P, d_challenge, sp, out_rp, out_ch);
+    k_finish<K, D><<<1, kBlock, lds, c->stream>>>(fp, m_in, pending, c->fi->P, d_challenge, sp, out_rp, out_ch, out_final);
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
@@ -910,13 +947,13 @@ static int32_t finish_enqueue(RoundState &st) {
     uint64_t *out_rp = st.ps.d_rp + st.round * (st.D + 1) * 4, *out_ch = st.ps.d_ch + st.round * 4;
     int32_t rc = ZK_ERR_UNSUPPORTED;
     switch ((int)st.k * 10 + (int)st.D) {
-        case 11: rc = launch_finish<1, 1>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch); break;
-        case 12: rc = launch_finish<1, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch); break;
-        case 21: rc = launch_finish<2, 1>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch); break;
-        case 22: rc = launch_finish<2, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch); break;
-        case 23: rc = launch_finish<2, 3>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch); break;
-        case 32: rc = launch_finish<3, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch); break;
-        case 33: rc = launch_finish<3, 3>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch); break;
+        case 11: rc = launch_finish<1, 1>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+        case 12: rc = launch_finish<1, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+        case 21: rc = launch_finish<2, 1>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+        case 22: rc = launch_finish<2, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+        case 23: rc = launch_finish<2, 3>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+        case 32: rc = launch_finish<3, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+        case 33: rc = launch_finish<3, 3>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
         default: break;
     }
     if (rc == ZK_OK) {
@@ -927,7 +964,7 @@ static int32_t finish_enqueue(RoundState &st) {
     return rc;
 }
 static inline bool finish_applies(const RoundState &st) {
-    if (!finish_shape_ok(st.k, st.D)) return false;
+    if (st.terms.n_terms != 1 || !finish_shape_ok(st.k, st.D)) return false;
     const uint64_t after = st.pending_fold ? st.vars_left - 1 : st.vars_left;
     return after >= 1 && after <= (uint64_t)kFinishVars;
 }
@@ -941,8 +978,10 @@ static int32_t sponge_to_device(zk_ctx *c, const Sponge &host, WordSponge *d_spo
     return ZK_OK;
 }
 
-extern "C" int32_t zk_sumcheck_prove(zk_ctx *c, zk_mle *const *f, uint64_t k, uint32_t D, const uint64_t sum[4],
-                                     int32_t absorb_table, int32_t consume, uint64_t *out_rp, uint64_t *out_ch) {
+// The prover for sum_i prod_{f in term i} T_f (one term = the reference's ProductPoly).  out_final (optional): the k
+// factors evaluated at the challenge point.
+static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpec &ts, uint32_t D, const uint64_t sum[4],
+                          int32_t absorb_table, int32_t consume, uint64_t *out_rp, uint64_t *out_ch, uint64_t *out_final) {
     if (!sum) return ZK_ERR_BAD_ARG;
     ZKCHK(product_args(c, (const zk_mle *const *)f, k));
     if (f[0]->n_vars && (!out_rp || !out_ch)) return ZK_ERR_BAD_ARG;
@@ -953,19 +992,38 @@ extern "C" int32_t zk_sumcheck_prove(zk_ctx *c, zk_mle *const *f, uint64_t k, ui
     sp.init();                                                           // Transcript::new (prover.rs:16,28)
     if (absorb_table) ZKCHK(absorb_tables(c, sp, f, k));                 // prover.rs:17
     absorb_elements(sp, sum, 1, P);                                      // prover.rs:42
-    if (n == 0) return ZK_OK;                                            // no rounds (prover.rs:44)
+    if (n == 0) {                                                        // no rounds (prover.rs:44)
+        if (out_final)
+            for (uint64_t i = 0; i < k; ++i) ZKCHK(zk_mle_download(c, f[i], out_final + 4 * i));
+        return ZK_OK;
+    }
     RoundState st;
     ZKCHK(round_state_init(st, c, f, k, D, consume != 0, n));
-    int32_t rc = sponge_to_device(c, sp, st.ps.d_sponge);
+    st.terms = ts;
+    int32_t rc = ZK_OK;
+    if (out_final) rc = pool_alloc(c, kMaxFactors * 32, (void **)&st.d_final);
+    if (rc == ZK_OK) rc = sponge_to_device(c, sp, st.ps.d_sponge);
+    bool finished_in_kernel = false;
     while (st.round < n && rc == ZK_OK) {                                // prover.rs:44-68, all on device
         if (finish_applies(st)) {
             rc = finish_enqueue(st);                                     // all remaining rounds in one launch
+            finished_in_kernel = true;
         } else {
             rc = round_enqueue(st, nullptr);
             ++st.round;
         }
     }
-    // prover.rs:64 after the LAST round folds to a 0-variable polynomial the reference drops: not computed.
+    // prover.rs:64 after the LAST round folds to a 0-variable polynomial the reference drops: computed only on request.
+    if (rc == ZK_OK && out_final) {
+        if (!finished_in_kernel) {
+            FactorPtrs fp = {};
+            for (uint64_t i = 0; i < k; ++i) fp.in[i] = st.cur[i];
+            k_final_evals<<<1, 64, 0, c->stream>>>(fp, (uint32_t)k, st.ps.d_challenge, st.d_final, P);
+            if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+        }
+        if (rc == ZK_OK && hipMemcpyAsync(out_final, st.d_final, (size_t)k * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+            rc = ZK_ERR_HIP;
+    }
     if (rc == ZK_OK) {
         if (hipMemcpyAsync(out_rp, st.ps.d_rp, (size_t)n * (D + 1) * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipMemcpyAsync(out_ch, st.ps.d_ch, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
@@ -977,6 +1035,37 @@ extern "C" int32_t zk_sumcheck_prove(zk_ctx *c, zk_mle *const *f, uint64_t k, ui
     }
     round_state_release(st);
     return rc;
+}
+
+extern "C" int32_t zk_sumcheck_prove(zk_ctx *c, zk_mle *const *f, uint64_t k, uint32_t D, const uint64_t sum[4],
+                                     int32_t absorb_table, int32_t consume, uint64_t *out_rp, uint64_t *out_ch) {
+    if (k == 0 || k > (uint64_t)kMaxFactors) return product_args(c, (const zk_mle *const *)f, k);
+    return prove_core(c, f, k, single_term((int)k), D, sum, absorb_table, consume, out_rp, out_ch, nullptr);
+}
+
+// prove_partial for a SUM of products (what a GKR layer needs): factors flat, term_k[i] factors per term.
+// Tables must not be shared between terms (each is folded by the term that lists it).
+extern "C" int32_t zk_sumcheck_prove_terms(zk_ctx *c, zk_mle *const *f, const uint64_t *term_k, uint64_t n_terms, uint32_t D,
+                                           const uint64_t sum[4], int32_t consume, uint64_t *out_rp, uint64_t *out_ch,
+                                           uint64_t *out_final) {
+    if (!c || !f || !term_k) return ZK_ERR_BAD_ARG;
+    if (n_terms == 0) return ZK_ERR_EMPTY_PRODUCT;
+    if (n_terms > (uint64_t)kMaxTerms) return ZK_ERR_UNSUPPORTED;
+    TermSpec ts = {};
+    ts.n_terms = (int)n_terms;
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < n_terms; ++i) {
+        if (term_k[i] == 0) return ZK_ERR_EMPTY_PRODUCT;
+        if (term_k[i] > (uint64_t)kMaxFactors || term_k[i] > D) return ZK_ERR_UNSUPPORTED;   // a term of k factors has degree k
+        ts.term_k[i] = (int)term_k[i];
+        k += term_k[i];
+    }
+    if (k > (uint64_t)kMaxFactors) return ZK_ERR_UNSUPPORTED;
+    for (uint64_t i = 0; i < k; ++i)
+        for (uint64_t j = i + 1; j < k; ++j)
+            if (f[i] && f[i] == f[j]) return ZK_ERR_BAD_ARG;
+    if (n_terms > 1 && !fast_degree(D)) return ZK_ERR_UNSUPPORTED;
+    return prove_core(c, f, k, ts, D, sum, 0, consume, out_rp, out_ch, out_final);
 }
 
 extern "C" int32_t zk_sumcheck_prove_host(zk_ctx *c, const uint64_t *const *tables, uint64_t k, uint64_t n_vars, uint32_t D,
@@ -1544,3 +1633,5 @@ extern "C" int32_t zk_bench_copy(zk_ctx *c, uint64_t bytes, int32_t reps, double
     *out_gbps = 2.0 * (double)n16 * 16.0 * reps / (ms * 1e-3) / 1e9;
     return ZK_OK;
 }
+
+#include "gkr_host.inc"

@@ -1,0 +1,152 @@
+// gkr_kernels.cuh -- device side of the GKR-shaped driver (the reference has NO gkr crate, so there is no
+// reference file to cite; the building block it would call is prove_partial, sumcheck/src/prover.rs:24-30, whose intent
+// for GKR is noted at polynomial/src/multilinear/evaluation_form.rs:45-48).  Protocol and formats are ours: DESIGN.md 10.
+//
+// A layer is 2^s_out fan-in-2 gates over the 2^s_in values of the layer below: gate z = (op, left x, right y),
+// op 0 = add, 1 = mul.  All tables use the MLE index convention of the reference (variable 0 = index MSB).
+// Bookkeeping tables for the two-phase (Libra-style) layer sumcheck, E = alpha*eq(g1,.) + beta*eq(g2,.):
+//   phase 1 (over x):  H [x] = sum_{add (z,x,y)} E[z] + sum_{mul (z,x,y)} E[z]*W[y],   B1[x] = sum_{add (z,x,y)} E[z]*W[y]
+//                      layer polynomial  P1(x) = W(x)*H(x) + B1(x)
+//   phase 2 (over y):  A2[y] = sum_{add (z,x,y)} E[z]*eq_u[x],  M2[y] = sum_{mul (z,x,y)} E[z]*eq_u[x]
+//                      H2 = A2 + W(u)*M2,  C2 = W(u)*A2,   P2(y) = W(y)*H2(y) + C2(y)
+// Rows are walked through a CSR index of the gate list (by left input / by right input) built once at upload: no
+// atomics on 256-bit values, one thread per row.
+#pragma once
+#include "common.cuh"
+
+namespace zk {
+
+// eq(point, .) over nv variables by direct products (small tables only: nv muls per entry):
+// out[j] = scale * prod_w (bit_{nv-1-w}(j) ? g_w : 1 - g_w), scale = *d_scale or 1
+__global__ __launch_bounds__(kBlock) void k_eq_direct(const uint64_t *__restrict__ point, uint32_t nv,
+                                                      const uint64_t *__restrict__ d_scale, uint64_t *__restrict__ out,
+                                                      FieldParams P) {
+    const uint64_t n = 1ull << nv, stride = (uint64_t)gridDim.x * kBlock;
+    Fe one;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        Fe acc = d_scale ? fe_load(d_scale, 0) : one;
+        for (uint32_t w = 0; w < nv; ++w) {
+            const Fe g = fe_load(point, w);
+            const bool bit = (j >> (nv - 1 - w)) & 1;
+            acc = fe_mul(acc, bit ? g : fe_sub(one, g, P), P);
+        }
+        fe_store(out, j, acc);
+    }
+}
+// out[idx] (+)= hi[idx >> lo_bits] * lo[idx & mask]: the full table as the outer product of its two halves
+template <bool ACCUMULATE>
+__global__ __launch_bounds__(kBlock) void k_eq_outer(const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo,
+                                                     uint32_t lo_bits, uint64_t n, uint64_t *__restrict__ out, FieldParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock, mask = (1ull << lo_bits) - 1;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        Fe v = fe_mul(fe_load(hi, j >> lo_bits), fe_load(lo, j & mask), P);
+        if (ACCUMULATE) v = fe_add(v, fe_load(out, j), P);
+        fe_store(out, j, v);
+    }
+}
+
+// layer evaluation: out[z] = W[left[z]] (+|*) W[right[z]]
+__global__ __launch_bounds__(kBlock) void k_gkr_forward(const uint8_t *__restrict__ op, const uint32_t *__restrict__ left,
+                                                        const uint32_t *__restrict__ right, const uint64_t *__restrict__ W,
+                                                        uint64_t n_gates, uint64_t *__restrict__ out, FieldParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t z = (uint64_t)blockIdx.x * kBlock + threadIdx.x; z < n_gates; z += stride) {
+        const Fe a = fe_load(W, left[z]), b = fe_load(W, right[z]);
+        fe_store(out, z, op[z] ? fe_mul(a, b, P) : fe_add(a, b, P));
+    }
+}
+
+// phase 1 bookkeeping: one thread per x (row of the by-left CSR)
+__global__ __launch_bounds__(kBlock) void k_gkr_phase1(const uint32_t *__restrict__ lptr, const uint32_t *__restrict__ lperm,
+                                                       const uint8_t *__restrict__ op, const uint32_t *__restrict__ right,
+                                                       const uint64_t *__restrict__ E, const uint64_t *__restrict__ W,
+                                                       uint64_t n_in, uint64_t *__restrict__ H, uint64_t *__restrict__ B1,
+                                                       FieldParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < n_in; x += stride) {
+        Fe h = fe_zero(), b = fe_zero();
+        for (uint32_t e = lptr[x]; e < lptr[x + 1]; ++e) {
+            const uint32_t z = lperm[e];
+            const Fe ez = fe_load(E, z), t = fe_mul(ez, fe_load(W, right[z]), P);
+            if (op[z]) {
+                h = fe_add(h, t, P);
+            } else {
+                h = fe_add(h, ez, P);
+                b = fe_add(b, t, P);
+            }
+        }
+        fe_store(H, x, h);
+        fe_store(B1, x, b);
+    }
+}
+// phase 2 bookkeeping: one thread per y (row of the by-right CSR); wu = W(u), one device element
+__global__ __launch_bounds__(kBlock) void k_gkr_phase2(const uint32_t *__restrict__ rptr, const uint32_t *__restrict__ rperm,
+                                                       const uint8_t *__restrict__ op, const uint32_t *__restrict__ left,
+                                                       const uint64_t *__restrict__ E, const uint64_t *__restrict__ eq_u,
+                                                       const uint64_t *__restrict__ wu, uint64_t n_in,
+                                                       uint64_t *__restrict__ H2, uint64_t *__restrict__ C2, FieldParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const Fe w = fe_load(wu, 0);
+    for (uint64_t y = (uint64_t)blockIdx.x * kBlock + threadIdx.x; y < n_in; y += stride) {
+        Fe a = fe_zero(), m = fe_zero();
+        for (uint32_t e = rptr[y]; e < rptr[y + 1]; ++e) {
+            const uint32_t z = rperm[e];
+            const Fe t = fe_mul(fe_load(E, z), fe_load(eq_u, left[z]), P);
+            if (op[z]) m = fe_add(m, t, P);
+            else a = fe_add(a, t, P);
+        }
+        fe_store(H2, y, fe_add(a, fe_mul(w, m, P), P));
+        fe_store(C2, y, fe_mul(w, a, P));
+    }
+}
+
+// verifier side: the wiring predicates of one layer at (u, v),
+//   add~E(u,v) = sum_{add (z,x,y)} E[z]*eq_u[x]*eq_v[y],  mul~E(u,v) = the same over mul gates
+// -> per-block partials [block][2] (reduced by k_round_tail with ns = 2)
+__global__ __launch_bounds__(kBlock) void k_gkr_wiring_eval(const uint8_t *__restrict__ op, const uint32_t *__restrict__ left,
+                                                            const uint32_t *__restrict__ right, const uint64_t *__restrict__ E,
+                                                            const uint64_t *__restrict__ eq_u, const uint64_t *__restrict__ eq_v,
+                                                            uint64_t n_gates, uint64_t *__restrict__ partials, FieldParams P) {
+    __shared__ uint32_t red[kBlock / 64][2][8];
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    Fe sum[2] = {fe_zero(), fe_zero()};
+    for (uint64_t z = (uint64_t)blockIdx.x * kBlock + threadIdx.x; z < n_gates; z += stride) {
+        const Fe t = fe_mul(fe_mul(fe_load(E, z), fe_load(eq_u, left[z]), P), fe_load(eq_v, right[z]), P);
+        if (op[z]) sum[1] = fe_add(sum[1], t, P);
+        else sum[0] = fe_add(sum[0], t, P);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        sum[t] = fe_wave_sum(sum[t], P);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[wave][t][i] = sum[t].v[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        Fe acc = fe_zero();
+        for (int w = 0; w < kBlock / 64; ++w) {
+            Fe o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] = red[w][threadIdx.x][i];
+            acc = fe_add(acc, o, P);
+        }
+        fe_store(partials, (uint64_t)blockIdx.x * 2 + threadIdx.x, acc);
+    }
+}
+
+// The factors of a sum-of-products sumcheck at the challenge point: the fold after the LAST round (prover.rs:64), which
+// the reference computes and drops; a layered driver needs it (W(u), W(v)).  tables hold 2 elements each.
+__global__ void k_final_evals(FactorPtrs fp, uint32_t k, const uint64_t *__restrict__ d_challenge, uint64_t *__restrict__ out,
+                              FieldParams P) {
+    const uint32_t f = threadIdx.x;
+    if (f >= k) return;
+    const Fe r = fe_load(d_challenge, 0), lo = fe_load(fp.in[f], 0), hi = fe_load(fp.in[f], 1);
+    fe_store(out, f, fe_sub(lo, fe_mul(r, fe_sub(lo, hi, P), P), P));
+}
+
+}  // namespace zk

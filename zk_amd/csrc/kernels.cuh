@@ -429,10 +429,12 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
 // One workgroup keeps the K tables (<= 2^kFinishVars elements each) in LDS and the sponge in the registers of wave 0 and
 // loops: sums -> workgroup reduction -> transcript step -> fold in LDS (prover.rs:44-68, unchanged semantics).
 //   pending != 0: the tables in HBM still need the previous challenge applied (prover.rs:64) while they are loaded.
+//   out_final: optional, K elements: the factors evaluated at the full challenge point.
 constexpr int kFinishVars = 9;
 template <int K, int D>
 __global__ __launch_bounds__(kBlock) void k_finish(FactorPtrs fp, uint32_t m_in, int pending, FieldParams P,
-                                                   uint64_t *d_challenge, WordSponge *gsponge, uint64_t *out_rp, uint64_t *out_ch) {
+                                                   uint64_t *d_challenge, WordSponge *gsponge, uint64_t *out_rp, uint64_t *out_ch,
+                                                   uint64_t *out_final) {
     constexpr int NS = D + 1;
     // all LDS is carved from the dynamic region at 16-byte aligned offsets (no static __shared__ in front of it)
     extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
@@ -544,6 +546,16 @@ __global__ __launch_bounds__(kBlock) void k_finish(FactorPtrs fp, uint32_t m_in,
         ++round;
     }
     if (wave0) lane_sponge_store(gsponge, sp, L);
+    // out_final != null: the factors at the challenge point, i.e. the fold after the last round (the reference computes
+    // and drops it, prover.rs:64; a layered driver needs W(u))
+    if (out_final && tid < K) {
+        Mul29 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.l[i] = sh_r29p->l[i];
+        const uint64_t *T = tab + (size_t)tid * n_elems * 4;
+        const Fe lo = fe_load(T, 0), hi = fe_load(T, 1);
+        fe_store(out_final, tid, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P));
+    }
 }
 
 // Sharded prover, after the all-reduce: lanes hold sums over ranks of 32-bit digits.  Carry-propagate, reduce mod p
