@@ -667,12 +667,6 @@ struct TailTargets {
     uint64_t *d_challenge;  // challenge for the next fused fold
     uint64_t *lanes;        // 32-bit digit lanes for the cross-GPU all-reduce, may be null
 };
-// A sum of products sum_i prod_{f in term i} T_f: the factors are listed flat, term after term.
-constexpr int kMaxTerms = 4;
-struct TermSpec {
-    int n_terms;
-    int term_k[kMaxTerms];
-};
 static inline TermSpec single_term(int k) {
     TermSpec ts = {1, {k, 0, 0, 0}};
     return ts;
@@ -946,15 +940,38 @@ static int32_t finish_enqueue(RoundState &st) {
     const uint64_t remaining = pending ? st.vars_left - 1 : st.vars_left;
     uint64_t *out_rp = st.ps.d_rp + st.round * (st.D + 1) * 4, *out_ch = st.ps.d_ch + st.round * 4;
     int32_t rc = ZK_ERR_UNSUPPORTED;
-    switch ((int)st.k * 10 + (int)st.D) {
-        case 11: rc = launch_finish<1, 1>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
-        case 12: rc = launch_finish<1, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
-        case 21: rc = launch_finish<2, 1>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
-        case 22: rc = launch_finish<2, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
-        case 23: rc = launch_finish<2, 3>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
-        case 32: rc = launch_finish<3, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
-        case 33: rc = launch_finish<3, 3>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
-        default: break;
+    if (st.terms.n_terms > 1) {
+        const uint32_t m = pending ? m_in - 1 : m_in;
+        const size_t lds = (size_t)st.k * ((size_t)32 << m) + (kBlock / 64) * (st.D + 1) * 32 + (st.D + 1) * 32 + 48;
+        const FieldParams &P = c->fi->P;
+#define ZK_FINISH_TERMS(DD)                                                                                                     \
+    case DD:                                                                                                                    \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_finish_terms<DD>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds) != hipSuccess)                                                                        \
+            return ZK_ERR_HIP;                                                                                                  \
+        k_finish_terms<DD><<<1, kBlock, lds, c->stream>>>(fp, st.terms, m_in, pending, P, st.ps.d_challenge, st.ps.d_sponge,     \
+                                                          out_rp, out_ch, st.d_final);                                          \
+        break;
+        switch (st.D) {
+            ZK_FINISH_TERMS(1)
+            ZK_FINISH_TERMS(2)
+            ZK_FINISH_TERMS(3)
+            ZK_FINISH_TERMS(4)
+            default: return ZK_ERR_UNSUPPORTED;
+        }
+#undef ZK_FINISH_TERMS
+        rc = hipGetLastError() == hipSuccess ? ZK_OK : ZK_ERR_HIP;
+    } else {
+        switch ((int)st.k * 10 + (int)st.D) {
+            case 11: rc = launch_finish<1, 1>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+            case 12: rc = launch_finish<1, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+            case 21: rc = launch_finish<2, 1>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+            case 22: rc = launch_finish<2, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+            case 23: rc = launch_finish<2, 3>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+            case 32: rc = launch_finish<3, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+            case 33: rc = launch_finish<3, 3>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+            default: break;
+        }
     }
     if (rc == ZK_OK) {
         st.round += remaining;
@@ -964,7 +981,7 @@ static int32_t finish_enqueue(RoundState &st) {
     return rc;
 }
 static inline bool finish_applies(const RoundState &st) {
-    if (st.terms.n_terms != 1 || !finish_shape_ok(st.k, st.D)) return false;
+    if (st.terms.n_terms == 1 ? !finish_shape_ok(st.k, st.D) : !fast_degree(st.D)) return false;
     const uint64_t after = st.pending_fold ? st.vars_left - 1 : st.vars_left;
     return after >= 1 && after <= (uint64_t)kFinishVars;
 }
@@ -1288,19 +1305,26 @@ extern "C" int32_t zk_ctx_device_free(zk_ctx *c, void *ptr, uint64_t bytes) {
 // ------------------------------------------------------------------------------------------------------------
 // value at x of the unique polynomial of degree <= D through (i, ys[i]), i = 0..D: what
 // UnivariatePolynomial::interpolate(ys).evaluate(x) returns (univariate_poly.rs:43-49, :29-40); exact in F_p.
-static Fe interp_eval(const std::vector<Fe> &ys, const Fe &x, const FieldParams &P) {
+// Lagrange basis on the nodes 0..D: w_i = 1 / prod_{j != i} (i - j), computed once per proof (one field inversion each)
+static std::vector<Fe> interp_weights(uint32_t D, const FieldParams &P) {
+    std::vector<Fe> w(D + 1);
+    for (uint32_t i = 0; i <= D; ++i) {
+        Fe den = fe_one(P);
+        const Fe xi = fe_from_u32(i, P);
+        for (uint32_t j = 0; j <= D; ++j)
+            if (j != i) den = fe_mul(den, fe_sub(xi, fe_from_u32(j, P), P), P);
+        w[i] = fe_inverse(den, P);
+    }
+    return w;
+}
+static Fe interp_eval(const std::vector<Fe> &ys, const std::vector<Fe> &w, const Fe &x, const FieldParams &P) {
     const size_t n = ys.size();
     Fe acc = fe_zero();
     for (size_t i = 0; i < n; ++i) {
-        Fe num = fe_one(P), den = fe_one(P);
-        const Fe xi = fe_from_u32((uint32_t)i, P);
-        for (size_t j = 0; j < n; ++j) {
-            if (j == i) continue;
-            const Fe xj = fe_from_u32((uint32_t)j, P);
-            num = fe_mul(num, fe_sub(x, xj, P), P);
-            den = fe_mul(den, fe_sub(xi, xj, P), P);
-        }
-        acc = fe_add(acc, fe_mul(ys[i], fe_mul(num, fe_inverse(den, P), P), P), P);
+        Fe num = fe_one(P);
+        for (size_t j = 0; j < n; ++j)
+            if (j != i) num = fe_mul(num, fe_sub(x, fe_from_u32((uint32_t)j, P), P), P);
+        acc = fe_add(acc, fe_mul(ys[i], fe_mul(num, w[i], P), P), P);
     }
     return acc;
 }
@@ -1308,15 +1332,16 @@ static int32_t verify_internal(const FieldParams &P, Sponge &sp, uint64_t n_roun
                                const uint64_t *rps, Fe &claimed, uint64_t *out_ch) {   // verifier.rs:44-78
     absorb_elements(sp, sum, 1, P);                                      // :50
     claimed = fe_from_u64limbs(sum);
+    const std::vector<Fe> w = interp_weights(D, P);
     for (uint64_t r = 0; r < n_rounds; ++r) {
         const uint64_t *rp = rps + r * (D + 1) * 4;
         absorb_elements(sp, rp, D + 1, P);                               // :56
         std::vector<Fe> ys(D + 1);
         for (uint32_t t = 0; t <= D; ++t) ys[t] = fe_from_u64limbs(rp + 4 * t);
-        const Fe p0 = interp_eval(ys, fe_zero(), P), p1 = interp_eval(ys, fe_one(P), P);   // :61-62
+        const Fe p0 = interp_eval(ys, w, fe_zero(), P), p1 = interp_eval(ys, w, fe_one(P), P);   // :61-62
         if (!fe_eq(claimed, fe_add(p0, p1, P))) return ZK_ERR_VERIFY_SUM;                  // :64
         const Fe ch = squeeze_field_element(sp, P);                      // :69
-        claimed = interp_eval(ys, ch, P);                                // :70
+        claimed = interp_eval(ys, w, ch, P);                             // :70
         fe_to_u64limbs(ch, out_ch + 4 * r);
     }
     return ZK_OK;

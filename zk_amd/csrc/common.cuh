@@ -16,6 +16,12 @@ struct FactorPtrs {
 // Challenge record in device memory (written by the on-device transcript): 8 words of r (Montgomery form) followed by
 // the 9 words of its prepared multiplier form (Mul29 of r).  kChallengeBytes is the allocation size.
 constexpr int kChallengeBytes = 96;
+// A sum of products sum_i prod_{f in term i} T_f: the factors are listed flat (FactorPtrs), term after term.
+constexpr int kMaxTerms = 4;
+struct TermSpec {
+    int n_terms;
+    int term_k[kMaxTerms];
+};
 #if defined(__HIPCC__)
 ZK_D Mul29 load_challenge29(const uint64_t *rptr) {
     const uint32_t *w = reinterpret_cast<const uint32_t *>(rptr) + 8;

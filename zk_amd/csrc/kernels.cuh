@@ -558,6 +558,139 @@ __global__ __launch_bounds__(kBlock) void k_finish(FactorPtrs fp, uint32_t m_in,
     }
 }
 
+// The same finisher for a SUM of products (zk_sumcheck_prove_terms; a GKR layer polynomial): the factor list is grouped into
+// terms at run time, each pair contributes sum_i prod_{f in term i}.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_finish_terms(FactorPtrs fp, TermSpec ts, uint32_t m_in, int pending, FieldParams P,
+                                                   uint64_t *d_challenge, WordSponge *gsponge, uint64_t *out_rp, uint64_t *out_ch,
+                                                   uint64_t *out_final) {
+    constexpr int NS = D + 1;
+    int K = 0;   // factors in all (runtime here)
+    for (int i = 0; i < ts.n_terms; ++i) K += ts.term_k[i];
+    // all LDS is carved from the dynamic region at 16-byte aligned offsets (no static __shared__ in front of it)
+    extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool wave0 = __builtin_amdgcn_readfirstlane(wave) == 0;
+    uint32_t m = pending ? m_in - 1 : m_in;       // variables of the tables held in LDS
+    const uint32_t n_elems = 1u << m;
+    uint64_t *tab = reinterpret_cast<uint64_t *>(fin_smem);                 // K tables of 2^m elements, 4 u64 each
+    unsigned char *carve = fin_smem + (size_t)K * n_elems * 32;
+    uint32_t(*red)[NS][8] = reinterpret_cast<uint32_t(*)[NS][8]>(carve);    // [waves][NS][8]
+    Fe *fin = reinterpret_cast<Fe *>(carve + (kBlock / 64) * NS * 32);
+    Mul29 *sh_r29p = reinterpret_cast<Mul29 *>(carve + (kBlock / 64) * NS * 32 + NS * 32);
+    // ---- load (and fold when pending) ----
+    if (pending) {
+        const Mul29 r = load_challenge29(d_challenge);
+#pragma unroll
+        for (int f = 0; f < K; ++f)
+            for (uint32_t j = tid; j < n_elems; j += kBlock) {
+                const Fe lo = fe_load(fp.in[f], j), hi = fe_load(fp.in[f], j + n_elems);
+                fe_store(tab + (size_t)f * n_elems * 4, j, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P));
+            }
+    } else {
+#pragma unroll
+        for (int f = 0; f < K; ++f)
+            for (uint32_t j = tid; j < n_elems; j += kBlock) fe_store(tab + (size_t)f * n_elems * 4, j, fe_load(fp.in[f], j));
+    }
+    LaneKeccak L = lane_keccak_init();
+    LaneSponge sp = {0, 0};
+    if (wave0) sp = lane_sponge_load(gsponge, L);
+    __syncthreads();
+    uint32_t round = 0;
+    while (m >= 1) {
+        const uint32_t q = 1u << (m - 1);
+        // ---- sums over the pairs (j, j+q) ----
+        Fe sum[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) sum[t] = fe_zero();
+        for (uint32_t j = tid; j < q; j += kBlock) {
+            int f = 0;
+            for (int i = 0; i < ts.n_terms; ++i) {
+                Fe prod[NS];
+                for (int g = 0; g < ts.term_k[i]; ++g, ++f) {
+                    const uint64_t *T = tab + (size_t)f * n_elems * 4;
+                    const Fe lo = fe_load(T, j), hi = fe_load(T, j + q);
+                    const Fe diff = fe_sub(hi, lo, P);
+                    Fe v = lo;
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) {
+                        if (t == 1) v = hi;
+                        else if (t > 1) v = fe_add(v, diff, P);
+                        prod[t] = (g == 0) ? v : fe_mul(prod[t], v, P);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NS; ++t) sum[t] = fe_add(sum[t], prod[t], P);
+            }
+        }
+        // ---- workgroup reduction -> fin[] ----
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            sum[t] = fe_wave_sum(sum[t], P, q < 64 ? q : 64);   // lanes >= q hold zero: empty levels are skipped
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) red[wave][t][i] = sum[t].v[i];
+            }
+        }
+        __syncthreads();
+        if (tid < NS) {
+            Fe acc;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc.v[i] = red[0][tid][i];
+            if (q > 64) {
+                for (int w = 1; w < kBlock / 64; ++w) {
+                    Fe o;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o.v[i] = red[w][tid][i];
+                    acc = fe_add(acc, o, P);
+                }
+            }
+            fin[tid] = acc;
+            fe_store(out_rp, (uint64_t)round * NS + tid, acc);
+        }
+        __syncthreads();
+        // ---- transcript step on wave 0, challenge to everyone through LDS ----
+        if (wave0) {
+            Mul29 ch29;
+            const Fe ch = transcript_step(sp, L, fin, NS, P, ch29);
+            if (lane == 0) {
+                fe_store(out_ch, round, ch);
+                *sh_r29p = ch29;
+            }
+            if (m == 1) publish_challenge(d_challenge, nullptr, ch, ch29, (int)lane);   // last one: for the sharded tail
+        }
+        __syncthreads();
+        // ---- fold at the challenge, in LDS (prover.rs:64); the fold after the last round is dropped by the reference
+        if (m > 1) {
+            Mul29 r;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) r.l[i] = __builtin_amdgcn_readfirstlane(sh_r29p->l[i]);
+#pragma unroll
+            for (int f = 0; f < K; ++f) {
+                uint64_t *T = tab + (size_t)f * n_elems * 4;
+                for (uint32_t j = tid; j < q; j += kBlock) {
+                    const Fe lo = fe_load(T, j), hi = fe_load(T, j + q);
+                    fe_store(T, j, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P));
+                }
+            }
+            __syncthreads();
+        }
+        --m;
+        ++round;
+    }
+    if (wave0) lane_sponge_store(gsponge, sp, L);
+    // out_final != null: the factors at the challenge point, i.e. the fold after the last round (the reference computes
+    // and drops it, prover.rs:64; a layered driver needs W(u))
+    if (out_final && (int)tid < K) {
+        Mul29 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.l[i] = sh_r29p->l[i];
+        const uint64_t *T = tab + (size_t)tid * n_elems * 4;
+        const Fe lo = fe_load(T, 0), hi = fe_load(T, 1);
+        fe_store(out_final, tid, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P));
+    }
+}
+
 // Sharded prover, after the all-reduce: lanes hold sums over ranks of 32-bit digits.  Carry-propagate, reduce mod p
 // (value < world * p, world <= 2^16), then the same transcript step.  One lane.
 __global__ void k_lanes_transcript(const uint64_t *__restrict__ lanes, uint32_t ns, WordSponge *__restrict__ sponge,
