@@ -19,6 +19,8 @@ use std::os::raw::{c_char, c_void};
 type zk_ctx = c_void;
 #[allow(non_camel_case_types)]
 type zk_mle = c_void;
+#[allow(non_camel_case_types)]
+type zk_circuit = c_void;
 
 extern "C" {
     fn zk_strerror(status: i32) -> *const c_char;
@@ -38,6 +40,19 @@ extern "C" {
     fn zk_sumcheck_prove(ctx: *mut zk_ctx, factors: *const *mut zk_mle, k: u64, max_var_degree: u32, sum: *const u64,
                          absorb_table: i32, consume: i32, out_round_polys: *mut u64, out_challenges: *mut u64) -> i32;
     fn zk_fft_host(ctx: *mut zk_ctx, input: *const u64, n: u64, out: *mut u64) -> i32;
+    // GKR-shaped driver (no reference crate; include/zk_amd.h "sum of products + GKR-shaped driver")
+    fn zk_sumcheck_prove_terms(ctx: *mut zk_ctx, factors: *const *mut zk_mle, term_k: *const u64, n_terms: u64,
+                               max_var_degree: u32, sum: *const u64, consume: i32, out_round_polys: *mut u64,
+                               out_challenges: *mut u64, out_final: *mut u64) -> i32;
+    fn zk_circuit_create(ctx: *mut zk_ctx, out: *mut *mut zk_circuit) -> i32;
+    fn zk_circuit_add_layer(c: *mut zk_circuit, log_out: u64, log_in: u64, op: *const u8, left: *const u32,
+                            right: *const u32) -> i32;
+    fn zk_circuit_free(c: *mut zk_circuit) -> i32;
+    fn zk_circuit_proof_elems(c: *const zk_circuit, out: *mut u64) -> i32;
+    fn zk_gkr_prove(c: *const zk_circuit, input: *const zk_mle, seed: *const u8, out_outputs: *mut *mut zk_mle,
+                    out_proof: *mut u64) -> i32;
+    fn zk_gkr_verify(c: *const zk_circuit, input: *const zk_mle, outputs: *const zk_mle, seed: *const u8,
+                     proof: *const u64) -> i32;
     fn zk_ifft_host(ctx: *mut zk_ctx, input: *const u64, n: u64, out: *mut u64) -> i32;
 }
 
@@ -196,4 +211,63 @@ pub fn ifft<F: GpuField>(evaluations: Vec<F>) -> Vec<F> {
     let rc = unsafe { zk_ifft_host(ctx::<F>(), limbs(&evaluations), evaluations.len() as u64, out.as_mut_ptr() as *mut u64) };
     assert!(rc == 0, "{}", err(rc));
     out
+}
+
+// ---- GKR-shaped driver ---------------------------------------------------------------------------------------------
+// The reference has no gkr crate (its building block is prove_partial, prover.rs:24-30; intent at
+// evaluation_form.rs:45-48).  These are the bindings of this library's own layered driver.
+
+/// prove_partial on sum_i prod_{f in terms[i]}: (round polys, challenges, every factor at the challenge point)
+pub fn prove_partial_terms<const MAX_VAR_DEGREE: u8, F: GpuField>(terms: &[Vec<MultiLinearPolynomial<F>>], sum: F)
+    -> Result<(SumcheckProof<F>, Vec<F>, Vec<F>), &'static str> {
+    let h: Vec<*mut zk_mle> = terms.iter().flat_map(|t| t.iter().map(|p| p.h)).collect();
+    let tk: Vec<u64> = terms.iter().map(|t| t.len() as u64).collect();
+    if h.is_empty() { return Err(err(-3)); }
+    let n = terms[0][0].n_vars();
+    let ns = MAX_VAR_DEGREE as usize + 1;
+    let (mut rp, mut ch, mut fin) = (vec![F::zero(); n * ns], vec![F::zero(); n], vec![F::zero(); h.len()]);
+    let rc = unsafe { zk_sumcheck_prove_terms(terms[0][0].ctx, h.as_ptr(), tk.as_ptr(), tk.len() as u64, MAX_VAR_DEGREE as u32,
+                                              &sum as *const F as *const u64, 0, rp.as_mut_ptr() as *mut u64,
+                                              ch.as_mut_ptr() as *mut u64, fin.as_mut_ptr() as *mut u64) };
+    if rc != 0 { return Err(err(rc)); }
+    Ok((SumcheckProof { sum, round_polys: rp.chunks(ns).map(|c| c.to_vec()).collect() }, ch, fin))
+}
+
+/// One layer: 2^log_out gates (op 0 = add, 1 = mul) over the 2^log_in values of the layer below.
+pub struct Layer { pub log_out: usize, pub log_in: usize, pub op: Vec<u8>, pub left: Vec<u32>, pub right: Vec<u32> }
+
+pub struct Circuit<F: GpuField> { h: *mut zk_circuit, _f: PhantomData<F> }
+impl<F: GpuField> Drop for Circuit<F> { fn drop(&mut self) { unsafe { zk_circuit_free(self.h); } } }
+impl<F: GpuField> Circuit<F> {
+    /// layers[0] = output layer
+    pub fn new(layers: &[Layer]) -> Result<Self, &'static str> {
+        let mut h: *mut zk_circuit = std::ptr::null_mut();
+        let rc = unsafe { zk_circuit_create(ctx::<F>(), &mut h) };
+        if rc != 0 { return Err(err(rc)); }
+        let c = Circuit { h, _f: PhantomData };
+        for l in layers {
+            let rc = unsafe { zk_circuit_add_layer(h, l.log_out as u64, l.log_in as u64, l.op.as_ptr(), l.left.as_ptr(), l.right.as_ptr()) };
+            if rc != 0 { return Err(err(rc)); }
+        }
+        Ok(c)
+    }
+    /// -> (outputs, proof elements: per layer [round polys #1 | round polys #2 | W(u) | W(v)])
+    pub fn prove(&self, input: &MultiLinearPolynomial<F>, seed: &[u8; 32]) -> Result<(MultiLinearPolynomial<F>, Vec<F>), &'static str> {
+        let mut n = 0u64;
+        unsafe { zk_circuit_proof_elems(self.h, &mut n); }
+        let mut proof = vec![F::zero(); n as usize];
+        let mut out: *mut zk_mle = std::ptr::null_mut();
+        let rc = unsafe { zk_gkr_prove(self.h, input.h, seed.as_ptr(), &mut out, proof.as_mut_ptr() as *mut u64) };
+        if rc != 0 { return Err(err(rc)); }
+        Ok((MultiLinearPolynomial { ctx: input.ctx, h: out, _f: PhantomData }, proof))
+    }
+    /// Ok(true) accept / Ok(false) reject (a sumcheck round check, a layer's wiring check or the input check failed)
+    pub fn verify(&self, input: &MultiLinearPolynomial<F>, outputs: &MultiLinearPolynomial<F>, seed: &[u8; 32], proof: &[F])
+        -> Result<bool, &'static str> {
+        match unsafe { zk_gkr_verify(self.h, input.h, outputs.h, seed.as_ptr(), proof.as_ptr() as *const u64) } {
+            0 => Ok(true),
+            -9 | -27 => Ok(false),
+            rc => Err(err(rc)),
+        }
+    }
 }

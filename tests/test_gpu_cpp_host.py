@@ -18,6 +18,17 @@ def test_cpp_reference_kats_on_gpu():
     assert "ok: 11 reference tests passed" in r.stdout
 
 
+@pytest.mark.gpu
+def test_cpp_gkr_host_on_gpu():
+    """the GKR-shaped driver through zk.hpp (tests/cpp/test_gkr_host.cpp)"""
+    gkr_bin = os.path.join(ROOT, "tests", "cpp", "test_gkr_host")
+    if not os.path.exists(gkr_bin):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
+    r = subprocess.run([gkr_bin], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ok: gkr host tests passed" in r.stdout
+
+
 def test_cpp_host_mirror_compiles_and_fails_loudly_without_gpu():
     import torch
 

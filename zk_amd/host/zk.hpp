@@ -96,6 +96,7 @@ class MultiLinearPolynomial {
     explicit MultiLinearPolynomial(zk_mle *h) : h_(std::make_shared<Handle>()) { h_->h = h; }
     template <class> friend class ProductPoly;
     template <uint8_t, class> friend class SumcheckProver;
+    template <class> friend class Circuit;
 
 public:
     // evaluation_form.rs:15-27
@@ -325,5 +326,106 @@ inline std::vector<Fe<F>> ifft(const std::vector<Fe<F>> &evaluations) {
     if (rc != ZK_OK) throw std::runtime_error(zk_strerror(rc));
     return out;
 }
+
+// ---- GKR-shaped driver (the reference has no gkr crate; formats are this library's) ----------
+// prove_partial (prover.rs:24-30) on a sum of products: terms[i] = the factors of product i.
+template <class F>
+struct TermsProof {
+    std::vector<std::vector<Fe<F>>> round_polys;
+    std::vector<Fe<F>> challenges, finals;   // finals: every factor at the challenge point, term after term
+};
+template <uint8_t MAX_VAR_DEGREE, class F>
+inline Result<TermsProof<F>> prove_partial_terms(const std::vector<std::vector<MultiLinearPolynomial<F>>> &terms, Fe<F> sum) {
+    std::vector<zk_mle *> h;
+    std::vector<uint64_t> tk;
+    for (auto &t : terms) {
+        tk.push_back(t.size());
+        for (auto &p : t) h.push_back(p.raw());
+    }
+    if (h.empty()) return Result<TermsProof<F>>(ZK_ERR_EMPTY_PRODUCT);
+    const size_t n = terms[0][0].n_vars(), ns = (size_t)MAX_VAR_DEGREE + 1;
+    std::vector<uint64_t> rp(4 * n * ns + 4), ch(4 * n + 4), fin(4 * h.size());
+    const int32_t rc = zk_sumcheck_prove_terms(context<F>(), h.data(), tk.data(), tk.size(), MAX_VAR_DEGREE, sum.l.data(), 0,
+                                               rp.data(), ch.data(), fin.data());
+    if (rc != ZK_OK) return rc;
+    TermsProof<F> out;
+    out.challenges.resize(n);
+    out.finals.resize(h.size());
+    for (size_t r = 0; r < n; ++r) {
+        std::vector<Fe<F>> row(ns);
+        for (size_t t = 0; t < ns; ++t)
+            for (int i = 0; i < 4; ++i) row[t].l[i] = rp[4 * (r * ns + t) + i];
+        out.round_polys.push_back(row);
+        for (int i = 0; i < 4; ++i) out.challenges[r].l[i] = ch[4 * r + i];
+    }
+    for (size_t f = 0; f < h.size(); ++f)
+        for (int i = 0; i < 4; ++i) out.finals[f].l[i] = fin[4 * f + i];
+    return out;
+}
+
+struct Layer {   // 2^log_out gates over 2^log_in values; op 0 = add, 1 = mul
+    size_t log_out, log_in;
+    std::vector<uint8_t> op;
+    std::vector<uint32_t> left, right;
+};
+template <class F>
+struct GkrProof {
+    std::vector<Fe<F>> elements;   // per layer [round polys #1 | round polys #2 | W(u) | W(v)]
+};
+template <class F>
+class Circuit {
+    struct Handle {
+        zk_circuit *h = nullptr;
+        ~Handle() { if (h) zk_circuit_free(h); }
+    };
+    std::shared_ptr<Handle> h_;
+    explicit Circuit(zk_circuit *h) : h_(std::make_shared<Handle>()) { h_->h = h; }
+
+public:
+    // layers[0] = output layer
+    static Result<Circuit> new_(const std::vector<Layer> &layers) {
+        zk_circuit *z = nullptr;
+        int32_t rc = zk_circuit_create(context<F>(), &z);
+        if (rc != ZK_OK) return rc;
+        Circuit c(z);
+        for (auto &l : layers) {
+            if (l.op.size() != ((size_t)1 << l.log_out) || l.left.size() != l.op.size() || l.right.size() != l.op.size())
+                return Result<Circuit>(ZK_ERR_BAD_ARG);
+            rc = zk_circuit_add_layer(z, l.log_out, l.log_in, l.op.data(), l.left.data(), l.right.data());
+            if (rc != ZK_OK) return rc;
+        }
+        return c;
+    }
+    Result<MultiLinearPolynomial<F>> evaluate(const MultiLinearPolynomial<F> &input) const {
+        zk_mle *o = nullptr;
+        const int32_t rc = zk_gkr_evaluate(h_->h, input.raw(), &o);
+        if (rc != ZK_OK) return rc;
+        return MultiLinearPolynomial<F>(o);
+    }
+    // -> (outputs, proof)
+    Result<std::pair<MultiLinearPolynomial<F>, GkrProof<F>>> prove(const MultiLinearPolynomial<F> &input,
+                                                                   const std::array<uint8_t, 32> &seed) const {
+        uint64_t n = 0;
+        zk_circuit_proof_elems(h_->h, &n);
+        GkrProof<F> proof;
+        proof.elements.resize(n);
+        zk_mle *o = nullptr;
+        const int32_t rc = zk_gkr_prove(h_->h, input.raw(), seed.data(), &o, reinterpret_cast<uint64_t *>(proof.elements.data()));
+        if (rc != ZK_OK) return rc;
+        return std::make_pair(MultiLinearPolynomial<F>(o), proof);
+    }
+    // Ok(true) accept, Ok(false) reject, Err on misuse
+    Result<bool> verify(const MultiLinearPolynomial<F> &input, const MultiLinearPolynomial<F> &outputs,
+                        const std::array<uint8_t, 32> &seed, const GkrProof<F> &proof) const {
+        uint64_t n = 0;
+        zk_circuit_proof_elems(h_->h, &n);
+        if (proof.elements.size() != n) return Result<bool>(ZK_ERR_BAD_ARG);
+        const int32_t rc = zk_gkr_verify(h_->h, input.raw(), outputs.raw(), seed.data(),
+                                         reinterpret_cast<const uint64_t *>(proof.elements.data()));
+        if (rc == ZK_OK) return true;
+        if (rc == ZK_ERR_VERIFY_SUM || rc == ZK_ERR_GKR_REJECT) return false;
+        return rc;
+    }
+};
 
 }  // namespace zk
