@@ -310,6 +310,27 @@ def main():
             if rank == 0:
                 result.setdefault("extra", {})[f"sharded_sumcheck_ms_shard2p{ns}_k2_d2_world{world}"] = float(tt.item()) * 1e3
                 result["extra"]["sharded_challenges_identical_on_all_ranks"] = same
+            # four-step NTT across the ranks (one all-to-all): every rank holds 2^22 points of a 2^22 * world point vector
+            try:
+                from zk_amd.distributed import GpuNttBackend, ShardedNtt
+                xs = zk_amd.MultiLinearPolynomial.random(ctx, ns, 0x5EED0300, first_index=rank << ns)
+                nb = GpuNttBackend(xs, rank, world)
+                ShardedNtt(nb).forward()
+                torch.cuda.synchronize()
+                tn = []
+                for it in range(3):
+                    dist.barrier()
+                    t1 = time.perf_counter()
+                    ShardedNtt(nb).forward()
+                    torch.cuda.synchronize()
+                    tn.append(time.perf_counter() - t1)
+                tt = torch.tensor([sorted(tn)[1]], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                if rank == 0:
+                    result["extra"][f"sharded_ntt_ms_2p{ns}_per_rank_world{world}"] = float(tt.item()) * 1e3
+            except Exception as e:
+                if rank == 0:
+                    result.setdefault("extra", {})["sharded_ntt_error"] = repr(e)
             ctx.use_own_stream()
         except Exception as e:
             if rank == 0:

@@ -82,6 +82,8 @@ int32_t zk_ctx_field(const zk_ctx *ctx, int32_t *out_field);
 int32_t zk_field_modulus(int32_t field, uint64_t out_p[4]);
 int32_t zk_field_two_adicity(int32_t field, int32_t *out_s);
 /* host-side element helpers for callers without ark-ff (tests, Python): F::from(u64), into_bigint, from_be_bytes_mod_order */
+/* F::get_root_of_unity(2^log_n) (fft/src/lib.rs:6,14): g^((p-1)/2^log_n); None -> ZK_ERR_FFT_NO_ROOT */
+int32_t zk_field_root_of_unity(int32_t field, uint64_t log_n, uint64_t out[4]);
 int32_t zk_fe_from_u64(int32_t field, uint64_t v, uint64_t out[4]);
 int32_t zk_fe_from_canonical(int32_t field, const uint64_t limbs[4], uint64_t out[4]);
 int32_t zk_fe_to_canonical(int32_t field, const uint64_t a[4], uint64_t out_limbs[4]);
@@ -226,6 +228,15 @@ int32_t zk_gkr_prove(const zk_circuit *c, const zk_mle *input, const uint8_t see
 /* ZK_OK = accept; ZK_ERR_VERIFY_SUM = a sumcheck round check failed; ZK_ERR_GKR_REJECT = wiring / input check failed */
 int32_t zk_gkr_verify(const zk_circuit *c, const zk_mle *input, const zk_mle *outputs, const uint8_t seed[32],
                       const uint64_t *proof);
+
+/* ---- pieces of the multi-GPU four-step NTT (orchestration: zk_amd/distributed.py ShardedNtt) -------------
+ * The fft crate's transform (fft/src/lib.rs:21-46) over a vector sharded by index mod W: local zk_ntt per rank, then
+ * the inter-rank twiddles, one all-to-all, and W-point transforms across the ranks' rows. */
+/* t[j] *= scale * base^j */
+int32_t zk_mle_mul_powers(zk_ctx *ctx, zk_mle *table, const uint64_t base[4], const uint64_t scale[4]);
+/* in / out read as W = 2^log_w rows of L elements: out[k][j] = sum_r w^(r*k) in[r][j], w = get_root_of_unity(W)
+ * (its inverse, unscaled, when inverse != 0); log_w <= 10 */
+int32_t zk_dft_across(zk_ctx *ctx, const zk_mle *in, zk_mle *out, uint64_t log_w, int32_t inverse);
 
 /* ---- SumcheckVerifier  (sumcheck/src/verifier.rs) -- host-side protocol logic; oracle check on device ------------ */
 /* ::verify_partial :38-41 -> SubClaim{sum, challenges} */

@@ -86,3 +86,51 @@ class OracleShardBackend:
 
     def results(self):
         return np.stack(self.rp), np.stack(self.ch)
+
+
+class OracleNttBackend:
+    """CPU stand-in for GpuNttBackend (zk_amd/distributed.py): local transforms by the oracle's NTT, twiddles and the
+    W-point transforms across rows in Python integers."""
+
+    def __init__(self, field, shard, rank, world):
+        self.field, self.rank, self.world = field, rank, world
+        self.src = np.ascontiguousarray(shard, dtype=np.uint64).reshape(-1, 4)
+        self.M = self.src.shape[0]
+        self.p = orc.modulus(field)
+        self.w_n = orc.to_int(field, orc.root_of_unity(field, self.M * world))
+        self.a = np.zeros_like(self.src)
+        self.b = np.zeros_like(self.src)
+        self._ta = torch.from_numpy(self.a.view(np.int64).reshape(-1))
+        self._tb = torch.from_numpy(self.b.view(np.int64).reshape(-1))
+
+    def local_ntt(self, inverse):
+        self.a[:] = orc.ntt_fast(self.field, self.b if inverse else self.src, inverse)
+
+    def twiddle(self, inverse):
+        t = self.b if inverse else self.a
+        w = pow(self.w_n, -1, self.p) if inverse else self.w_n
+        base = pow(w, self.rank, self.p)
+        scale = pow(self.world, -1, self.p) if inverse else 1
+        vals = orc.to_ints(self.field, t)
+        t[:] = orc.from_ints(self.field, [v * scale * pow(base, j, self.p) % self.p for j, v in enumerate(vals)])
+
+    def across(self, inverse):
+        src = self.src if inverse else self.b
+        W, L = self.world, self.M // self.world
+        w = pow(self.w_n, self.M, self.p)                 # get_root_of_unity(W)
+        if inverse:
+            w = pow(w, -1, self.p)
+        rows = [orc.to_ints(self.field, src[r * L:(r + 1) * L]) for r in range(W)]
+        out = []
+        for k in range(W):
+            out += [sum(rows[r][j] * pow(w, r * k, self.p) for r in range(W)) % self.p for j in range(L)]
+        self.a[:] = orc.from_ints(self.field, out)
+
+    def send_tensor(self):
+        return self._ta
+
+    def recv_tensor(self):
+        return self._tb
+
+    def result(self):
+        return self.a

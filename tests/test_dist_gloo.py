@@ -74,3 +74,39 @@ def test_shard_of_is_the_suffix_shard():
         parts = [shard_of(t, g, w) for g in range(w)]
         for g, part in enumerate(parts):
             assert np.array_equal(part[:, 0] // 4, np.arange(g, 16, w))   # global idx = local*w + g
+
+
+def _ntt_worker(rank, world, port, field, log_n, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from shard_backend_oracle import OracleNttBackend
+
+        from oracle import binding as orc
+        from zk_amd.distributed import ShardedNtt, shard_of, sliced_shard_of
+
+        x = orc.fill_random(field, 4242, 1 << log_n)
+        fwd = ShardedNtt(OracleNttBackend(field, shard_of(x, rank, world), rank, world)).forward().copy()
+        X = orc.ntt_fast(field, x, False)
+        inv = ShardedNtt(OracleNttBackend(field, sliced_shard_of(X, rank, world), rank, world)).inverse().copy()
+        np.savez(os.path.join(out_dir, f"ntt{rank}.npz"), fwd=fwd, inv=inv)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("field,log_n", [(0, 6), (2, 5), (1, 4)])
+def test_sharded_ntt_matches_single_process_oracle(tmp_path, world, field, log_n):
+    """four-step NTT over gloo: forward (strided shards -> sliced shards of fft(x)) and inverse (sliced -> strided),
+    one all-to-all each, against the oracle's transform of the whole vector (fft/src/lib.rs:4-19)."""
+    from oracle import binding as orc
+    from zk_amd.distributed import shard_of, sliced_shard_of
+
+    port = _free_port()
+    mp.spawn(_ntt_worker, args=(world, port, field, log_n, str(tmp_path)), nprocs=world, join=True)
+    x = orc.fill_random(field, 4242, 1 << log_n)
+    X = orc.fft(field, x) if log_n <= 5 else orc.ntt_fast(field, x, False)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"ntt{r}.npz"))
+        assert np.array_equal(got["fwd"], sliced_shard_of(X, r, world)), f"rank {r}: forward shard differs"
+        assert np.array_equal(got["inv"], shard_of(x, r, world)), f"rank {r}: inverse shard differs"

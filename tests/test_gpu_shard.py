@@ -65,3 +65,84 @@ def test_single_rank_orchestration_equals_plain_prover():
     rp, ch = ShardedSumcheckProver(GpuShardBackend(poly, D, claimed, 1)).prove_partial()
     want_rp, want_ch = orc.sumcheck_prove(field, n, tabs, D, claimed, False)
     assert np.array_equal(rp, want_rp) and np.array_equal(ch, want_ch)
+
+
+# ---- four-step NTT across ranks (zk_amd.distributed.ShardedNtt / GpuNttBackend) --------------------------------------
+@pytest.mark.parametrize("field", [zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR])
+def test_mul_powers_and_dft_across_primitives(field):
+    from zk_amd._lib import check, lib, u64p
+
+    ctx = zk_amd.Context(field, 0)
+    p = zk_amd.modulus(field)
+    n = 13
+    x = orc.fill_random(field, 77, 1 << n)
+    xs = orc.to_ints(field, x)
+    base, scale = 0x1234567 * 31337 % p, 0xABCDEF % p
+    t = MLE.new(ctx, n, x)
+    check(lib.zk_mle_mul_powers(ctx._h, t._h, zk_amd.fe_from_int(field, base).ctypes.data_as(u64p),
+                                zk_amd.fe_from_int(field, scale).ctypes.data_as(u64p)))
+    assert zk_amd.fe_to_ints(field, t.evaluation_slice()) == [v * scale * pow(base, j, p) % p for j, v in enumerate(xs)]
+    for log_w in (0, 1, 3):
+        W, L = 1 << log_w, 1 << (n - log_w)
+        w = zk_amd.fe_to_int(field, zk_amd.root_of_unity(field, log_w))
+        assert zk_amd.root_of_unity(field, log_w).tolist() == orc.root_of_unity(field, W).tolist()
+        for inverse in (0, 1):
+            ww = pow(w, -1, p) if inverse else w
+            out, src = MLE.alloc(ctx, n), MLE.new(ctx, n, x)
+            check(lib.zk_dft_across(ctx._h, src._h, out._h, log_w, inverse))
+            got = zk_amd.fe_to_ints(field, out.evaluation_slice())
+            for k in range(W):
+                for j in (0, 1, L // 2, L - 1):
+                    assert got[k * L + j] == sum(xs[r * L + j] * pow(ww, r * k, p) for r in range(W)) % p
+
+
+@pytest.mark.parametrize("field", [zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR])
+@pytest.mark.parametrize("world,log_n", [(1, 9), (2, 10), (4, 12), (8, 16), (8, 6), (2, 2)])
+def test_sharded_ntt_rehearsal_matches_oracle(field, world, log_n):
+    """W GpuNttBackends in ONE process on one GPU, the all-to-all done by hand with torch ops, against the oracle's
+    transform of the whole vector (fft/src/lib.rs:4-19); forward then inverse."""
+    import torch
+
+    from zk_amd.distributed import GpuNttBackend, sliced_shard_of
+
+    ctx = zk_amd.Context(field, 0)
+    x = orc.fill_random(field, 31 + log_n, 1 << log_n)
+    X = orc.ntt_fast(field, x, False)
+    m = log_n - int(np.log2(world))
+
+    def exchange(backends):
+        sends = [b.send_tensor().view(world, -1) for b in backends]
+        for s, b in enumerate(backends):
+            b.recv_tensor().view(world, -1).copy_(torch.stack([sends[r][s] for r in range(world)]))
+
+    fw = [GpuNttBackend(MLE.new(ctx, m, shard_of(x, r, world)), r, world) for r in range(world)]
+    for b in fw:
+        b.local_ntt(False)
+        b.twiddle(False)
+    exchange(fw)
+    for r, b in enumerate(fw):
+        b.across(False)
+        assert np.array_equal(b.result().evaluation_slice(), sliced_shard_of(X, r, world)), f"forward, rank {r}"
+    bw = [GpuNttBackend(MLE.new(ctx, m, sliced_shard_of(X, r, world)), r, world) for r in range(world)]
+    for b in bw:
+        b.across(True)
+    exchange(bw)
+    for r, b in enumerate(bw):
+        b.twiddle(True)
+        b.local_ntt(True)
+        assert np.array_equal(b.result().evaluation_slice(), shard_of(x, r, world)), f"inverse, rank {r}"
+    # and through the orchestration class itself (world of one process: the exchange is a local copy)
+    if world == 1:
+        from zk_amd.distributed import ShardedNtt
+
+        assert np.array_equal(ShardedNtt(GpuNttBackend(MLE.new(ctx, m, x), 0, 1)).forward().evaluation_slice(), X)
+
+
+def test_sharded_ntt_needs_world_elements_per_shard():
+    from zk_amd.distributed import GpuNttBackend
+
+    ctx = zk_amd.Context(zk_amd.BN254_FR, 0)
+    with pytest.raises(ValueError, match="at least `world` elements"):
+        GpuNttBackend(MLE.random(ctx, 2, 1), 0, 8)
+    with pytest.raises(ValueError, match="power of two"):
+        GpuNttBackend(MLE.random(ctx, 4, 1), 0, 3)

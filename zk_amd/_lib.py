@@ -76,6 +76,7 @@ _sig = {
     "zk_ctx_field": [c.c_void_p, c.POINTER(c.c_int32)],
     "zk_field_modulus": [c.c_int32, u64p],
     "zk_field_two_adicity": [c.c_int32, c.POINTER(c.c_int32)],
+    "zk_field_root_of_unity": [c.c_int32, c.c_uint64, u64p],
     "zk_fe_from_u64": [c.c_int32, c.c_uint64, u64p],
     "zk_fe_from_canonical": [c.c_int32, u64p, u64p],
     "zk_fe_to_canonical": [c.c_int32, u64p, u64p],
@@ -132,6 +133,8 @@ _sig = {
     "zk_gkr_evaluate": [c.c_void_p, c.c_void_p, vpp],
     "zk_gkr_prove": [c.c_void_p, c.c_void_p, u8p, vpp, u64p],
     "zk_gkr_verify": [c.c_void_p, c.c_void_p, c.c_void_p, u8p, u64p],
+    "zk_mle_mul_powers": [c.c_void_p, c.c_void_p, u64p, u64p],
+    "zk_dft_across": [c.c_void_p, c.c_void_p, c.c_void_p, c.c_uint64, c.c_int32],
     "zk_ntt": [c.c_void_p, c.c_void_p, c.c_int32, c.c_void_p],
     "zk_fft_host": [c.c_void_p, u64p, c.c_uint64, u64p],
     "zk_ifft_host": [c.c_void_p, u64p, c.c_uint64, u64p],

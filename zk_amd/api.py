@@ -43,6 +43,13 @@ def two_adicity(field):
     return s.value
 
 
+def root_of_unity(field, log_n):
+    """F::get_root_of_unity(2^log_n) (fft/src/lib.rs:6) as a Montgomery element"""
+    out = np.zeros(4, dtype=np.uint64)
+    check(lib.zk_field_root_of_unity(field, log_n, _p(out)))
+    return out
+
+
 def fe_from_int(field, v):
     """F::from(v) for any Python int (reduced mod p first)."""
     v %= modulus(field)
@@ -428,5 +435,5 @@ def bench_ntt(ctx, vec_in, vec_out, inverse=False, reps=5):
 __all__ = [
     "BN254_FR", "BLS12_381_FR", "BLS12_377_FR", "Context", "MultiLinearPolynomial", "CoeffMultilinearPolynomial", "ProductPoly", "SumcheckProof",
     "SubClaim", "SumcheckProver", "SumcheckVerifier", "Transcript", "ZkError", "fft", "ifft", "fft_internal", "ntt", "bench_ntt",
-    "fe_from_int", "fe_from_ints", "fe_to_int", "fe_to_ints", "keccak256", "modulus", "two_adicity",
+    "fe_from_int", "fe_from_ints", "fe_to_int", "fe_to_ints", "keccak256", "modulus", "two_adicity", "root_of_unity",
 ]

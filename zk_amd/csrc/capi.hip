@@ -170,6 +170,16 @@ extern "C" int32_t zk_field_two_adicity(int32_t field, int32_t *out) {
     *out = (int32_t)fi->two_adicity;
     return ZK_OK;
 }
+// F::get_root_of_unity(2^log_n) (fft/src/lib.rs:6): None -> ZK_ERR_FFT_NO_ROOT
+extern "C" int32_t zk_field_root_of_unity(int32_t field, uint64_t log_n, uint64_t out[4]) {
+    const FieldInfo *fi = field_info(field);
+    if (!fi) return ZK_ERR_BAD_FIELD;
+    if (!out) return ZK_ERR_BAD_ARG;
+    Fe w;
+    if (log_n > 64 || !field_root_of_unity(*fi, (uint32_t)log_n, w)) return ZK_ERR_FFT_NO_ROOT;
+    fe_to_u64limbs(w, out);
+    return ZK_OK;
+}
 extern "C" int32_t zk_fe_from_u64(int32_t field, uint64_t v, uint64_t out[4]) {
     const FieldInfo *fi = field_info(field);
     if (!fi) return ZK_ERR_BAD_FIELD;

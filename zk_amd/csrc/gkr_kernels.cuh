@@ -149,4 +149,35 @@ __global__ void k_final_evals(FactorPtrs fp, uint32_t k, const uint64_t *__restr
     fe_store(out, f, fe_sub(lo, fe_mul(r, fe_sub(lo, hi, P), P), P));
 }
 
+// ---- pieces of the multi-GPU four-step NTT (the fft crate's transform, fft/src/lib.rs:21-46, across
+// ranks).  t[j] *= scale * base^j: lane-strided geometric sequence, one exponentiation per thread then 2 multiplies per
+// element (the inter-rank twiddles omega_N^(rank*j)).
+__global__ __launch_bounds__(kBlock) void k_mul_powers(uint64_t *__restrict__ t, uint64_t n, Fe base, Fe scale, Fe step /* base^stride */,
+                                                       FieldParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock, first = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (first >= n) return;
+    Fe cur = scale, b = base;   // cur = scale * base^first by square-and-multiply
+    for (uint64_t e = first; e; e >>= 1) {
+        if (e & 1) cur = fe_mul(cur, b, P);
+        b = fe_mul(b, b, P);
+    }
+    for (uint64_t j = first; j < n; j += stride) {
+        fe_store(t, j, fe_mul(fe_load(t, j), cur, P));
+        cur = fe_mul(cur, step, P);
+    }
+}
+// out[k][j] = sum_r w^(r*k) in[r][j], r, k in [0, W): the W-point transforms ACROSS the ranks' rows, one thread per column j.
+// pw: W elements, pw[e] = w^e.
+__global__ __launch_bounds__(kBlock) void k_dft_across(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t W,
+                                                       uint64_t L, const uint64_t *__restrict__ pw, FieldParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < L; j += stride) {
+        for (uint32_t k = 0; k < W; ++k) {
+            Fe acc = fe_load(in, j);   // r = 0
+            for (uint32_t r = 1; r < W; ++r) acc = fe_add(acc, fe_mul(fe_load(in, (uint64_t)r * L + j), fe_load(pw, (r * k) & (W - 1)), P), P);
+            fe_store(out, (uint64_t)k * L + j, acc);
+        }
+    }
+}
+
 }  // namespace zk

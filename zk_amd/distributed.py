@@ -29,6 +29,15 @@ def shard_of(table, rank, world):
     return np.ascontiguousarray(t[rank::world])
 
 
+def sliced_shard_of(vector, rank, world):
+    """ShardedNtt's "sliced" layout of an (N, 4) vector: the k with k mod M in the rank's slice, as W rows of M/W
+    (local position k2*(M/W) + c  <->  k = rank*M/W + c + M*k2)."""
+    v = np.ascontiguousarray(vector, dtype=np.uint64).reshape(-1, 4)
+    m = v.shape[0] // world
+    c = m // world
+    return np.ascontiguousarray(v.reshape(world, m, 4)[:, rank * c:(rank + 1) * c].reshape(-1, 4))
+
+
 class _DevArray:
     """Zero-copy view of a device buffer for torch.as_tensor (__cuda_array_interface__ v2)."""
 
@@ -132,3 +141,108 @@ class ShardedSumcheckProver:
             gathered = tail
         b.tail_rounds(gathered)
         return b.results()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Four-step NTT across the ranks (SURVEY.md 8e "NTT does not shard without an all-to-all", 8 f4)
+# ---------------------------------------------------------------------------------------------------------------------
+class ShardedNtt:
+    """fft / ifft (fft/src/lib.rs:4-19: out[k] = sum_i in[i] * w^(i*k), w = F::get_root_of_unity(N), natural order both
+    sides) of an N = W * M point vector held by W = 2^w ranks, ONE all-to-all per transform.
+
+    Layouts.  "strided": rank r holds x[r + W*j], j in [0, M) -- the index-mod-W shard the sharded prover uses.
+    "sliced": rank s holds X[(s*M/W + c) + M*k2] at local position k2*(M/W) + c, k2 in [0, W), c in [0, M/W) -- the k with
+    k mod M in the rank's slice.  forward: strided -> sliced; inverse: sliced -> strided (so forward . pointwise . inverse
+    needs no re-layout).  With k = k1 + M*k2:
+
+        X[k1 + M*k2] = sum_r w_W^(r*k2) * ( w_N^(r*k1) * NTT_M(shard r)[k1] )
+
+    forward: local M-point NTT -> twiddle w_N^(r*k1) -> all-to-all (rank s receives the k1 of its slice from every r) ->
+    W-point transforms across the received rows.  inverse: the same steps backwards with inverse roots, scaled by 1/N.
+    backend: local_ntt(inverse), twiddle(inverse), across(inverse), send_tensor(), recv_tensor() (int64 views, M*4
+    words each), result().  Host logic only; tests drive it over gloo with a checker backend.
+    """
+
+    def __init__(self, backend, group=None):
+        self.backend, self.group = backend, group
+
+    def _exchange(self):
+        import torch.distributed as dist
+
+        b = self.backend
+        send, recv = b.send_tensor(), b.recv_tensor()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_to_all_single(recv, send, group=self.group)   # the transform's one collective: M/W elements per pair
+        else:
+            recv.copy_(send)
+
+    def forward(self):
+        b = self.backend
+        b.local_ntt(False)
+        b.twiddle(False)
+        self._exchange()
+        b.across(False)
+        return b.result()
+
+    def inverse(self):
+        b = self.backend
+        b.across(True)
+        self._exchange()
+        b.twiddle(True)
+        b.local_ntt(True)
+        return b.result()
+
+
+class GpuNttBackend:
+    """One rank's share of ShardedNtt on its GPU (zk_ntt, zk_mle_mul_powers, zk_dft_across in include/zk_amd.h).
+    shard: MultiLinearPolynomial of m variables (M = 2^m elements in this rank's layout); it is not modified."""
+
+    def __init__(self, shard, rank, world):
+        import torch
+
+        from .api import MultiLinearPolynomial, fe_from_int, fe_to_int, modulus, root_of_unity
+
+        self.ctx, self.rank, self.world = shard.ctx, rank, world
+        self.log_w = world.bit_length() - 1
+        if world != 1 << self.log_w:
+            raise ValueError("world size must be a power of two")
+        self.m = shard.n_vars()
+        if self.m < self.log_w:
+            raise ValueError("a shard needs at least `world` elements")
+        self.ctx.use_torch_stream()   # kernels and the all-to-all are ordered on one stream
+        self.field = self.ctx.field
+        p = modulus(self.field)
+        w_n = fe_to_int(self.field, root_of_unity(self.field, self.m + self.log_w))
+        self._tw = {False: fe_from_int(self.field, pow(w_n, rank, p)),
+                    True: fe_from_int(self.field, pow(pow(w_n, -1, p), rank, p))}
+        self._scale = {False: fe_from_int(self.field, 1), True: fe_from_int(self.field, pow(world, -1, p))}
+        self.src = shard
+        self.a = MultiLinearPolynomial.alloc(self.ctx, self.m)
+        self.b = MultiLinearPolynomial.alloc(self.ctx, self.m)
+        dev = f"cuda:{self.ctx.device}"
+        self._ta = torch.as_tensor(_DevArray(self.a.device_ptr(), (1 << self.m) * 4), device=dev)
+        self._tb = torch.as_tensor(_DevArray(self.b.device_ptr(), (1 << self.m) * 4), device=dev)
+        self._out = None
+
+    # forward: src -NTT-> a -twiddle-> a =exchange=> b -across-> a        inverse: src -across-> a =exchange=> b -twiddle-> b -iNTT-> a
+    def local_ntt(self, inverse):
+        check(lib.zk_ntt(self.ctx._h, (self.b if inverse else self.src)._h, int(inverse), self.a._h))
+        self._out = self.a
+
+    def twiddle(self, inverse):
+        t = self.b if inverse else self.a
+        check(lib.zk_mle_mul_powers(self.ctx._h, t._h, self._tw[inverse].ctypes.data_as(u64p),
+                                    self._scale[inverse].ctypes.data_as(u64p)))
+
+    def across(self, inverse):
+        check(lib.zk_dft_across(self.ctx._h, (self.src if inverse else self.b)._h, self.a._h, self.log_w, int(inverse)))
+        self._out = self.a
+
+    def send_tensor(self):
+        return self._ta
+
+    def recv_tensor(self):
+        return self._tb
+
+    def result(self):
+        return self._out
