@@ -689,6 +689,20 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
     if (fast_degree(D)) {
         uint32_t total = 0;
         int first = 0;
+        if (ts.n_terms == 2 && ts.term_k[1] == 1) {   // product + one single-factor term (a GKR layer): one pass
+            uint32_t g = 0;
+            const int lrc = launch_round_plus1(launch_ctx(c), fp, ts.term_k[0], q, D, fused, d_r, &g);
+            if (lrc == kLaunchHipError) {
+                g_hip_err = "round kernel launch failed";
+                return ZK_ERR_HIP;
+            }
+            if (lrc == kLaunchOk) {
+                k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, g, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
+                                                          tt.lanes, P);
+                HIPCHK(hipGetLastError());
+                return ZK_OK;
+            }
+        }
         for (int i = 0; i < ts.n_terms; ++i) {
             FactorPtrs sub = {};
             for (int f = 0; f < ts.term_k[i]; ++f) {

@@ -110,16 +110,19 @@ __global__ __launch_bounds__(kBlock) void k_round(FactorPtrs fp, int k, uint64_t
 //  * the host sizes the grid so that a thread handles at most kMaxLazy pairs: the unreduced accumulators are reduced
 //    once, after the loop (no flush path, no separate running sums in registers);
 //  * factor indices are template parameters (round_factor<F>), so every array index is static and nothing spills.
-template <int K, int D, bool FUSED>
+// EXTRA = 1 adds a second, single-factor term to the sum (table index K): S_t = sum_x (prod_{f<K} P_f(t,x) + P_K(t,x)) --
+// the GKR layer polynomial W*H + B in ONE pass instead of a second launch per round (zk_sumcheck_prove_terms, terms {K, 1}).
+template <int K, int D, bool FUSED, int EXTRA = 0>
 struct RoundRegs {
     static constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
-    Fe cur[K][NL];
+    Fe cur[K + EXTRA][NL];
     Fe prod[NS];
     Fe sum[NS];
+    Fe sum_b[EXTRA ? NS : 1];
     WideAcc acc[K > 1 ? NS : 1];
 };
-template <int F, int K, int D, bool FUSED>
-ZK_D void round_factor(RoundRegs<K, D, FUSED> &R, const FactorPtrs &fp, uint64_t j, uint64_t jn, bool more, uint64_t q,
+template <int F, int K, int D, bool FUSED, int EXTRA>
+ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, uint64_t j, uint64_t jn, bool more, uint64_t q,
                        const Mul29 &r, const FieldParams &P) {
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
     Fe lo, hi;
@@ -142,45 +145,52 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED> &R, const FactorPtrs &fp, uint64_t
     for (int t = 0; t < NS; ++t) {
         if (t == 1) v = hi;
         else if (t > 1) v = fe_add(v, diff, P);
-        if (K == 1) R.sum[t] = fe_add(R.sum[t], v, P);
+        if (F == K) R.sum_b[t] = fe_add(R.sum_b[t], v, P);            // the extra single-factor term
+        else if (K == 1) R.sum[t] = fe_add(R.sum[t], v, P);
         else if (F == 0) R.prod[t] = v;
         else if (F < K - 1) R.prod[t] = fe_mul(R.prod[t], v, P);
         else wide_mac(R.acc[t], R.prod[t].v, v.v);
     }
 }
-// K <= 2 fits 2 waves per SIMD (<= 256 VGPRs); K >= 3 keeps K*4 elements in flight and gets the whole register file.
-template <int K, int D, bool FUSED>
-__global__ __launch_bounds__(kBlock, (K <= 2 ? 2 : 1)) void k_round_kd(FactorPtrs fp, uint64_t q, FieldParams P,
+// K <= 2 fits 2 waves per SIMD (<= 256 VGPRs); K >= 3 (or an extra term) keeps >= 12 elements in flight and gets the whole
+// register file.
+template <int K, int D, bool FUSED, int EXTRA = 0>
+__global__ __launch_bounds__(kBlock, (K + EXTRA <= 2 ? 2 : 1)) void k_round_kd(FactorPtrs fp, uint64_t q, FieldParams P,
                                                         const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials) {
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
     Mul29 r = {};
     if (FUSED) r = load_challenge29(rptr);
-    RoundRegs<K, D, FUSED> R;
+    RoundRegs<K, D, FUSED, EXTRA> R;
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
         R.sum[t] = fe_zero();
+        if (EXTRA) R.sum_b[t] = fe_zero();
         if (K > 1) wide_zero(R.acc[t]);
     }
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j < q) {
 #pragma unroll
-        for (int f = 0; f < K; ++f)
+        for (int f = 0; f < K + EXTRA; ++f)
 #pragma unroll
             for (int l = 0; l < NL; ++l) R.cur[f][l] = fe_load(fp.in[f], j + (uint64_t)l * q);
     }
     while (j < q) {
         const uint64_t jn = j + stride;
         const bool more = jn < q;
-        round_factor<0, K, D, FUSED>(R, fp, j, jn, more, q, r, P);
-        if constexpr (K > 1) round_factor<1, K, D, FUSED>(R, fp, j, jn, more, q, r, P);
-        if constexpr (K > 2) round_factor<2, K, D, FUSED>(R, fp, j, jn, more, q, r, P);
-        if constexpr (K > 3) round_factor<3, K, D, FUSED>(R, fp, j, jn, more, q, r, P);
+        round_factor<0, K, D, FUSED, EXTRA>(R, fp, j, jn, more, q, r, P);
+        if constexpr (K + EXTRA > 1) round_factor<1, K, D, FUSED, EXTRA>(R, fp, j, jn, more, q, r, P);
+        if constexpr (K + EXTRA > 2) round_factor<2, K, D, FUSED, EXTRA>(R, fp, j, jn, more, q, r, P);
+        if constexpr (K + EXTRA > 3) round_factor<3, K, D, FUSED, EXTRA>(R, fp, j, jn, more, q, r, P);
         j = jn;
     }
     if (K > 1) {
 #pragma unroll
         for (int t = 0; t < NS; ++t) R.sum[t] = redc_wide(R.acc[t], P);
+    }
+    if (EXTRA) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) R.sum[t] = fe_add(R.sum[t], R.sum_b[t], P);
     }
     block_reduce_store<NS>(R.sum, partials, P);
 }

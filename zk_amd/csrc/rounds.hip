@@ -72,6 +72,26 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
     return kLaunchOk;
 }
 
+// Terms {k, 1}: the k-factor product plus one single-factor term in one pass (fp lists the k factors, then the extra one).
+int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused,
+                       const uint64_t *d_r, uint32_t *out_grid) {
+    const uint32_t g = round_grid(q);
+    if ((uint64_t)g * (D + 1) > lc.capacity_elems) return kLaunchUnsupported;
+    const int shape = k * 10 + (int)D;
+    if (shape == 22) {
+        if (fused) k_round_kd<2, 2, true, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        else k_round_kd<2, 2, false, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+    } else if (shape == 33) {
+        if (fused) k_round_kd<3, 3, true, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        else k_round_kd<3, 3, false, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+    } else {
+        return kLaunchUnsupported;
+    }
+    if (hipGetLastError() != hipSuccess) return kLaunchHipError;
+    *out_grid = g;
+    return kLaunchOk;
+}
+
 int launch_round_single_t(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, const Fe &tval, uint32_t *out_grid) {
     const uint32_t g = capped_grid(q);
     k_round_single_t<<<g, kBlock, 0, lc.stream>>>(fp, k, q, *lc.P, tval, lc.d_partials);
