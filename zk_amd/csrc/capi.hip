@@ -34,6 +34,8 @@ struct zk_ctx {
     uint64_t *d_partials;   // per-block partial sums of a round: kMaxGrid * kMaxSums elements
     uint64_t *d_sums;       // final round sums (kMaxSums elements) + lanes area
     uint64_t *h_pinned;     // pinned staging: kMaxSums*8 u64
+    uint8_t *h_results;     // pinned staging for proofs (grown on demand)
+    size_t h_results_bytes;
     hipEvent_t ev0, ev1;
     std::map<std::pair<uint32_t, int>, uint64_t *> twiddles;   // (log_n, inverse) -> omega^i table, i < n/2 (n < 2^8 path)
     std::map<std::pair<uint32_t, int>, NttPlan> ntt_plans;     // (log_n, inverse) -> pass plan + two-level twiddle tables
@@ -227,6 +229,8 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     c->fi = fi;
     c->own_stream = nullptr;
     c->d_partials = c->d_sums = c->h_pinned = nullptr;
+    c->h_results = nullptr;
+    c->h_results_bytes = 0;
     c->pool_bytes = 0;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -255,6 +259,7 @@ extern "C" int32_t zk_ctx_destroy(zk_ctx *c) {
     (void)hipFree(c->d_partials);
     (void)hipFree(c->d_sums);
     (void)hipHostFree(c->h_pinned);
+    if (c->h_results) (void)hipHostFree(c->h_results);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->own_stream);
@@ -643,24 +648,41 @@ struct ProverScratch {
     uint64_t *d_challenge;   // 1 element, Montgomery
     uint64_t *d_rp;          // rounds * (D+1) elements
     uint64_t *d_ch;          // rounds elements
+    uint64_t *d_final;       // kMaxFactors elements (same block as d_rp, d_ch)
     size_t rp_bytes, ch_bytes;
 };
+// The proof being assembled is ONE device block [round polys | challenges | factor values at the point] so that it comes
+// back in one copy (through pinned memory: a device-to-pageable copy blocks the host once per call).
 static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint32_t D) {
     ps = {};
     ps.rp_bytes = (size_t)(rounds ? rounds : 1) * (D + 1) * 32;
     ps.ch_bytes = (size_t)(rounds ? rounds : 1) * 32;
     ZKCHK(pool_alloc(c, sizeof(WordSponge), (void **)&ps.d_sponge));
     ZKCHK(pool_alloc(c, kChallengeBytes, (void **)&ps.d_challenge));
-    ZKCHK(pool_alloc(c, ps.rp_bytes, (void **)&ps.d_rp));
-    ZKCHK(pool_alloc(c, ps.ch_bytes, (void **)&ps.d_ch));
+    ZKCHK(pool_alloc(c, ps.rp_bytes + ps.ch_bytes + kMaxFactors * 32, (void **)&ps.d_rp));
+    ps.d_ch = ps.d_rp + ps.rp_bytes / 8;
+    ps.d_final = ps.d_ch + ps.ch_bytes / 8;
     return ZK_OK;
 }
 static void scratch_free(zk_ctx *c, ProverScratch &ps) {
     pool_free(c, ps.d_sponge, sizeof(WordSponge));
     pool_free(c, ps.d_challenge, kChallengeBytes);
-    pool_free(c, ps.d_rp, ps.rp_bytes);
-    pool_free(c, ps.d_ch, ps.ch_bytes);
+    pool_free(c, ps.d_rp, ps.rp_bytes + ps.ch_bytes + kMaxFactors * 32);
     ps = {};
+}
+// pinned staging for results, grown on demand
+static int32_t results_staging(zk_ctx *c, size_t bytes, uint8_t **out) {
+    if (c->h_results_bytes < bytes) {
+        if (c->h_results) (void)hipHostFree(c->h_results);
+        c->h_results = nullptr;
+        c->h_results_bytes = 0;
+        size_t cap = 1 << 16;
+        while (cap < bytes) cap <<= 1;
+        HIPCHK(hipHostMalloc((void **)&c->h_results, cap, hipHostMallocDefault));
+        c->h_results_bytes = cap;
+    }
+    *out = c->h_results;
+    return ZK_OK;
 }
 
 static inline RoundLaunchCtx launch_ctx(zk_ctx *c) {
@@ -856,7 +878,7 @@ struct RoundState {
     size_t scratch_bytes[kMaxFactors];
     ProverScratch ps;
     TermSpec terms;                   // how the k flat factors group into products (one term = ProductPoly)
-    uint64_t *d_final;                // optional (owned): k elements, the factors at the challenge point
+    uint64_t *d_final;                // optional (= ps.d_final when requested): the factors at the challenge point
 };
 static void round_state_release(RoundState &st) {
     for (uint64_t i = 0; i < (uint64_t)kMaxFactors; ++i)
@@ -864,10 +886,7 @@ static void round_state_release(RoundState &st) {
             pool_free(st.c, st.scratch[i], st.scratch_bytes[i]);
             st.scratch[i] = nullptr;
         }
-    if (st.d_final) {
-        pool_free(st.c, st.d_final, kMaxFactors * 32);
-        st.d_final = nullptr;
-    }
+    st.d_final = nullptr;
     scratch_free(st.c, st.ps);
 }
 static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uint64_t k, uint32_t D, bool consume,
@@ -1010,19 +1029,23 @@ static inline bool finish_applies(const RoundState &st) {
     return after >= 1 && after <= (uint64_t)kFinishVars;
 }
 
-// host byte sponge (table + claimed sum absorbed) -> device word sponge
+// host byte sponge (table + claimed sum absorbed) -> device word sponge.  The 208-byte state travels as a kernel argument:
+// no staging buffer, no copy engine, no host synchronisation in front of the first round.
 static int32_t sponge_to_device(zk_ctx *c, const Sponge &host, WordSponge *d_sponge) {
-    WordSponge *w = reinterpret_cast<WordSponge *>(c->h_pinned);
-    if (!w->from_byte_sponge(host)) return ZK_ERR_BAD_ARG;
-    HIPCHK(hipMemcpyAsync(d_sponge, w, sizeof(WordSponge), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));   // h_pinned is reused
+    WordSponge w;
+    if (!w.from_byte_sponge(host)) return ZK_ERR_BAD_ARG;
+    k_store_sponge<<<1, 64, 0, c->stream>>>(w, d_sponge);
+    HIPCHK(hipGetLastError());
     return ZK_OK;
 }
 
 // The prover for sum_i prod_{f in term i} T_f (one term = the reference's ProductPoly).  out_final (optional): the k
 // factors evaluated at the challenge point.
+// d_keep_ch / d_keep_final (optional, DEVICE buffers of n / k elements): device-resident copies of the challenges and of the
+// factor values, for a caller that chains further device work on them without a host round trip (the GKR driver).
 static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpec &ts, uint32_t D, const uint64_t sum[4],
-                          int32_t absorb_table, int32_t consume, uint64_t *out_rp, uint64_t *out_ch, uint64_t *out_final) {
+                          int32_t absorb_table, int32_t consume, uint64_t *out_rp, uint64_t *out_ch, uint64_t *out_final,
+                          uint64_t *d_keep_ch = nullptr, uint64_t *d_keep_final = nullptr) {
     if (!sum) return ZK_ERR_BAD_ARG;
     ZKCHK(product_args(c, (const zk_mle *const *)f, k));
     if (f[0]->n_vars && (!out_rp || !out_ch)) return ZK_ERR_BAD_ARG;
@@ -1042,7 +1065,7 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
     ZKCHK(round_state_init(st, c, f, k, D, consume != 0, n));
     st.terms = ts;
     int32_t rc = ZK_OK;
-    if (out_final) rc = pool_alloc(c, kMaxFactors * 32, (void **)&st.d_final);
+    if (out_final) st.d_final = st.ps.d_final;
     if (rc == ZK_OK) rc = sponge_to_device(c, sp, st.ps.d_sponge);
     bool finished_in_kernel = false;
     while (st.round < n && rc == ZK_OK) {                                // prover.rs:44-68, all on device
@@ -1062,17 +1085,25 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
             k_final_evals<<<1, 64, 0, c->stream>>>(fp, (uint32_t)k, st.ps.d_challenge, st.d_final, P);
             if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
         }
-        if (rc == ZK_OK && hipMemcpyAsync(out_final, st.d_final, (size_t)k * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
-            rc = ZK_ERR_HIP;
     }
-    if (rc == ZK_OK) {
-        if (hipMemcpyAsync(out_rp, st.ps.d_rp, (size_t)n * (D + 1) * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipMemcpyAsync(out_ch, st.ps.d_ch, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
-            rc = ZK_ERR_HIP;
-    }
+    if (rc == ZK_OK && d_keep_ch && hipMemcpyAsync(d_keep_ch, st.ps.d_ch, (size_t)n * 32, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+        rc = ZK_ERR_HIP;
+    if (rc == ZK_OK && d_keep_final && out_final &&
+        hipMemcpyAsync(d_keep_final, st.ps.d_final, (size_t)k * 32, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+        rc = ZK_ERR_HIP;
+    // one copy of [round polys | challenges | finals] into pinned memory, one synchronisation
+    uint8_t *stage = nullptr;
+    const size_t block = st.ps.rp_bytes + st.ps.ch_bytes + kMaxFactors * 32;
+    if (rc == ZK_OK) rc = results_staging(c, block, &stage);
+    if (rc == ZK_OK && hipMemcpyAsync(stage, st.ps.d_rp, block, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ZK_ERR_HIP;
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == ZK_OK) {
         g_hip_err = "sumcheck: stream synchronize failed";
         rc = ZK_ERR_HIP;
+    }
+    if (rc == ZK_OK) {
+        memcpy(out_rp, stage, (size_t)n * (D + 1) * 32);
+        memcpy(out_ch, stage + st.ps.rp_bytes, (size_t)n * 32);
+        if (out_final) memcpy(out_final, stage + st.ps.rp_bytes + st.ps.ch_bytes, (size_t)k * 32);
     }
     round_state_release(st);
     return rc;

@@ -17,16 +17,15 @@
 namespace zk {
 
 // eq(point, .) over nv variables by direct products (small tables only: nv muls per entry):
-// out[j] = scale * prod_w (bit_{nv-1-w}(j) ? g_w : 1 - g_w), scale = *d_scale or 1
-__global__ __launch_bounds__(kBlock) void k_eq_direct(const uint64_t *__restrict__ point, uint32_t nv,
-                                                      const uint64_t *__restrict__ d_scale, uint64_t *__restrict__ out,
-                                                      FieldParams P) {
+// out[j] = scale * prod_w (bit_{nv-1-w}(j) ? g_w : 1 - g_w)
+__global__ __launch_bounds__(kBlock) void k_eq_direct(const uint64_t *__restrict__ point, uint32_t nv, Fe scale,
+                                                      uint64_t *__restrict__ out, FieldParams P) {
     const uint64_t n = 1ull << nv, stride = (uint64_t)gridDim.x * kBlock;
     Fe one;
 #pragma unroll
     for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
     for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
-        Fe acc = d_scale ? fe_load(d_scale, 0) : one;
+        Fe acc = scale;
         for (uint32_t w = 0; w < nv; ++w) {
             const Fe g = fe_load(point, w);
             const bool bit = (j >> (nv - 1 - w)) & 1;
@@ -44,6 +43,40 @@ __global__ __launch_bounds__(kBlock) void k_eq_outer(const uint64_t *__restrict_
         Fe v = fe_mul(fe_load(hi, j >> lo_bits), fe_load(lo, j & mask), P);
         if (ACCUMULATE) v = fe_add(v, fe_load(out, j), P);
         fe_store(out, j, v);
+    }
+}
+
+// eq(point, .) in ONE launch for m <= 30: the m variables split into three groups (high, middle, low index bits); every
+// workgroup builds the three small direct tables in LDS (<= 2^10 entries each, scale folded into the first), then
+// out[idx] (+)= T0[i0] * T1[i1] * T2[i2], two multiplies per element, point read from DEVICE memory (no host staging).
+template <bool ACCUMULATE>
+__global__ __launch_bounds__(kBlock) void k_eq_table3(const uint64_t *__restrict__ point, uint32_t m, Fe scale,
+                                                      uint64_t *__restrict__ out, FieldParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char eq_smem[];
+    uint64_t *tab = reinterpret_cast<uint64_t *>(eq_smem);
+    const uint32_t g0 = (m + 2) / 3, g1 = (m + 1) / 3, g2 = m / 3;   // g0 >= g1 >= g2, g0 + g1 + g2 = m
+    const uint32_t n0 = 1u << g0, n1 = 1u << g1, n2 = 1u << g2;
+    Fe one;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
+    for (uint32_t e = threadIdx.x; e < n0 + n1 + n2; e += kBlock) {
+        const uint32_t grp = e < n0 ? 0 : (e < n0 + n1 ? 1 : 2);
+        const uint32_t j = grp == 0 ? e : (grp == 1 ? e - n0 : e - n0 - n1);
+        const uint32_t nv = grp == 0 ? g0 : (grp == 1 ? g1 : g2), first = grp == 0 ? 0 : (grp == 1 ? g0 : g0 + g1);
+        Fe acc = grp == 0 ? scale : one;
+        for (uint32_t w = 0; w < nv; ++w) {
+            const Fe g = fe_load(point, first + w);
+            acc = fe_mul(acc, ((j >> (nv - 1 - w)) & 1) ? g : fe_sub(one, g, P), P);
+        }
+        fe_store(tab, e, acc);
+    }
+    __syncthreads();
+    const uint64_t n = 1ull << m, stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < n; idx += stride) {
+        const uint32_t i0 = (uint32_t)(idx >> (g1 + g2)), i1 = (uint32_t)(idx >> g2) & (n1 - 1), i2 = (uint32_t)idx & (n2 - 1);
+        Fe v = fe_mul(fe_mul(fe_load(tab, i0), fe_load(tab, n0 + i1), P), fe_load(tab, n0 + n1 + i2), P);
+        if (ACCUMULATE) v = fe_add(v, fe_load(out, idx), P);
+        fe_store(out, idx, v);
     }
 }
 

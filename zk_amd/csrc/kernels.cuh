@@ -691,6 +691,15 @@ __global__ __launch_bounds__(kBlock) void k_finish_terms(FactorPtrs fp, TermSpec
     }
 }
 
+// the prover's initial sponge state, passed by value in the kernel arguments
+__global__ void k_store_sponge(WordSponge w, WordSponge *__restrict__ dst) {
+    if (threadIdx.x < 25) dst->s[threadIdx.x] = w.s[threadIdx.x];
+    if (threadIdx.x == 0) {
+        dst->pos = w.pos;
+        dst->pad_ = 0;
+    }
+}
+
 // Sharded prover, after the all-reduce: lanes hold sums over ranks of 32-bit digits.  Carry-propagate, reduce mod p
 // (value < world * p, world <= 2^16), then the same transcript step.  One lane.
 __global__ void k_lanes_transcript(const uint64_t *__restrict__ lanes, uint32_t ns, WordSponge *__restrict__ sponge,
