@@ -46,38 +46,37 @@ __global__ __launch_bounds__(kBlock) void k_eq_outer(const uint64_t *__restrict_
     }
 }
 
-// eq(point, .) in ONE launch for m <= 30: the m variables split into three groups (high, middle, low index bits); every
-// workgroup builds the three small direct tables in LDS (<= 2^10 entries each, scale folded into the first), then
-// out[idx] (+)= T0[i0] * T1[i1] * T2[i2], two multiplies per element, point read from DEVICE memory (no host staging).
-template <bool ACCUMULATE>
-__global__ __launch_bounds__(kBlock) void k_eq_table3(const uint64_t *__restrict__ point, uint32_t m, Fe scale,
-                                                      uint64_t *__restrict__ out, FieldParams P) {
+// The two half tables of eq(point, .) for m <= 30 in one launch: workgroup 0 builds hi (the first m/2 variables, scale
+// folded in), workgroup 1 builds lo.  A half of nv <= 15 variables is itself the outer product of two quarter tables that
+// are built by direct products in LDS (<= 8 dependent multiplies), so the whole chain is <= 9 multiplies deep; the point
+// is read from DEVICE memory once.  k_eq_outer then needs ONE multiply per element of the full table.
+__global__ __launch_bounds__(kBlock) void k_eq_halves(const uint64_t *__restrict__ point, uint32_t m, Fe scale,
+                                                      uint64_t *__restrict__ d_hi, uint64_t *__restrict__ d_lo, FieldParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char eq_smem[];
-    uint64_t *tab = reinterpret_cast<uint64_t *>(eq_smem);
-    const uint32_t g0 = (m + 2) / 3, g1 = (m + 1) / 3, g2 = m / 3;   // g0 >= g1 >= g2, g0 + g1 + g2 = m
-    const uint32_t n0 = 1u << g0, n1 = 1u << g1, n2 = 1u << g2;
+    const uint32_t hi_bits = m / 2, lo_bits = m - hi_bits;
+    const bool is_hi = blockIdx.x == 0;
+    const uint32_t nv = is_hi ? hi_bits : lo_bits, first = is_hi ? 0 : hi_bits;
+    const uint32_t a = nv / 2, b = nv - a, na = 1u << a, nb = 1u << b;
+    uint64_t *qa = reinterpret_cast<uint64_t *>(eq_smem), *qb = qa + (size_t)na * 4, *pt = qb + (size_t)nb * 4;
     Fe one;
 #pragma unroll
     for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
-    for (uint32_t e = threadIdx.x; e < n0 + n1 + n2; e += kBlock) {
-        const uint32_t grp = e < n0 ? 0 : (e < n0 + n1 ? 1 : 2);
-        const uint32_t j = grp == 0 ? e : (grp == 1 ? e - n0 : e - n0 - n1);
-        const uint32_t nv = grp == 0 ? g0 : (grp == 1 ? g1 : g2), first = grp == 0 ? 0 : (grp == 1 ? g0 : g0 + g1);
-        Fe acc = grp == 0 ? scale : one;
-        for (uint32_t w = 0; w < nv; ++w) {
-            const Fe g = fe_load(point, first + w);
-            acc = fe_mul(acc, ((j >> (nv - 1 - w)) & 1) ? g : fe_sub(one, g, P), P);
-        }
-        fe_store(tab, e, acc);
+    if (threadIdx.x < nv) {   // (1 - g, g) pairs of this half's variables
+        const Fe g = fe_load(point, first + threadIdx.x);
+        fe_store(pt, 2 * threadIdx.x, fe_sub(one, g, P));
+        fe_store(pt, 2 * threadIdx.x + 1, g);
     }
     __syncthreads();
-    const uint64_t n = 1ull << m, stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < n; idx += stride) {
-        const uint32_t i0 = (uint32_t)(idx >> (g1 + g2)), i1 = (uint32_t)(idx >> g2) & (n1 - 1), i2 = (uint32_t)idx & (n2 - 1);
-        Fe v = fe_mul(fe_mul(fe_load(tab, i0), fe_load(tab, n0 + i1), P), fe_load(tab, n0 + n1 + i2), P);
-        if (ACCUMULATE) v = fe_add(v, fe_load(out, idx), P);
-        fe_store(out, idx, v);
+    for (uint32_t e = threadIdx.x; e < na + nb; e += kBlock) {
+        const bool in_a = e < na;
+        const uint32_t j = in_a ? e : e - na, cnt = in_a ? a : b, off = in_a ? 0 : a;
+        Fe acc = (in_a && is_hi) ? scale : one;
+        for (uint32_t w = 0; w < cnt; ++w) acc = fe_mul(acc, fe_load(pt, 2 * (off + w) + ((j >> (cnt - 1 - w)) & 1)), P);
+        fe_store(in_a ? qa : qb, j, acc);
     }
+    __syncthreads();
+    uint64_t *dst = is_hi ? d_hi : d_lo;
+    for (uint32_t i = threadIdx.x; i < (1u << nv); i += kBlock) fe_store(dst, i, fe_mul(fe_load(qa, i >> b), fe_load(qb, i & (nb - 1)), P));
 }
 
 // layer evaluation: out[z] = W[left[z]] (+|*) W[right[z]]
