@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel-trace + stats for the prover (n=24 and n=20) and the NTT: summaries for profiles/
+# kernel-trace + stats for the prover (n=24 and n=20), the NTT and the GKR driver: summaries for profiles/ (tools/summarize_prof_all.py)
 set -u
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_all
@@ -15,4 +15,5 @@ PY
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sumcheck_n24 -- python3 tools/prof_sumcheck.py 24 5 > $OUT/sumcheck_n24.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sumcheck_n20 -- python3 tools/prof_sumcheck.py 20 5 > $OUT/sumcheck_n20.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ntt -- python3 /tmp/ntt_run.py > $OUT/ntt.log 2>&1 || exit 1
-grep -h "^n \|ntt ms" $OUT/*.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/gkr -- python3 tools/prof_gkr.py 20 8 > $OUT/gkr.log 2>&1 || exit 1
+grep -h "^n \|ntt ms\|prove ms\|verify ms" $OUT/*.log
