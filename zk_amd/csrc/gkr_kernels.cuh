@@ -9,8 +9,8 @@
 //                      layer polynomial  P1(x) = W(x)*H(x) + B1(x)
 //   phase 2 (over y):  A2[y] = sum_{add (z,x,y)} E[z]*eq_u[x],  M2[y] = sum_{mul (z,x,y)} E[z]*eq_u[x]
 //                      H2 = A2 + W(u)*M2,  C2 = W(u)*A2,   P2(y) = W(y)*H2(y) + C2(y)
-// Rows are walked through a CSR index of the gate list (by left input / by right input) built once at upload: no
-// atomics on 256-bit values, one thread per row.
+// Rows are walked through a CSR index of the gate list (by left input / by right input) built once at upload, whose
+// entries carry the gate's output index, other input and op: no atomics on 256-bit values, one thread per row.
 #pragma once
 #include "common.cuh"
 
@@ -90,9 +90,10 @@ __global__ __launch_bounds__(kBlock) void k_gkr_forward(const uint8_t *__restric
     }
 }
 
-// phase 1 bookkeeping: one thread per x (row of the by-left CSR)
-__global__ __launch_bounds__(kBlock) void k_gkr_phase1(const uint32_t *__restrict__ lptr, const uint32_t *__restrict__ lperm,
-                                                       const uint8_t *__restrict__ op, const uint32_t *__restrict__ right,
+// phase 1 bookkeeping: one thread per x (row of the by-left CSR).  A CSR entry is {z, other | op << 31}: the gate's
+// output index and its OTHER input (right for the by-left index), so a row needs no second indirection through the gate
+// arrays -- the only random accesses left are the two 32-byte elements E[z] and W[y].
+__global__ __launch_bounds__(kBlock) void k_gkr_phase1(const uint32_t *__restrict__ lptr, const uint2 *__restrict__ lent,
                                                        const uint64_t *__restrict__ E, const uint64_t *__restrict__ W,
                                                        uint64_t n_in, uint64_t *__restrict__ H, uint64_t *__restrict__ B1,
                                                        FieldParams P) {
@@ -100,9 +101,9 @@ __global__ __launch_bounds__(kBlock) void k_gkr_phase1(const uint32_t *__restric
     for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < n_in; x += stride) {
         Fe h = fe_zero(), b = fe_zero();
         for (uint32_t e = lptr[x]; e < lptr[x + 1]; ++e) {
-            const uint32_t z = lperm[e];
-            const Fe ez = fe_load(E, z), t = fe_mul(ez, fe_load(W, right[z]), P);
-            if (op[z]) {
+            const uint2 ent = lent[e];
+            const Fe ez = fe_load(E, ent.x), t = fe_mul(ez, fe_load(W, ent.y & 0x7FFFFFFFu), P);
+            if (ent.y >> 31) {
                 h = fe_add(h, t, P);
             } else {
                 h = fe_add(h, ez, P);
@@ -113,9 +114,8 @@ __global__ __launch_bounds__(kBlock) void k_gkr_phase1(const uint32_t *__restric
         fe_store(B1, x, b);
     }
 }
-// phase 2 bookkeeping: one thread per y (row of the by-right CSR); wu = W(u), one device element
-__global__ __launch_bounds__(kBlock) void k_gkr_phase2(const uint32_t *__restrict__ rptr, const uint32_t *__restrict__ rperm,
-                                                       const uint8_t *__restrict__ op, const uint32_t *__restrict__ left,
+// phase 2 bookkeeping: one thread per y (row of the by-right CSR, entries {z, left | op << 31}); wu = W(u), one device element
+__global__ __launch_bounds__(kBlock) void k_gkr_phase2(const uint32_t *__restrict__ rptr, const uint2 *__restrict__ rent,
                                                        const uint64_t *__restrict__ E, const uint64_t *__restrict__ eq_u,
                                                        const uint64_t *__restrict__ wu, uint64_t n_in,
                                                        uint64_t *__restrict__ H2, uint64_t *__restrict__ C2, FieldParams P) {
@@ -124,9 +124,9 @@ __global__ __launch_bounds__(kBlock) void k_gkr_phase2(const uint32_t *__restric
     for (uint64_t y = (uint64_t)blockIdx.x * kBlock + threadIdx.x; y < n_in; y += stride) {
         Fe a = fe_zero(), m = fe_zero();
         for (uint32_t e = rptr[y]; e < rptr[y + 1]; ++e) {
-            const uint32_t z = rperm[e];
-            const Fe t = fe_mul(fe_load(E, z), fe_load(eq_u, left[z]), P);
-            if (op[z]) m = fe_add(m, t, P);
+            const uint2 ent = rent[e];
+            const Fe t = fe_mul(fe_load(E, ent.x), fe_load(eq_u, ent.y & 0x7FFFFFFFu), P);
+            if (ent.y >> 31) m = fe_add(m, t, P);
             else a = fe_add(a, t, P);
         }
         fe_store(H2, y, fe_add(a, fe_mul(w, m, P), P));
