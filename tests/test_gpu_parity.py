@@ -469,3 +469,18 @@ def test_config_24var_fold_properties():
         hi = orc.fill_random(field, 0x5EED0000 + 24, 1, first_index=j + half)[0]
         want = orc.sub(field, lo, orc.mul(field, pt[0], orc.sub(field, lo, hi)))
         assert np.array_equal(got[j], want)
+
+
+def test_skip1_rounds_bit_exact():
+    """Big fused rounds leave out the t = 1 sums and derive S(1) from the previous round's claim (k_round_kd SKIP1,
+    TailDerive).  A child process with the threshold forced to 1 pair proves the (k, D) grid that way and compares every
+    proof with the oracle bit for bit (tests/skip1_check.py)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZK_SKIP1_MIN_PAIRS="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "skip1_check.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "skip1 ok" in r.stdout, r.stdout + r.stderr

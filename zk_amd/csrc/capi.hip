@@ -35,6 +35,7 @@ struct zk_ctx {
     uint64_t *d_sums;       // final round sums (kMaxSums elements) + lanes area
     uint64_t *h_pinned;     // pinned staging: kMaxSums*8 u64
     uint8_t *h_results;     // pinned staging for proofs (grown on demand)
+    std::map<uint32_t, std::vector<Fe>> lagrange_w;   // interp_weights(D), cached (a field inversion per node)
     size_t h_results_bytes;
     hipEvent_t ev0, ev1;
     std::map<std::pair<uint32_t, int>, uint64_t *> twiddles;   // (log_n, inverse) -> omega^i table, i < n/2 (n < 2^8 path)
@@ -699,32 +700,45 @@ struct TailTargets {
     uint64_t *d_challenge;  // challenge for the next fused fold
     uint64_t *lanes;        // 32-bit digit lanes for the cross-GPU all-reduce, may be null
 };
+static std::vector<Fe> interp_weights(uint32_t D, const FieldParams &P);   // defined with the verifier
+// Rounds with at least this many pairs leave out the t = 1 sums (k_round_kd SKIP1 + TailDerive): below it the extra
+// D + 1 dependent multiplies in the tail cost more than the products they save.  ZK_SKIP1_MIN_PAIRS overrides (tests).
+static uint64_t skip1_min_pairs() {
+    static const uint64_t v = [] {
+        const char *e = getenv("ZK_SKIP1_MIN_PAIRS");
+        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)1 << 17;
+    }();
+    return v;
+}
 static inline TermSpec single_term(int k) {
     TermSpec ts = {1, {k, 0, 0, 0}};
     return ts;
 }
 // sums of the current tables (already folded) -> targets.  Handles every degree.  With several terms each term's round
 // kernel writes its own range of block partials and the one tail reduction adds them all (the sum over terms is free).
+// dv (optional): previous round polynomial + Lagrange weights; allows the big fused rounds to skip the t = 1 sums.
 static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, uint64_t q, uint32_t D, bool fused,
-                           const uint64_t *d_r, const TailTargets &tt) {
+                           const uint64_t *d_r, const TailTargets &tt, const TailDerive *dv = nullptr) {
     const FieldParams &P = c->fi->P;
     if (fast_degree(D)) {
         uint32_t total = 0;
         int first = 0;
+        bool skip1 = dv && dv->prev_rp && fused && !tt.lanes && D <= (uint32_t)kMaxSkipDegree && q >= skip1_min_pairs();
         if (ts.n_terms == 2 && ts.term_k[1] == 1) {   // product + one single-factor term (a GKR layer): one pass
             uint32_t g = 0;
-            const int lrc = launch_round_plus1(launch_ctx(c), fp, ts.term_k[0], q, D, fused, d_r, &g);
+            const int lrc = launch_round_plus1(launch_ctx(c), fp, ts.term_k[0], q, D, fused, d_r, &g, &skip1);
             if (lrc == kLaunchHipError) {
                 g_hip_err = "round kernel launch failed";
                 return ZK_ERR_HIP;
             }
             if (lrc == kLaunchOk) {
                 k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, g, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
-                                                          tt.lanes, P);
+                                                          tt.lanes, P, skip1 ? *dv : TailDerive{});
                 HIPCHK(hipGetLastError());
                 return ZK_OK;
             }
         }
+        if (ts.n_terms != 1) skip1 = false;
         for (int i = 0; i < ts.n_terms; ++i) {
             FactorPtrs sub = {};
             for (int f = 0; f < ts.term_k[i]; ++f) {
@@ -735,7 +749,7 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
             lc.d_partials += (size_t)total * (D + 1) * 4;
             lc.capacity_elems -= (uint64_t)total * (D + 1);
             uint32_t g = 0;
-            const int lrc = launch_round(lc, sub, ts.term_k[i], q, D, fused, d_r, &g);
+            const int lrc = launch_round(lc, sub, ts.term_k[i], q, D, fused, d_r, &g, &skip1);
             if (lrc == kLaunchUnsupported) return ZK_ERR_UNSUPPORTED;
             if (lrc != kLaunchOk) {
                 g_hip_err = "round kernel launch failed";
@@ -745,7 +759,7 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
             first += ts.term_k[i];
         }
         k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, total, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
-                                                  tt.lanes, P);
+                                                  tt.lanes, P, skip1 ? *dv : TailDerive{});
         HIPCHK(hipGetLastError());
         return ZK_OK;
     }
@@ -879,6 +893,7 @@ struct RoundState {
     ProverScratch ps;
     TermSpec terms;                   // how the k flat factors group into products (one term = ProductPoly)
     uint64_t *d_final;                // optional (= ps.d_final when requested): the factors at the challenge point
+    TailDerive dv;                    // Lagrange weights on 0..D (prev_rp is set per round)
 };
 static void round_state_release(RoundState &st) {
     for (uint64_t i = 0; i < (uint64_t)kMaxFactors; ++i)
@@ -901,6 +916,12 @@ static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uin
     st.ps = {};
     st.terms = single_term((int)k);
     st.d_final = nullptr;
+    st.dv = {};
+    if (D >= 1 && D <= (uint32_t)kMaxSkipDegree) {
+        auto it = c->lagrange_w.find(D);
+        if (it == c->lagrange_w.end()) it = c->lagrange_w.emplace(D, interp_weights(D, c->fi->P)).first;
+        for (uint32_t t = 0; t <= D; ++t) st.dv.w[t] = it->second[t];
+    }
     for (uint64_t i = 0; i < (uint64_t)kMaxFactors; ++i) {
         st.cur[i] = i < k ? f[i]->d : nullptr;
         st.scratch[i] = nullptr;
@@ -948,7 +969,8 @@ static int32_t round_enqueue(RoundState &st, uint64_t *lanes) {
         for (uint64_t i = 0; i < st.k; ++i) g.in[i] = fp.out[i];
         if (rc == ZK_OK) rc = launch_sums(c, g, st.terms, q, st.D, false, nullptr, tt);
     } else {
-        rc = launch_sums(c, fp, st.terms, q, st.D, st.pending_fold, st.ps.d_challenge, tt);
+        st.dv.prev_rp = st.round ? tt.out_rp - (size_t)(st.D + 1) * 4 : nullptr;
+        rc = launch_sums(c, fp, st.terms, q, st.D, st.pending_fold, st.ps.d_challenge, tt, &st.dv);
     }
     if (st.pending_fold) {
         for (uint64_t i = 0; i < st.k; ++i) st.cur[i] = fp.out[i];

@@ -30,6 +30,15 @@ ZK_D Mul29 load_challenge29(const uint64_t *rptr) {
     for (int i = 0; i < 9; ++i) r.l[i] = __builtin_amdgcn_readfirstlane(w[i]);   // wave-uniform -> SGPRs
     return r;
 }
+// Big fused rounds leave out the t = 1 sums; the tail derives S_i(1) = S_{i-1}(r_{i-1}) - S_i(0) (k_round_kd, SKIP1).
+// prev_rp: the previous round polynomial (D + 1 elements, device); w[t] = 1 / prod_{u != t} (t - u), the Lagrange weights
+// on the nodes 0..D (Montgomery form, computed by the host once per proof).
+constexpr int kMaxSkipDegree = 4;
+struct TailDerive {
+    const uint64_t *prev_rp;   // null: nothing to derive
+    Fe w[kMaxSkipDegree + 1];
+};
+
 // Sum of one field element per lane over a wave, entirely on the VALU: v_permlane32_swap / v_permlane16_swap (gfx950)
 // across wave halves and 16-lane rows, DPP row rotations inside a row -- no ds_bpermute round trips.  Lanes >= width
 // must hold zero (their levels are skipped; width is wave-uniform); the total is valid in lane 0, and in every lane when

@@ -393,22 +393,52 @@ ZK_D void transcript_round(WordSponge *gsp, const Fe *sums, uint32_t ns, uint64_
 __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restrict__ partials, uint32_t nblocks, uint32_t ns,
                                                        WordSponge *__restrict__ sponge, uint64_t *__restrict__ out_rp,
                                                        uint64_t *__restrict__ out_ch, uint64_t *__restrict__ d_challenge,
-                                                       uint64_t *__restrict__ lanes, FieldParams P) {
+                                                       uint64_t *__restrict__ lanes, FieldParams P, TailDerive dv = {}) {
     __shared__ Fe fin[256];
+    __shared__ Fe claim;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool wave0 = __builtin_amdgcn_readfirstlane(wave) == 0;
+    const bool derive1 = dv.prev_rp != nullptr;   // the partials carry no t = 1 sums (k_round_kd SKIP1)
     // wave 0 fetches the sponge first, so that load is in flight while the partials are reduced
     const LaneKeccak L = lane_keccak_init();
     LaneSponge sp = {0, 0};
     if (sponge && wave0) sp = lane_sponge_load(sponge, L);
     // wave w owns the sums t = w, w+4, ...: lanes stride over the blocks' partials, one VALU wave reduction, one barrier
     for (uint32_t t = wave; t < ns; t += kBlock / 64) {
+        if (derive1 && t == 1) {
+            // this wave would own t = 1: it evaluates the previous round polynomial at the previous challenge instead,
+            //   claim = sum_t prev[t] * w[t] * prod_{u != t} (r - u)   (lane t takes term t; D + 1 multiplies deep)
+            const Fe r = fe_load(d_challenge, 0);
+            Fe term = fe_zero();
+            if ((uint32_t)lane < ns) {
+                Fe one;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
+                Fe wt = dv.w[0];   // static indices only: the weights live in the kernel arguments
+#pragma unroll
+                for (int i = 1; i <= kMaxSkipDegree; ++i)
+                    if (lane == i) wt = dv.w[i];
+                term = fe_mul(fe_load(dv.prev_rp, lane), wt, P);
+                Fe node = fe_zero();   // Montgomery form of u
+                for (uint32_t u = 0; u < ns; ++u) {
+                    if (u != (uint32_t)lane) term = fe_mul(term, fe_sub(r, node, P), P);
+                    node = fe_add(node, one, P);
+                }
+            }
+            term = fe_wave_sum(term, P, 8);
+            if (lane == 0) claim = term;
+            continue;
+        }
         Fe s = fe_zero();
         for (uint32_t b = lane; b < nblocks; b += 64) s = fe_add(s, fe_load(partials, (uint64_t)b * ns + t), P);
         s = fe_wave_sum(s, P);
         if (lane == 0) fin[t] = s;
     }
     __syncthreads();
+    if (derive1) {
+        if (threadIdx.x == 0) fin[1] = fe_sub(claim, fin[0], P);   // S(1) = S_prev(r_prev) - S(0)
+        __syncthreads();
+    }
     if (threadIdx.x == kBlock - 64) {   // the last wave stores the round polynomial while wave 0 runs the transcript
         for (uint32_t t = 0; t < ns; ++t) {
             if (out_rp) fe_store(out_rp, t, fin[t]);

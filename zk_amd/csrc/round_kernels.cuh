@@ -6,12 +6,14 @@
 namespace zk {
 
 // ---- workgroup reduction of NS field elements per thread -> partials[block][NS] -------------------------------
-template <int NS>
+// SKIP1: sum[1] is not computed by the caller (the tail derives S(1) from the previous round's claim): not reduced, not stored.
+template <int NS, bool SKIP1 = false>
 ZK_D void block_reduce_store(Fe (&sum)[NS], uint64_t *__restrict__ partials, const FieldParams &P) {
     __shared__ uint32_t red[kBlock / 64][NS][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
+        if (SKIP1 && t == 1) continue;
         sum[t] = fe_wave_sum(sum[t], P);
         if (lane == 0) {
 #pragma unroll
@@ -19,7 +21,7 @@ ZK_D void block_reduce_store(Fe (&sum)[NS], uint64_t *__restrict__ partials, con
         }
     }
     __syncthreads();
-    if (threadIdx.x < NS) {
+    if (threadIdx.x < NS && !(SKIP1 && threadIdx.x == 1)) {
         const int t = threadIdx.x;
         Fe acc;
 #pragma unroll
@@ -121,7 +123,7 @@ struct RoundRegs {
     Fe sum_b[EXTRA ? NS : 1];
     WideAcc acc[K > 1 ? NS : 1];
 };
-template <int F, int K, int D, bool FUSED, int EXTRA>
+template <int F, int K, int D, bool FUSED, int EXTRA, bool SKIP1 = false>
 ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, uint64_t j, uint64_t jn, bool more, uint64_t q,
                        const Mul29 &r, const FieldParams &P) {
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
@@ -145,6 +147,7 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, u
     for (int t = 0; t < NS; ++t) {
         if (t == 1) v = hi;
         else if (t > 1) v = fe_add(v, diff, P);
+        if (SKIP1 && t == 1) continue;                                  // S(1) = claim - S(0): derived in the tail
         if (F == K) R.sum_b[t] = fe_add(R.sum_b[t], v, P);            // the extra single-factor term
         else if (K == 1) R.sum[t] = fe_add(R.sum[t], v, P);
         else if (F == 0) R.prod[t] = v;
@@ -154,7 +157,10 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, u
 }
 // K <= 2 fits 2 waves per SIMD (<= 256 VGPRs); K >= 3 (or an extra term) keeps >= 12 elements in flight and gets the whole
 // register file.
-template <int K, int D, bool FUSED, int EXTRA = 0>
+// SKIP1 (big fused rounds): the products for t = 1 are not formed at all -- S_i(0) + S_i(1) = S_{i-1}(r_{i-1}) holds
+// identically for the sums the prover itself computed in the previous round (exact field arithmetic, so the derived S_i(1)
+// is bit-identical to the computed one); k_round_tail rebuilds it from the previous round polynomial.
+template <int K, int D, bool FUSED, int EXTRA = 0, bool SKIP1 = false>
 __global__ __launch_bounds__(kBlock, (K + EXTRA <= 2 ? 2 : 1)) void k_round_kd(FactorPtrs fp, uint64_t q, FieldParams P,
                                                         const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials) {
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
@@ -178,21 +184,23 @@ __global__ __launch_bounds__(kBlock, (K + EXTRA <= 2 ? 2 : 1)) void k_round_kd(F
     while (j < q) {
         const uint64_t jn = j + stride;
         const bool more = jn < q;
-        round_factor<0, K, D, FUSED, EXTRA>(R, fp, j, jn, more, q, r, P);
-        if constexpr (K + EXTRA > 1) round_factor<1, K, D, FUSED, EXTRA>(R, fp, j, jn, more, q, r, P);
-        if constexpr (K + EXTRA > 2) round_factor<2, K, D, FUSED, EXTRA>(R, fp, j, jn, more, q, r, P);
-        if constexpr (K + EXTRA > 3) round_factor<3, K, D, FUSED, EXTRA>(R, fp, j, jn, more, q, r, P);
+        round_factor<0, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P);
+        if constexpr (K + EXTRA > 1) round_factor<1, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P);
+        if constexpr (K + EXTRA > 2) round_factor<2, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P);
+        if constexpr (K + EXTRA > 3) round_factor<3, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P);
         j = jn;
     }
     if (K > 1) {
 #pragma unroll
-        for (int t = 0; t < NS; ++t) R.sum[t] = redc_wide(R.acc[t], P);
+        for (int t = 0; t < NS; ++t)
+            if (!(SKIP1 && t == 1)) R.sum[t] = redc_wide(R.acc[t], P);
     }
     if (EXTRA) {
 #pragma unroll
-        for (int t = 0; t < NS; ++t) R.sum[t] = fe_add(R.sum[t], R.sum_b[t], P);
+        for (int t = 0; t < NS; ++t)
+            if (!(SKIP1 && t == 1)) R.sum[t] = fe_add(R.sum[t], R.sum_b[t], P);
     }
-    block_reduce_store<NS>(R.sum, partials, P);
+    block_reduce_store<NS, SKIP1>(R.sum, partials, P);
 }
 
 // Generic-degree fallback: one evaluation point t per launch (any D up to 255, any k <= kMaxFactors).

@@ -44,9 +44,21 @@ static void launch_generic(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k
 }
 
 int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused,
-                 const uint64_t *d_r, uint32_t *out_grid) {
+                 const uint64_t *d_r, uint32_t *out_grid, bool *skip1) {
     if (D < 1 || D > 4 || k < 1 || k > kMaxFactors) return kLaunchUnsupported;
     uint32_t g = round_grid(q);
+    if (skip1 && *skip1) {   // the variants without the t = 1 products exist for the GKR-style shapes, fused only
+        const bool fits1 = (uint64_t)g * (D + 1) <= lc.capacity_elems;
+        const int shape1 = (fits1 && fused) ? k * 10 + (int)D : 0;
+        if (shape1 == 22) k_round_kd<2, 2, true, 0, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        else if (shape1 == 33) k_round_kd<3, 3, true, 0, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        else *skip1 = false;
+        if (*skip1) {
+            if (hipGetLastError() != hipSuccess) return kLaunchHipError;
+            *out_grid = g;
+            return kLaunchOk;
+        }
+    }
     const bool fits = (uint64_t)g * (D + 1) <= lc.capacity_elems;
     // specialised shapes (GKR-style products have D = k): everything else takes the runtime-k kernel
     const int shape = fits ? k * 10 + (int)D : 0;
@@ -74,12 +86,14 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
 
 // Terms {k, 1}: the k-factor product plus one single-factor term in one pass (fp lists the k factors, then the extra one).
 int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused,
-                       const uint64_t *d_r, uint32_t *out_grid) {
+                       const uint64_t *d_r, uint32_t *out_grid, bool *skip1) {
     const uint32_t g = round_grid(q);
     if ((uint64_t)g * (D + 1) > lc.capacity_elems) return kLaunchUnsupported;
     const int shape = k * 10 + (int)D;
+    if (skip1 && *skip1 && !(shape == 22 && fused)) *skip1 = false;
     if (shape == 22) {
-        if (fused) k_round_kd<2, 2, true, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        if (fused && skip1 && *skip1) k_round_kd<2, 2, true, 1, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        else if (fused) k_round_kd<2, 2, true, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
         else k_round_kd<2, 2, false, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
     } else if (shape == 33) {
         if (fused) k_round_kd<3, 3, true, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
