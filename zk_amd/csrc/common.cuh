@@ -30,6 +30,57 @@ ZK_D Mul29 load_challenge29(const uint64_t *rptr) {
     for (int i = 0; i < 9; ++i) r.l[i] = __builtin_amdgcn_readfirstlane(w[i]);   // wave-uniform -> SGPRs
     return r;
 }
+// ---- wave-coalesced element access (the fold's and the big rounds' data movement) ------------------------------------------
+// A wave moves a run of 64 consecutive elements (2 KiB) as two fully coalesced 1-KiB dwordx4 accesses: lane l touches bytes
+// [16l, 16l+16) of each half-run, so it holds half (l & 1) of element (l >> 1) of chunk A (elements 0..31) and of chunk B
+// (32..63); lanes 2i / 2i+1 swap one half with a DPP quad_perm and each lane owns a whole element: even lane 2i element i,
+// odd lane 2i+1 element 32+i.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+ZK_D uint4 nt_load16(const uint4 *p) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+ZK_D void nt_store16(uint4 v, uint4 *p) {
+    const u32x4_t w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(p));
+}
+ZK_D uint32_t swap_pair_lane(uint32_t v) { return __builtin_amdgcn_mov_dpp(v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true); }
+// chunks A (elements 0..31 of the run) and B (elements 32..63): lane l holds half (l & 1) of element (l >> 1) of each
+ZK_D Fe pair_gather(const uint4 &A, const uint4 &B, bool odd) {
+    const uint4 send = odd ? A : B;   // what the neighbour needs from me
+    const uint4 recv = make_uint4(swap_pair_lane(send.x), swap_pair_lane(send.y), swap_pair_lane(send.z), swap_pair_lane(send.w));
+    Fe r;
+    if (!odd) r = {{A.x, A.y, A.z, A.w, recv.x, recv.y, recv.z, recv.w}};
+    else r = {{recv.x, recv.y, recv.z, recv.w, B.x, B.y, B.z, B.w}};
+    return r;
+}
+ZK_D void pair_scatter(const Fe &e, bool odd, uint4 &A, uint4 &B) {
+    const uint4 lo = make_uint4(e.v[0], e.v[1], e.v[2], e.v[3]), hi = make_uint4(e.v[4], e.v[5], e.v[6], e.v[7]);
+    const uint4 send = odd ? lo : hi;
+    const uint4 recv = make_uint4(swap_pair_lane(send.x), swap_pair_lane(send.y), swap_pair_lane(send.z), swap_pair_lane(send.w));
+    if (!odd) {
+        A = lo;
+        B = recv;
+    } else {
+        A = recv;
+        B = hi;
+    }
+}
+// the element a lane owns after pair_gather, relative to the start of the wave's run
+ZK_D uint32_t pair_owned(uint32_t lane) { return (lane >> 1) + ((lane & 1) << 5); }
+// plain (cached) forms for tables that the next round re-reads
+ZK_D Fe run_load(const uint64_t *run /* first element of the wave's run */, uint32_t lane) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(run) + lane;
+    return pair_gather(p[0], p[64], lane & 1);
+}
+ZK_D void run_store(uint64_t *run, uint32_t lane, const Fe &e) {
+    uint4 A, B;
+    pair_scatter(e, lane & 1, A, B);
+    uint4 *p = reinterpret_cast<uint4 *>(run) + lane;
+    p[0] = A;
+    p[64] = B;
+}
+
 // Big fused rounds leave out the t = 1 sums; the tail derives S_i(1) = S_{i-1}(r_{i-1}) - S_i(0) (k_round_kd, SKIP1).
 // prev_rp: the previous round polynomial (D + 1 elements, device); w[t] = 1 / prod_{u != t} (t - u), the Lagrange weights
 // on the nodes 0..D (Montgomery form, computed by the host once per proof).

@@ -42,37 +42,6 @@ __global__ __launch_bounds__(kBlock) void k_fold(const uint64_t *in, uint64_t *o
 // the run), and lanes 2i / 2i+1 swap halves with one DPP quad_perm so each lane ends up owning one whole element
 // (even lane: element i, odd lane: element 32+i).  All accesses are nontemporal: the table is streamed once.
 // Measured on MI355X (tools/mb/mb_stream.hip, 2^24): 5.8-5.9 TB/s vs 5.4 TB/s for the 32-B-per-lane form.
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-ZK_D uint4 nt_load16(const uint4 *p) {
-    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-ZK_D void nt_store16(uint4 v, uint4 *p) {
-    const u32x4_t w = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(p));
-}
-ZK_D uint32_t swap_pair_lane(uint32_t v) { return __builtin_amdgcn_mov_dpp(v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true); }
-// chunks A (elements 0..31 of the run) and B (elements 32..63): lane l holds half (l & 1) of element (l >> 1) of each
-ZK_D Fe pair_gather(const uint4 &A, const uint4 &B, bool odd) {
-    const uint4 send = odd ? A : B;   // what the neighbour needs from me
-    const uint4 recv = make_uint4(swap_pair_lane(send.x), swap_pair_lane(send.y), swap_pair_lane(send.z), swap_pair_lane(send.w));
-    Fe r;
-    if (!odd) r = {{A.x, A.y, A.z, A.w, recv.x, recv.y, recv.z, recv.w}};
-    else r = {{recv.x, recv.y, recv.z, recv.w, B.x, B.y, B.z, B.w}};
-    return r;
-}
-ZK_D void pair_scatter(const Fe &e, bool odd, uint4 &A, uint4 &B) {
-    const uint4 lo = make_uint4(e.v[0], e.v[1], e.v[2], e.v[3]), hi = make_uint4(e.v[4], e.v[5], e.v[6], e.v[7]);
-    const uint4 send = odd ? lo : hi;
-    const uint4 recv = make_uint4(swap_pair_lane(send.x), swap_pair_lane(send.y), swap_pair_lane(send.z), swap_pair_lane(send.w));
-    if (!odd) {
-        A = lo;
-        B = recv;
-    } else {
-        A = recv;
-        B = hi;
-    }
-}
 // half = 2^(m-1) >= 64 (a multiple of 64).  Out of place or in place (a wave reads its 64 lo/hi elements before
 // writing the 64 outputs at the lo positions; no other wave touches them).
 __global__ __launch_bounds__(kBlock) void k_fold_msb(const uint64_t *in, uint64_t *out, uint64_t half, FieldParams P, Mul29 r) {
