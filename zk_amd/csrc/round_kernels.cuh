@@ -118,6 +118,7 @@ template <int K, int D, bool FUSED, int EXTRA = 0>
 struct RoundRegs {
     static constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
     Fe cur[K + EXTRA][NL];
+    Fe nxt[FUSED ? 1 : K + EXTRA][FUSED ? 1 : NL];   // sums-only kernels prefetch TWO pair indices ahead (see round_factor)
     Fe prod[NS];
     Fe sum[NS];
     Fe sum_b[EXTRA ? NS : 1];
@@ -125,7 +126,7 @@ struct RoundRegs {
 };
 template <int F, int K, int D, bool FUSED, int EXTRA, bool SKIP1 = false>
 ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, uint64_t j, uint64_t jn, bool more, uint64_t q,
-                       const Mul29 &r, const FieldParams &P) {
+                       const Mul29 &r, const FieldParams &P, uint64_t jnn = 0, bool more2 = false) {
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
     Fe lo, hi;
     if (FUSED) {
@@ -137,9 +138,20 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, u
         lo = R.cur[F][0];
         hi = R.cur[F][1];
     }
-    if (more) {   // this factor's input registers are free: start the next pair's loads now
+    if (FUSED) {
+        if (more) {   // this factor's input registers are free: start the next pair's loads now
 #pragma unroll
-        for (int l = 0; l < NL; ++l) R.cur[F][l] = fe_load(fp.in[F], jn + (uint64_t)l * q);
+            for (int l = 0; l < NL; ++l) R.cur[F][l] = fe_load(fp.in[F], jn + (uint64_t)l * q);
+        }
+    } else {
+        // sums only: ~600 instructions per pair index do not cover the HBM latency at 2 waves per SIMD, so the loads run
+        // two pair indices ahead (the second buffer costs 16 register moves per factor and iteration)
+#pragma unroll
+        for (int l = 0; l < NL; ++l) R.cur[F][l] = R.nxt[F][l];
+        if (more2) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) R.nxt[F][l] = fe_load(fp.in[F], jnn + (uint64_t)l * q);
+        }
     }
     const Fe diff = fe_sub(hi, lo, P);
     Fe v = lo;
@@ -181,13 +193,19 @@ __global__ __launch_bounds__(kBlock, (K + EXTRA <= 2 ? 2 : 1)) void k_round_kd(F
 #pragma unroll
             for (int l = 0; l < NL; ++l) R.cur[f][l] = fe_load(fp.in[f], j + (uint64_t)l * q);
     }
+    if (!FUSED && j + stride < q) {
+#pragma unroll
+        for (int f = 0; f < K + EXTRA; ++f)
+#pragma unroll
+            for (int l = 0; l < NL; ++l) R.nxt[f][l] = fe_load(fp.in[f], j + stride + (uint64_t)l * q);
+    }
     while (j < q) {
-        const uint64_t jn = j + stride;
-        const bool more = jn < q;
-        round_factor<0, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P);
-        if constexpr (K + EXTRA > 1) round_factor<1, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P);
-        if constexpr (K + EXTRA > 2) round_factor<2, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P);
-        if constexpr (K + EXTRA > 3) round_factor<3, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P);
+        const uint64_t jn = j + stride, jnn = jn + stride;
+        const bool more = jn < q, more2 = jnn < q;
+        round_factor<0, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P, jnn, more2);
+        if constexpr (K + EXTRA > 1) round_factor<1, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P, jnn, more2);
+        if constexpr (K + EXTRA > 2) round_factor<2, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P, jnn, more2);
+        if constexpr (K + EXTRA > 3) round_factor<3, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P, jnn, more2);
         j = jn;
     }
     if (K > 1) {
