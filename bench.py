@@ -63,11 +63,12 @@ def cpu_baseline(field):
     dt_par = time.perf_counter() - t1
     assert np.array_equal(out_par, out), "parallel CPU fold differs from the faithful fold"
     # the other half of the metric on the CPU: reference-faithful prover ((D+2)*k folds + (D+1) prod_reduce per round)
-    ns = 16
-    tabs = [orc.fill_random(field, 0x5EED0000 + ns + f, 1 << ns) for f in range(2)]
-    t1 = time.perf_counter()
-    orc.sumcheck_prove(field, ns, tabs, 2, orc.fill_random(field, 5, 1)[0], False)
-    cpu_prove_ms = (time.perf_counter() - t1) * 1e3
+    cpu_prove = {}
+    for ns in (12, 16, 20):   # configs[0] and configs[1] of BASELINE.json at full size, 16 for continuity
+        tabs = [orc.fill_random(field, 0x5EED0000 + ns + f, 1 << ns) for f in range(2)]
+        t1 = time.perf_counter()
+        orc.sumcheck_prove(field, ns, tabs, 2, orc.fill_random(field, 5, 1)[0], False)
+        cpu_prove[ns] = (time.perf_counter() - t1) * 1e3
     return {
         "value": ops / dt,
         "unit": "field-ops/s",
@@ -75,7 +76,9 @@ def cpu_baseline(field):
         "kind": "port",
         "sample": f"{reps} folds of a 2^{n}-element BN254-Fr table (clone + fold + copy as evaluation_form.rs:49-79), "
                   f"{dt:.1f} s, single thread (the reference is single-threaded)",
-        "sumcheck_prove_partial_ms_n16_k2_d2": cpu_prove_ms,
+        "sumcheck_prove_partial_ms_n12_k2_d2": cpu_prove[12],
+        "sumcheck_prove_partial_ms_n16_k2_d2": cpu_prove[16],
+        "sumcheck_prove_partial_ms_n20_k2_d2": cpu_prove[20],
         "optimised": {"value": 3 * (1 << (n - 1)) * reps_par / dt_par, "unit": "field-ops/s", "cores": used,
                       "sample": f"{reps_par} fused out-of-place folds of the same table, OpenMP, {dt_par:.1f} s"},
     }, out
