@@ -283,24 +283,23 @@ ZK_D Fe transcript_step(LaneSponge &sp, const LaneKeccak &L, const Fe *sums, uin
             const uint64_t limb = (uint64_t)c.v[2 * (3 - k)] | ((uint64_t)c.v[2 * (3 - k) + 1] << 32);
             w[k] = WordSponge::bswap64(limb);
         }
-        const uint32_t cnt = ns - base < 64 ? ns - base : 64;
-        if (sp.pos + 4 * cnt <= 17) {
-            // the whole batch fits the current block: state word i receives message word (i - pos) = word k of sum t,
-            // one gather per k instead of 4*cnt dependent absorb steps
+        const uint32_t cnt = ns - base < 64 ? ns - base : 64, total = 4 * cnt;
+        // absorb the batch rate-block by rate-block: state word i receives message word done + (i - pos) = word k of sum t,
+        // one gather per k instead of a dependent step per word (a batch may straddle a permutation: D = 3 absorbs 16 words
+        // at cursor 4)
+        for (uint32_t done = 0; done < total;) {
+            const uint32_t room = 17 - sp.pos, take = total - done < room ? total - done : room;
             const int rel = L.index - (int)sp.pos;
-            const int t = rel >= 0 ? rel >> 2 : 0, k = rel & 3;
+            const uint32_t m = done + (rel >= 0 ? (uint32_t)rel : 0u);
+            const int t = (int)(m >> 2), k = (int)(m & 3);
             const uint64_t g0 = shfl64(w[0], t), g1 = shfl64(w[1], t), g2 = shfl64(w[2], t), g3 = shfl64(w[3], t);
             const uint64_t g = k == 0 ? g0 : (k == 1 ? g1 : (k == 2 ? g2 : g3));
-            if (L.index >= 0 && rel >= 0 && rel < (int)(4 * cnt)) sp.a ^= g;
-            sp.pos += 4 * cnt;
+            if (L.index >= 0 && rel >= 0 && rel < (int)take) sp.a ^= g;
+            sp.pos += take;
+            done += take;
             if (sp.pos == 17) {
                 sp.a = lane_keccak_f1600(sp.a, L);
                 sp.pos = 0;
-            }
-        } else {
-            for (uint32_t t = 0; t < cnt; ++t) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) lane_absorb_word(sp, shfl64(w[k], (int)t), L);
             }
         }
     }
