@@ -484,3 +484,41 @@ def test_skip1_rounds_bit_exact():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "skip1_check.py")], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "skip1 ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_beyond_baseline_sizes_properties():
+    """Sizes past BASELINE.json's (byte offsets beyond 2^32, 288 GB HBM): a 26-variable sumcheck verified end to end, a
+    27-variable fold and a 2^25-point NTT round trip, each checked through a size-independent property (tables are
+    compared by their MLE value at a random point instead of being downloaded)."""
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    p = zk_amd.modulus(field)
+    rng = random.Random(2627)
+    # sumcheck n = 26: verify_partial accepts and the sub-claim equals the product at the challenge point (verifier.rs:27-31)
+    n = 26
+    A, B = MLE.random(c, n, 2601, 0), MLE.random(c, n, 2602, 0)
+    pp = ProductPoly.new([A, B])
+    s = pp.round_sums(1)
+    claimed = zk_amd.fe_from_int(field, (zk_amd.fe_to_int(field, s[0]) + zk_amd.fe_to_int(field, s[1])) % p)
+    proof, ch = SumcheckProver(2).prove_partial(pp, claimed)
+    sub = SumcheckVerifier.verify_partial(field, proof)
+    assert np.array_equal(sub.challenges, ch)
+    assert zk_amd.fe_to_int(field, pp.evaluate(ch)) == zk_amd.fe_to_int(field, sub.sum)
+    A.free(); B.free()
+    # fold n = 27 at r: evaluating the folded table at z equals evaluating the original at (r, z)  (evaluation_form.rs:83-89)
+    m = 27
+    T = MLE.random(c, m, 2701, 0)
+    r = rng.randrange(p)
+    z = [rng.randrange(p) for _ in range(m - 1)]
+    folded = T.partial_evaluate(0, F(field, [r]))
+    assert zk_amd.fe_to_int(field, folded.evaluate(F(field, z))) == zk_amd.fe_to_int(field, T.evaluate(F(field, [r] + z)))
+    T.free(); folded.free()
+    # NTT 2^25: ifft(fft(x)) == x  (fft/src/lib.rs:78-82), compared at a random MLE point
+    k = 25
+    x, y, w = MLE.random(c, k, 2501, 0), MLE.alloc(c, k), MLE.alloc(c, k)
+    zk_amd.ntt(c, x, y, False)
+    zk_amd.ntt(c, y, w, True)
+    pt = F(field, [rng.randrange(p) for _ in range(k)])
+    assert zk_amd.fe_to_int(field, w.evaluate(pt)) == zk_amd.fe_to_int(field, x.evaluate(pt))
+    assert zk_amd.fe_to_int(field, y.evaluate(pt)) != zk_amd.fe_to_int(field, x.evaluate(pt))
+    x.free(); y.free(); w.free()
