@@ -24,9 +24,10 @@
 
 namespace zk {
 
-constexpr int kNttCols = 16;          // tile columns (consecutive contiguous-axis indices)
-constexpr int kNttRowBytes = 272;     // 16 slots * 16 B + 16 B pad
-constexpr int kNttThreads = 512;
+constexpr int kNttColsLog = 3;
+constexpr int kNttCols = 1 << kNttColsLog;   // tile columns (consecutive contiguous-axis indices)
+constexpr int kNttRowBytes = kNttCols * 16 + 16;   // one 16-B slot per column + 16 B pad
+constexpr int kNttThreads = 32 * kNttCols;
 constexpr int kNttMaxLog = 8;         // R <= 256
 
 // Twiddles are stored ready for the carry-free multiplier (field.cuh fe_mul29): every multiplication of the transform
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
             uint32_t t, post;
             if (!LAST) {
                 t = it & (kNttCols - 1);
-                post = it >> 4;
+                post = it >> kNttColsLog;
             } else {
                 post = it & ((1u << S_LO) - 1);
                 t = it >> S_LO;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
         constexpr int S_HI = L - G0 - 1;   // group 1 covers S_HI .. 0
         constexpr uint32_t items1 = (R >> G1) * kNttCols;
         for (uint32_t it = tid; it < items1; it += kNttThreads) {
-            const uint32_t t = it & (kNttCols - 1), pre = it >> 4;
+            const uint32_t t = it & (kNttCols - 1), pre = it >> kNttColsLog;
             Fe x[1 << G1];
 #pragma unroll
             for (int u = 0; u < (1 << G1); ++u) x[u] = lds_get(lo_plane, hi_plane, (pre << G1) | u, t);
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
         constexpr int S_HI1 = L - G0 - 1, S_LO1 = S_HI1 - G1 + 1;   // group 1: S_HI1 .. S_LO1, group 2: S_LO1-1 .. 0
         constexpr uint32_t items1 = (R >> G1) * kNttCols;
         for (uint32_t it = tid; it < items1; it += kNttThreads) {
-            const uint32_t t = it & (kNttCols - 1), rr = it >> 4;
+            const uint32_t t = it & (kNttCols - 1), rr = it >> kNttColsLog;
             const uint32_t post = rr & ((1u << S_LO1) - 1), pre = rr >> S_LO1;
             Fe x[1 << G1];
 #pragma unroll
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
         __syncthreads();
         constexpr uint32_t items2 = (R >> G2) * kNttCols;
         for (uint32_t it = tid; it < items2; it += kNttThreads) {
-            const uint32_t t = it & (kNttCols - 1), pre = it >> 4;
+            const uint32_t t = it & (kNttCols - 1), pre = it >> kNttColsLog;
             Fe x[1 << G2];
 #pragma unroll
             for (int u = 0; u < (1 << G2); ++u) x[u] = lds_get(lo_plane, hi_plane, (pre << G2) | u, t);
