@@ -183,3 +183,28 @@ def test_gkr_width_2p16_depth4_verifies():
     bad = proof.copy()
     bad[len(bad) // 3, 0] ^= np.uint64(1)
     assert not gkr.gkr_verify(circ, x, out, seed, bad)
+
+
+@pytest.mark.parametrize("shape,D", [([2, 1], 3), ([1, 2], 2), ([1, 1, 1, 1], 1), ([2, 1], 4)])
+def test_prove_terms_consume_and_fallback_shapes(shape, D):
+    """terms {k, 1} with (k, D) outside the merged kernel's shapes take the term-by-term launches; consume = True may
+    fold the caller's tables in place but must produce the same proof"""
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    p = zk_amd.modulus(field)
+    rng = random.Random(sum(shape) * 7 + D)
+    n = 11
+    tabs = [[[rng.randrange(p) for _ in range(1 << n)] for _ in range(k)] for k in shape]
+    s = 0
+    for term in tabs:
+        for j in range(1 << n):
+            prod = 1
+            for t in term:
+                prod = prod * t[j] % p
+            s += prod
+    s %= p
+    want_rp, want_ch, want_fin = gkr_ref.prove_partial_terms(field, tabs, D, s)
+    for consume in (False, True):
+        poly = gkr.SumOfProductsPoly([[MLE.new(c, n, F(field, t)) for t in term] for term in tabs])
+        rp, ch, fin = gkr.prove_partial_terms(poly, D, zk_amd.fe_from_int(field, s), consume=consume)
+        assert [I(field, r) for r in rp] == want_rp and I(field, ch) == want_ch and I(field, fin) == want_fin
