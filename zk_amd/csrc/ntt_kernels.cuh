@@ -26,7 +26,7 @@ namespace zk {
 
 constexpr int kNttColsLog = 3;
 constexpr int kNttCols = 1 << kNttColsLog;   // tile columns (consecutive contiguous-axis indices)
-constexpr int kNttRowBytes = kNttCols * 16 + 16;   // one 16-B slot per column + 16 B pad
+constexpr int kNttRowBytes = kNttCols * 16 + 16;   // one 16-B slot per column + 16 B pad: 2 x 256 rows = 72 KiB, two workgroups per CU (a 32-B pad no longer fits two: 2.95 ms)
 constexpr int kNttThreads = 32 * kNttCols;
 constexpr int kNttMaxLog = 8;         // R <= 256
 
