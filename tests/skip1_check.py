@@ -1,4 +1,5 @@
-"""Run by tests/test_gpu_parity.py::test_skip1_rounds_bit_exact in a child process with ZK_SKIP1_MIN_PAIRS=1, so that EVERY
+"""Run by tests/test_gpu_parity.py::test_skip1_rounds_bit_exact in a child process with ZK_SKIP1_MIN_PAIRS=1 (and
+ZK_QUAD_MAX_PAIRS=0, so that the small-round kernel does not take these sizes), so that EVERY
 fused round of the shapes that have the variant leaves out the t = 1 sums and the tail derives S(1) = S_prev(r_prev) - S(0)
 (k_round_kd SKIP1 / TailDerive).  The proofs must stay bit-identical to the CPU oracle's (prover.rs:44-68 computes S(1)
 directly; the identity is exact in F_p), including a WRONG claimed sum: the identity is about the prover's own sums."""
@@ -8,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-assert os.environ.get("ZK_SKIP1_MIN_PAIRS") == "1"
+assert os.environ.get("ZK_QUAD_MAX_PAIRS") == "0"   # with ZK_SKIP1_MIN_PAIRS=1: the SKIP1 kernels; without: plain k_round_kd
 
 import numpy as np  # noqa: E402
 
@@ -47,4 +48,4 @@ for field in (zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR):
         assert [zk_amd.fe_to_ints(field, r) for r in rp] == want[0] and zk_amd.fe_to_ints(field, ch) == want[1]
         assert zk_amd.fe_to_ints(field, fin) == want[2]
         checked += 1
-print(f"skip1 ok: {checked} proofs bit-exact")
+print(f"skip1 ok: {checked} proofs bit-exact (ZK_SKIP1_MIN_PAIRS={os.environ.get('ZK_SKIP1_MIN_PAIRS')})")

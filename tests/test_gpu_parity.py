@@ -480,7 +480,13 @@ def test_skip1_rounds_bit_exact():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ZK_SKIP1_MIN_PAIRS="1")
+    env = dict(os.environ, ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0")   # no quad kernel: it would take the small rounds
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "skip1_check.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "skip1 ok" in r.stdout, r.stdout + r.stderr
+    # the same grid through plain k_round_kd at small sizes (by default the four-lanes-per-pair kernel takes those rounds)
+    env = dict(os.environ, ZK_QUAD_MAX_PAIRS="0")
+    env.pop("ZK_SKIP1_MIN_PAIRS", None)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "skip1_check.py")], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "skip1 ok" in r.stdout, r.stdout + r.stderr

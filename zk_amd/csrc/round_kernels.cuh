@@ -221,6 +221,132 @@ __global__ __launch_bounds__(kBlock, (K + EXTRA <= 2 ? 2 : 1)) void k_round_kd(F
     block_reduce_store<NS, SKIP1>(R.sum, partials, P);
 }
 
+// ---- small fused rounds: one FACTOR per lane, one EVALUATION POINT per lane, four lanes per pair index -----------------
+// Between ~2^10 and ~2^15 pairs a round is pure latency: k_round_kd gives a lane the whole pair index (7 dependent-ish
+// multiplies for k = 2, 14 for k = 3: 4-8 us of a single wave's issue time) while most of the machine idles.  Here the four
+// lanes of a quad share pair index j: lane f folds factor f (2 multiplies), the quad transposes the (factor, point) values
+// with DPP quad_perm broadcasts, and lane t forms the product for evaluation point t (k - 1 multiplies).  Same arithmetic
+// per pair index, spread over 4x the lanes: the per-lane chain drops to ~1100-1400 instructions.  K + EXTRA <= 4, D <= 3.
+template <int SRC>
+ZK_D Fe quad_bcast(const Fe &x) {   // every lane of a quad reads lane SRC of the quad
+    Fe o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = __builtin_amdgcn_mov_dpp(x.v[i], SRC | (SRC << 2) | (SRC << 4) | (SRC << 6), 0xF, 0xF, true);
+    return o;
+}
+template <int G, int NF, int NS>
+ZK_D void quad_transpose(const Fe (&v)[NS], Fe (&w)[NF], uint32_t l4) {   // w[g] of lane t <- v[t] of lane g
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const Fe b = quad_bcast<G>(v[t]);
+        if (l4 == (uint32_t)t) w[G] = b;
+    }
+    if constexpr (G + 1 < NF) quad_transpose<G + 1, NF, NS>(v, w, l4);
+}
+template <int K, int D, int EXTRA>
+__global__ __launch_bounds__(kBlock) void k_round_quad(FactorPtrs fp, uint64_t q, FieldParams P, const uint64_t *__restrict__ rptr,
+                                                       uint64_t *__restrict__ partials) {
+    constexpr int NF = K + EXTRA, NS = D + 1;
+    static_assert(NF <= 4 && NS <= 4, "four lanes per pair index");
+    __shared__ uint32_t red[kBlock / 64][4][8];
+    const Mul29 r = load_challenge29(rptr);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l4 = lane & 3;
+    const bool has_factor = l4 < (uint32_t)NF;
+    // this lane's factor (lanes >= NF alias factor 0 and keep their hands off memory)
+    const uint64_t *in = fp.in[0];
+    uint64_t *out = fp.out[0];
+#pragma unroll
+    for (int f = 1; f < NF; ++f)
+        if (l4 == (uint32_t)f) {
+            in = fp.in[f];
+            out = fp.out[f];
+        }
+    const uint64_t stride = (uint64_t)gridDim.x * (kBlock / 4);
+    uint64_t j = (uint64_t)blockIdx.x * (kBlock / 4) + (threadIdx.x >> 2);
+    WideAcc acc;
+    wide_zero(acc);
+    Fe sum = fe_zero();   // K == 1 products and the extra single-factor term
+    Fe cur[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) cur[l] = fe_zero();
+    if (j < q && has_factor) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) cur[l] = fe_load(in, j + (uint64_t)l * q);
+    }
+    while (j < q) {
+        const uint64_t jn = j + stride;
+        Fe v[NS];
+        v[0] = fe_sub(cur[0], fe_mul29(fe_sub(cur[0], cur[2], P), r, P), P);   // lo'
+        const Fe hi = fe_sub(cur[1], fe_mul29(fe_sub(cur[1], cur[3], P), r, P), P);
+        if (has_factor) {
+            fe_store(out, j, v[0]);
+            fe_store(out, j + q, hi);
+            if (jn < q) {
+#pragma unroll
+                for (int l = 0; l < 4; ++l) cur[l] = fe_load(in, jn + (uint64_t)l * q);
+            }
+        }
+        if constexpr (NS > 1) v[1] = hi;
+        if constexpr (NS > 2) {
+            const Fe diff = fe_sub(hi, v[0], P);
+#pragma unroll
+            for (int t = 2; t < NS; ++t) v[t] = fe_add(v[t - 1], diff, P);
+        }
+        Fe w[NF];
+#pragma unroll
+        for (int g = 0; g < NF; ++g) w[g] = fe_zero();
+        quad_transpose<0, NF, NS>(v, w, l4);
+        // lane t: product over the K factors at point t (+ the extra term's value); lanes > D compute on zeros
+        if constexpr (K == 1) {
+            sum = fe_add(sum, w[0], P);
+        } else {
+            Fe prod = w[0];
+#pragma unroll
+            for (int g = 1; g + 1 < K; ++g) prod = fe_mul(prod, w[g], P);
+            wide_mac(acc, prod.v, w[K - 1].v);
+        }
+        if constexpr (EXTRA) sum = fe_add(sum, w[K], P);
+        j = jn;
+    }
+    Fe s = sum;
+    if constexpr (K > 1) s = fe_add(redc_wide(acc, P), sum, P);
+    // wave sum that keeps the four quad positions apart: every level of fe_wave_sum except the two inside a quad
+    {
+        Fe a, b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const auto x = __builtin_amdgcn_permlane32_swap(s.v[i], s.v[i], false, false);
+            a.v[i] = x[0];
+            b.v[i] = x[1];
+        }
+        s = fe_add(a, b, P);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const auto x = __builtin_amdgcn_permlane16_swap(s.v[i], s.v[i], false, false);
+            a.v[i] = x[0];
+            b.v[i] = x[1];
+        }
+        s = fe_add(a, b, P);
+        s = fe_add(s, fe_dpp<0x128>(s), P);
+        s = fe_add(s, fe_dpp<0x12C>(s), P);
+    }
+    if (lane < 4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[wave][lane][i] = s.v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)NS) {
+        Fe tot = fe_zero();
+        for (int wv = 0; wv < kBlock / 64; ++wv) {
+            Fe o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] = red[wv][threadIdx.x][i];
+            tot = fe_add(tot, o, P);
+        }
+        fe_store(partials, (uint64_t)blockIdx.x * NS + threadIdx.x, tot);
+    }
+}
+
 // Generic-degree fallback: one evaluation point t per launch (any D up to 255, any k <= kMaxFactors).
 __global__ __launch_bounds__(kBlock) void k_round_single_t(FactorPtrs fp, int k, uint64_t q, FieldParams P, Fe tval,
                                                            uint64_t *__restrict__ partials) {

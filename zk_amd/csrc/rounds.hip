@@ -19,6 +19,24 @@ static uint32_t min_blocks() {
     }();
     return v;
 }
+// fused rounds with at most this many pairs (and at least 16) use the four-lanes-per-pair-index kernel (ZK_QUAD_MAX_PAIRS;
+// 0 switches it off)
+static uint64_t quad_max_pairs() {
+    static const uint64_t v = [] {
+        const char *e = getenv("ZK_QUAD_MAX_PAIRS");
+        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)1 << 15;
+    }();
+    return v;
+}
+template <int K, int D, int EXTRA>
+static uint32_t launch_quad(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, const uint64_t *d_r) {
+    // 64 pair indices per workgroup pass, at most kMaxLazy products per lane
+    uint64_t g = (q + 63) / 64;
+    const uint64_t cap = (q + 64ull * kMaxLazy - 1) / (64ull * kMaxLazy);
+    if (g > 2048) g = cap > 2048 ? cap : 2048;
+    k_round_quad<K, D, EXTRA><<<(uint32_t)g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+    return (uint32_t)g;
+}
 static inline uint32_t round_grid(uint64_t q) {
     uint64_t b = (q + (uint64_t)kBlock * kMaxLazy - 1) / ((uint64_t)kBlock * kMaxLazy);   // kMaxLazy pairs per thread
     const uint64_t one_pair = (q + kBlock - 1) / kBlock;                                    // one pair per thread
@@ -47,6 +65,19 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
                  const uint64_t *d_r, uint32_t *out_grid, bool *skip1) {
     if (D < 1 || D > 4 || k < 1 || k > kMaxFactors) return kLaunchUnsupported;
     uint32_t g = round_grid(q);
+    if (fused && q >= 16 && q <= 4 * quad_max_pairs() && (uint64_t)2048 * (D + 1) <= lc.capacity_elems) {
+        // measured cross-over (MI355X, BN254): 2^15 pairs for k = 2, 2^17 for k = 3 (its lane does 14 multiplies per pair index)
+        const int shq = k * 10 + (int)D;
+        uint32_t gq = 0;
+        if (shq == 22 && q <= quad_max_pairs()) gq = launch_quad<2, 2, 0>(lc, fp, q, d_r);
+        else if (shq == 33) gq = launch_quad<3, 3, 0>(lc, fp, q, d_r);
+        if (gq) {
+            if (skip1) *skip1 = false;
+            if (hipGetLastError() != hipSuccess) return kLaunchHipError;
+            *out_grid = gq;
+            return kLaunchOk;
+        }
+    }
     if (skip1 && *skip1) {   // the variants without the t = 1 products exist for the GKR-style shapes, fused only
         const bool fits1 = (uint64_t)g * (D + 1) <= lc.capacity_elems;
         const int shape1 = (fits1 && fused) ? k * 10 + (int)D : 0;
@@ -90,6 +121,13 @@ int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, ui
     const uint32_t g = round_grid(q);
     if ((uint64_t)g * (D + 1) > lc.capacity_elems) return kLaunchUnsupported;
     const int shape = k * 10 + (int)D;
+    if (fused && shape == 22 && q >= 16 && q <= quad_max_pairs() && (uint64_t)2048 * (D + 1) <= lc.capacity_elems) {
+        const uint32_t gq = launch_quad<2, 2, 1>(lc, fp, q, d_r);
+        if (skip1) *skip1 = false;
+        if (hipGetLastError() != hipSuccess) return kLaunchHipError;
+        *out_grid = gq;
+        return kLaunchOk;
+    }
     if (skip1 && *skip1 && !(shape == 22 && fused)) *skip1 = false;
     if (shape == 22) {
         if (fused && skip1 && *skip1) k_round_kd<2, 2, true, 1, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
