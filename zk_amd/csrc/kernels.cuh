@@ -466,6 +466,35 @@ __global__ __launch_bounds__(kBlock) void k_finish(FactorPtrs fp, uint32_t m_in,
     uint32_t round = 0;
     while (m >= 1) {
         const uint32_t q = 1u << (m - 1);
+        if (q <= 128) {
+            // ---- one evaluation point per WAVE: wave t forms S_t over all pairs (k - 1 multiplies per pair instead of
+            // (D + 1)(k - 1) on one lane), reduces it on the VALU and owns fin[t]: no cross-wave exchange ----
+            for (uint32_t t = wave; t < (uint32_t)NS; t += kBlock / 64) {
+                Fe s = fe_zero();
+                for (uint32_t j = lane; j < q; j += 64) {
+                    Fe prod;
+#pragma unroll
+                    for (int f = 0; f < K; ++f) {
+                        const uint64_t *T = tab + (size_t)f * n_elems * 4;
+                        const Fe lo = fe_load(T, j), hi = fe_load(T, j + q);
+                        Fe v = lo;
+                        if (t >= 1) v = hi;
+                        if (t >= 2) {
+                            const Fe diff = fe_sub(hi, lo, P);
+                            for (uint32_t u = 1; u < t; ++u) v = fe_add(v, diff, P);
+                        }
+                        prod = (f == 0) ? v : fe_mul(prod, v, P);
+                    }
+                    s = fe_add(s, prod, P);
+                }
+                s = fe_wave_sum(s, P, q < 64 ? q : 64);
+                if (lane == 0) {
+                    fin[t] = s;
+                    fe_store(out_rp, (uint64_t)round * NS + t, s);
+                }
+            }
+            __syncthreads();
+        } else {
         // ---- sums over the pairs (j, j+q) ----
         Fe sum[NS];
 #pragma unroll
@@ -514,6 +543,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(FactorPtrs fp, uint32_t m_in,
             fe_store(out_rp, (uint64_t)round * NS + tid, acc);
         }
         __syncthreads();
+        }
         // ---- transcript step on wave 0, challenge to everyone through LDS ----
         if (wave0) {
             Mul29 ch29;
@@ -530,13 +560,13 @@ __global__ __launch_bounds__(kBlock) void k_finish(FactorPtrs fp, uint32_t m_in,
             Mul29 r;
 #pragma unroll
             for (int i = 0; i < 9; ++i) r.l[i] = __builtin_amdgcn_readfirstlane(sh_r29p->l[i]);
-#pragma unroll
-            for (int f = 0; f < K; ++f) {
-                uint64_t *T = tab + (size_t)f * n_elems * 4;
-                for (uint32_t j = tid; j < q; j += kBlock) {
-                    const Fe lo = fe_load(T, j), hi = fe_load(T, j + q);
-                    fe_store(T, j, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P));
-                }
+            // work items (factor, index): every lane has at most ceil(k*q / 256) multiplies
+            const uint32_t lq = m - 1;
+            for (uint32_t i = tid; i < ((uint32_t)K << lq); i += kBlock) {
+                uint64_t *T = tab + (size_t)(i >> lq) * n_elems * 4;
+                const uint32_t j = i & (q - 1);
+                const Fe lo = fe_load(T, j), hi = fe_load(T, j + q);
+                fe_store(T, j, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P));
             }
             __syncthreads();
         }
@@ -597,6 +627,36 @@ __global__ __launch_bounds__(kBlock) void k_finish_terms(FactorPtrs fp, TermSpec
     uint32_t round = 0;
     while (m >= 1) {
         const uint32_t q = 1u << (m - 1);
+        if (q <= 128) {
+            // ---- one evaluation point per WAVE (see k_finish) ----
+            for (uint32_t t = wave; t < (uint32_t)NS; t += kBlock / 64) {
+                Fe s = fe_zero();
+                for (uint32_t j = lane; j < q; j += 64) {
+                    int f = 0;
+                    for (int i = 0; i < ts.n_terms; ++i) {
+                        Fe prod;
+                        for (int g = 0; g < ts.term_k[i]; ++g, ++f) {
+                            const uint64_t *T = tab + (size_t)f * n_elems * 4;
+                            const Fe lo = fe_load(T, j), hi = fe_load(T, j + q);
+                            Fe v = lo;
+                            if (t >= 1) v = hi;
+                            if (t >= 2) {
+                                const Fe diff = fe_sub(hi, lo, P);
+                                for (uint32_t u = 1; u < t; ++u) v = fe_add(v, diff, P);
+                            }
+                            prod = (g == 0) ? v : fe_mul(prod, v, P);
+                        }
+                        s = fe_add(s, prod, P);
+                    }
+                }
+                s = fe_wave_sum(s, P, q < 64 ? q : 64);
+                if (lane == 0) {
+                    fin[t] = s;
+                    fe_store(out_rp, (uint64_t)round * NS + t, s);
+                }
+            }
+            __syncthreads();
+        } else {
         // ---- sums over the pairs (j, j+q) ----
         Fe sum[NS];
 #pragma unroll
@@ -647,6 +707,7 @@ __global__ __launch_bounds__(kBlock) void k_finish_terms(FactorPtrs fp, TermSpec
             fe_store(out_rp, (uint64_t)round * NS + tid, acc);
         }
         __syncthreads();
+        }
         // ---- transcript step on wave 0, challenge to everyone through LDS ----
         if (wave0) {
             Mul29 ch29;
@@ -663,13 +724,12 @@ __global__ __launch_bounds__(kBlock) void k_finish_terms(FactorPtrs fp, TermSpec
             Mul29 r;
 #pragma unroll
             for (int i = 0; i < 9; ++i) r.l[i] = __builtin_amdgcn_readfirstlane(sh_r29p->l[i]);
-#pragma unroll
-            for (int f = 0; f < K; ++f) {
-                uint64_t *T = tab + (size_t)f * n_elems * 4;
-                for (uint32_t j = tid; j < q; j += kBlock) {
-                    const Fe lo = fe_load(T, j), hi = fe_load(T, j + q);
-                    fe_store(T, j, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P));
-                }
+            const uint32_t lq = m - 1;
+            for (uint32_t i = tid; i < ((uint32_t)K << lq); i += kBlock) {
+                uint64_t *T = tab + (size_t)(i >> lq) * n_elems * 4;
+                const uint32_t j = i & (q - 1);
+                const Fe lo = fe_load(T, j), hi = fe_load(T, j + q);
+                fe_store(T, j, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P));
             }
             __syncthreads();
         }
