@@ -4,7 +4,8 @@ duration and the idle gap since the previous kernel ended (shows where the seria
 import csv, glob, sys
 src = sys.argv[1]
 last = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-f = glob.glob(src + "/**/*_kernel_trace.csv", recursive=True)[0]
+import os
+f = max(glob.glob(src + "/**/*_kernel_trace.csv", recursive=True), key=os.path.getmtime)   # newest run
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 rows = rows[-last:]
 prev_end = None
