@@ -461,33 +461,42 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
         scratch_bytes = (size_t)32 << (n - 1);
         ZKCHK(pool_alloc(c, scratch_bytes, (void **)&scratch));
     }
-    uint32_t *d_ch = nullptr;
-    int32_t rc = pool_alloc(c, (size_t)kEvalTailVars * kEvalChWords * 4, (void **)&d_ch);
+    int32_t rc = ZK_OK;
     const uint64_t *src = t->d;
-    for (uint64_t i = 0; i < big && rc == ZK_OK; ++i) {
-        rc = launch_fold(c, src, scratch, n - i, 0, fe_from_u64limbs(point + 4 * i));
+    for (uint64_t i = 0; i < big && rc == ZK_OK;) {
+        const uint64_t left = big - i, m = n - i;
+        if (left >= 2) {   // three (or two) variables per launch
+            const int v = left >= 3 ? 3 : 2;
+            FoldChallenges ch = {};
+            for (int u = 0; u < v; ++u) ch.r[u] = mul29_prepare(fe_from_u64limbs(point + 4 * (i + u)), P);
+            const uint64_t n_out = 1ull << (m - v);
+            if (v == 3) k_fold_multi<3><<<grid_for(n_out), kBlock, 0, c->stream>>>(src, scratch, n_out, P, ch);
+            else k_fold_multi<2><<<grid_for(n_out), kBlock, 0, c->stream>>>(src, scratch, n_out, P, ch);
+            if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+            i += v;
+        } else {
+            rc = launch_fold(c, src, scratch, m, 0, fe_from_u64limbs(point + 4 * i));
+            i += 1;
+        }
         src = scratch;
     }
     if (rc == ZK_OK) {
-        // the remaining assignments in prepared form, staged through pinned memory
-        HIPCHK(hipStreamSynchronize(c->stream));           // h_pinned may still be in flight from an earlier call
-        uint32_t *h = reinterpret_cast<uint32_t *>(c->h_pinned);
+        // the remaining assignments travel in the kernel arguments: no staging buffer, no synchronisation
+        EvalTailChallenges chs = {};
         for (uint64_t v = 0; v < tail_vars; ++v) {
             const Mul29 r = mul29_prepare(fe_from_u64limbs(point + 4 * (big + v)), P);
-            for (int i = 0; i < 9; ++i) h[v * kEvalChWords + i] = r.l[i];
+            for (int i = 0; i < 9; ++i) chs.w[v][i] = r.l[i];
         }
-        if (hipMemcpyAsync(d_ch, h, (size_t)tail_vars * kEvalChWords * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ZK_ERR_HIP;
         const size_t lds = (size_t)32 << (tail_vars - 1);
-        if (rc == ZK_OK && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_evaluate_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_evaluate_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
             rc = ZK_ERR_HIP;
         if (rc == ZK_OK) {
-            k_evaluate_tail<<<1, kEvalTailThreads, lds, c->stream>>>(src, (uint32_t)tail_vars, d_ch, P, d_out_elem);
+            k_evaluate_tail<<<1, kEvalTailThreads, lds, c->stream>>>(src, (uint32_t)tail_vars, chs, P, d_out_elem);
             if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
         }
     }
     if (scratch) pool_free(c, scratch, scratch_bytes);
-    pool_free(c, d_ch, (size_t)kEvalTailVars * kEvalChWords * 4);
     return rc;
 }
 extern "C" int32_t zk_mle_evaluate(zk_ctx *c, const zk_mle *t, const uint64_t *point, uint64_t n_point, uint64_t out[4]) {
@@ -496,8 +505,9 @@ extern "C" int32_t zk_mle_evaluate(zk_ctx *c, const zk_mle *t, const uint64_t *p
     if (n_point != t->n_vars) return ZK_ERR_EVAL_ARITY;   // evaluation_form.rs:84-86
     ZKCHK(use_device(c));
     ZKCHK(evaluate_device(c, t, point, c->d_sums));
-    HIPCHK(hipMemcpyAsync(out, c->d_sums, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_sums, 32, hipMemcpyDeviceToHost, c->stream));   // through pinned memory: one wait
     HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_pinned, 32);
     return ZK_OK;
 }
 

@@ -78,24 +78,51 @@ __global__ __launch_bounds__(kBlock) void k_fold_dev(const uint64_t *in, uint64_
     }
 }
 
+// V consecutive MSB folds in one pass (evaluate, evaluation_form.rs:83-89: n folds in a row at KNOWN assignments): a thread
+// reads the 2^V elements that share the low index j = idx mod 2^(m-V) (element c = (x0..x_{V-1}) sits at c * n_out + j),
+// folds variable 0 over the pairs (c, c + 2^(V-1)), then variable 1, ... exactly in the reference's order, and writes one
+// element: 1/V of the launches and (2^V + 1) / (3 * (2^V - 1)) of the traffic of V single folds.  In place is safe
+// (index j is only touched by its own thread).
+struct FoldChallenges {
+    Mul29 r[3];
+};
+template <int V>
+__global__ __launch_bounds__(kBlock) void k_fold_multi(const uint64_t *in, uint64_t *out, uint64_t n_out, FieldParams P, FoldChallenges ch) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n_out; j += stride) {
+        Fe x[1 << V];
+#pragma unroll
+        for (int c = 0; c < (1 << V); ++c) x[c] = fe_load(in, j + (uint64_t)c * n_out);
+#pragma unroll
+        for (int lvl = 0; lvl < V; ++lvl) {
+#pragma unroll
+            for (int c = 0; c < (1 << (V - 1 - lvl)); ++c)
+                x[c] = fe_sub(x[c], fe_mul29(fe_sub(x[c], x[c + (1 << (V - 1 - lvl))], P), ch.r[lvl], P), P);
+        }
+        fe_store(out, j, x[0]);
+    }
+}
+
 // ---- MultiLinearPolynomial::evaluate, tail (evaluation_form.rs:83-89) -----------------------------------------------------
 // Once the table is small every further fold is launch latency.  One 1024-thread workgroup finishes the last m <= 12
 // variables: the first of them is folded while the 2^m elements are read from HBM (so 2^(m-1) elements = 64 KiB of LDS at
-// m = 12), the rest in place in LDS with one barrier per variable.  ch29: the m remaining assignments, prepared on the
-// host (Mul29 records of kEvalChWords words).
+// m = 12), the rest in place in LDS with one barrier per variable.  chs: the m remaining assignments, prepared on the host.
 constexpr int kEvalTailVars = 12;
 constexpr int kEvalTailThreads = 1024;
-constexpr int kEvalChWords = 16;
+constexpr int kEvalChWords = 9;
+struct EvalTailChallenges {   // the m remaining assignments in prepared form, passed in the kernel arguments (no staging copy)
+    uint32_t w[kEvalTailVars][kEvalChWords];
+};
 __global__ __launch_bounds__(kEvalTailThreads) void k_evaluate_tail(const uint64_t *__restrict__ in, uint32_t m,
-                                                                    const uint32_t *__restrict__ ch29, FieldParams P,
+                                                                    EvalTailChallenges chs, FieldParams P,
                                                                     uint64_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ev_smem[];
     uint64_t *T = reinterpret_cast<uint64_t *>(ev_smem);
     const uint32_t tid = threadIdx.x;
-    auto load_r = [&](uint32_t v) {
+    auto load_r = [&](uint32_t v) {   // v is wave-uniform: scalar loads from the argument segment
         Mul29 r;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) r.l[i] = __builtin_amdgcn_readfirstlane(ch29[v * kEvalChWords + i]);
+        for (int i = 0; i < 9; ++i) r.l[i] = chs.w[v][i];
         return r;
     };
     uint32_t q = 1u << (m - 1);
