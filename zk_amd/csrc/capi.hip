@@ -1425,7 +1425,8 @@ static int32_t verify_internal(const FieldParams &P, Sponge &sp, uint64_t n_roun
         absorb_elements(sp, rp, D + 1, P);                               // :56
         std::vector<Fe> ys(D + 1);
         for (uint32_t t = 0; t <= D; ++t) ys[t] = fe_from_u64limbs(rp + 4 * t);
-        const Fe p0 = interp_eval(ys, w, fe_zero(), P), p1 = interp_eval(ys, w, fe_one(P), P);   // :61-62
+        // :61-62 p(0), p(1): the interpolant through (i, ys[i]) takes exactly ys[0], ys[1] at the nodes 0 and 1
+        const Fe p0 = ys[0], p1 = D >= 1 ? ys[1] : interp_eval(ys, w, fe_one(P), P);
         if (!fe_eq(claimed, fe_add(p0, p1, P))) return ZK_ERR_VERIFY_SUM;                  // :64
         const Fe ch = squeeze_field_element(sp, P);                      // :69
         claimed = interp_eval(ys, w, ch, P);                             // :70
