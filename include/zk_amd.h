@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ZK_AMD_ABI_VERSION 1
+#define ZK_AMD_ABI_VERSION 2   /* 2: + sum-of-products prover, GKR-shaped driver, eq tables, sharded-NTT pieces, root of unity */
 
 typedef enum zk_field {
     ZK_FIELD_BN254_FR = 0,     /* north-star field (not a dependency of the reference: SURVEY D2) */
