@@ -208,3 +208,24 @@ def test_prove_terms_consume_and_fallback_shapes(shape, D):
         poly = gkr.SumOfProductsPoly([[MLE.new(c, n, F(field, t)) for t in term] for term in tabs])
         rp, ch, fin = gkr.prove_partial_terms(poly, D, zk_amd.fe_from_int(field, s), consume=consume)
         assert [I(field, r) for r in rp] == want_rp and I(field, ch) == want_ch and I(field, fin) == want_fin
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_gkr_degenerate_wiring(field):
+    """extreme fan-out (every gate reads input 0 on the left: one CSR row holds all gates, the others are empty), all-add
+    and all-mul layers, a zero input table -- against the model and through the verifier"""
+    c = ctx_for(field)
+    p = zk_amd.modulus(field)
+    rng = random.Random(99 + field)
+    s = 5
+    n = 1 << s
+    layers = [(s, s, [rng.randrange(2) for _ in range(n)], [0] * n, [rng.randrange(n) for _ in range(n)]),
+              (s, s, [0] * n, [rng.randrange(n) for _ in range(n)], [n - 1] * n),
+              (s, s, [1] * n, list(range(n)), list(range(n)))]
+    for inputs in ([rng.randrange(p) for _ in range(n)], [0] * n):
+        want_out, want_proof = gkr_ref.gkr_prove(field, layers, inputs, bytes(32))
+        circ = upload_circuit(c, layers)
+        x = MLE.new(c, s, F(field, inputs))
+        out, proof = gkr.gkr_prove(circ, x, bytes(32))
+        assert I(field, out.evaluation_slice()) == want_out and I(field, proof) == want_proof
+        assert gkr.gkr_verify(circ, x, out, bytes(32), proof)
