@@ -210,15 +210,15 @@ def test_prove_terms_consume_and_fallback_shapes(shape, D):
         assert [I(field, r) for r in rp] == want_rp and I(field, ch) == want_ch and I(field, fin) == want_fin
 
 
+@pytest.mark.parametrize("s", [5, 9])
 @pytest.mark.parametrize("field", FIELDS)
-def test_gkr_degenerate_wiring(field):
+def test_gkr_degenerate_wiring(field, s):
     """extreme fan-out (every gate reads input 0 on the left: one CSR row holds all gates, the others are empty), all-add
     and all-mul layers, a zero input table -- against the model and through the verifier"""
     c = ctx_for(field)
     p = zk_amd.modulus(field)
     rng = random.Random(99 + field)
-    s = 5
-    n = 1 << s
+    n = 1 << s   # s = 9: rows of 512 entries go through the one-workgroup-per-row kernels (kGkrHeavyRow = 256)
     layers = [(s, s, [rng.randrange(2) for _ in range(n)], [0] * n, [rng.randrange(n) for _ in range(n)]),
               (s, s, [0] * n, [rng.randrange(n) for _ in range(n)], [n - 1] * n),
               (s, s, [1] * n, list(range(n)), list(range(n)))]
@@ -229,3 +229,25 @@ def test_gkr_degenerate_wiring(field):
         out, proof = gkr.gkr_prove(circ, x, bytes(32))
         assert I(field, out.evaluation_slice()) == want_out and I(field, proof) == want_proof
         assert gkr.gkr_verify(circ, x, out, bytes(32), proof)
+
+
+def test_gkr_heavy_fanout_width_2p18():
+    """one input wire feeding every gate of a 2^18-wide layer must not serialise on one thread"""
+    import time
+
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    rng = np.random.default_rng(11)
+    w = 18
+    circ = gkr.Circuit(c)
+    circ.add_layer(w, w, rng.integers(0, 2, 1 << w, dtype=np.uint8), np.zeros(1 << w, dtype=np.uint32),
+                   rng.integers(0, 1 << w, 1 << w, dtype=np.uint32))
+    circ.add_layer(w, w, rng.integers(0, 2, 1 << w, dtype=np.uint8), rng.integers(0, 1 << w, 1 << w, dtype=np.uint32),
+                   np.full(1 << w, 5, dtype=np.uint32))
+    x = MLE.random(c, w, 3)
+    out, proof = gkr.gkr_prove(circ, x, bytes(32))
+    t0 = time.perf_counter()
+    out, proof = gkr.gkr_prove(circ, x, bytes(32))
+    dt = time.perf_counter() - t0
+    assert gkr.gkr_verify(circ, x, out, bytes(32), proof)
+    assert dt < 0.05, f"heavy fan-out proof took {dt * 1e3:.1f} ms"

@@ -90,6 +90,79 @@ __global__ __launch_bounds__(kBlock) void k_gkr_forward(const uint8_t *__restric
     }
 }
 
+// Rows longer than this (an input wire that feeds very many gates) are left to a whole workgroup each: a single thread
+// walking 2^20 entries would take a second.
+constexpr uint32_t kGkrHeavyRow = 256;
+// two field sums per thread -> workgroup totals in sum[] of thread 0
+ZK_D void gkr_block_sum2(Fe (&sum)[2], const FieldParams &P) {
+    __shared__ uint32_t red2[kBlock / 64][2][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        sum[t] = fe_wave_sum(sum[t], P);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red2[wave][t][i] = sum[t].v[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            Fe acc = fe_zero();
+            for (int w = 0; w < kBlock / 64; ++w) {
+                Fe o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o.v[i] = red2[w][t][i];
+                acc = fe_add(acc, o, P);
+            }
+            sum[t] = acc;
+        }
+    }
+}
+// heavy rows of phase 1 / phase 2: workgroup b takes row heavy[b]
+__global__ __launch_bounds__(kBlock) void k_gkr_phase1_heavy(const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ lptr,
+                                                             const uint2 *__restrict__ lent, const uint64_t *__restrict__ E,
+                                                             const uint64_t *__restrict__ W, uint64_t *__restrict__ H,
+                                                             uint64_t *__restrict__ B1, FieldParams P) {
+    const uint32_t x = heavy[blockIdx.x];
+    Fe s[2] = {fe_zero(), fe_zero()};   // h, b
+    for (uint32_t e = lptr[x] + threadIdx.x; e < lptr[x + 1]; e += kBlock) {
+        const uint2 ent = lent[e];
+        const Fe ez = fe_load(E, ent.x), t = fe_mul(ez, fe_load(W, ent.y & 0x7FFFFFFFu), P);
+        if (ent.y >> 31) {
+            s[0] = fe_add(s[0], t, P);
+        } else {
+            s[0] = fe_add(s[0], ez, P);
+            s[1] = fe_add(s[1], t, P);
+        }
+    }
+    gkr_block_sum2(s, P);
+    if (threadIdx.x == 0) {
+        fe_store(H, x, s[0]);
+        fe_store(B1, x, s[1]);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_gkr_phase2_heavy(const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ rptr,
+                                                             const uint2 *__restrict__ rent, const uint64_t *__restrict__ E,
+                                                             const uint64_t *__restrict__ eq_u, const uint64_t *__restrict__ wu,
+                                                             uint64_t *__restrict__ H2, uint64_t *__restrict__ C2, FieldParams P) {
+    const uint32_t y = heavy[blockIdx.x];
+    Fe s[2] = {fe_zero(), fe_zero()};   // a, m
+    for (uint32_t e = rptr[y] + threadIdx.x; e < rptr[y + 1]; e += kBlock) {
+        const uint2 ent = rent[e];
+        const Fe t = fe_mul(fe_load(E, ent.x), fe_load(eq_u, ent.y & 0x7FFFFFFFu), P);
+        if (ent.y >> 31) s[1] = fe_add(s[1], t, P);
+        else s[0] = fe_add(s[0], t, P);
+    }
+    gkr_block_sum2(s, P);
+    if (threadIdx.x == 0) {
+        const Fe w = fe_load(wu, 0);
+        fe_store(H2, y, fe_add(s[0], fe_mul(w, s[1], P), P));
+        fe_store(C2, y, fe_mul(w, s[0], P));
+    }
+}
+
 // phase 1 bookkeeping: one thread per x (row of the by-left CSR).  A CSR entry is {z, other | op << 31}: the gate's
 // output index and its OTHER input (right for the by-left index), so a row needs no second indirection through the gate
 // arrays -- the only random accesses left are the two 32-byte elements E[z] and W[y].
@@ -99,6 +172,7 @@ __global__ __launch_bounds__(kBlock) void k_gkr_phase1(const uint32_t *__restric
                                                        FieldParams P) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < n_in; x += stride) {
+        if (lptr[x + 1] - lptr[x] > kGkrHeavyRow) continue;   // a whole workgroup takes that row (k_gkr_phase1_heavy)
         Fe h = fe_zero(), b = fe_zero();
         for (uint32_t e = lptr[x]; e < lptr[x + 1]; ++e) {
             const uint2 ent = lent[e];
@@ -122,6 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_gkr_phase2(const uint32_t *__restric
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const Fe w = fe_load(wu, 0);
     for (uint64_t y = (uint64_t)blockIdx.x * kBlock + threadIdx.x; y < n_in; y += stride) {
+        if (rptr[y + 1] - rptr[y] > kGkrHeavyRow) continue;   // k_gkr_phase2_heavy
         Fe a = fe_zero(), m = fe_zero();
         for (uint32_t e = rptr[y]; e < rptr[y + 1]; ++e) {
             const uint2 ent = rent[e];
