@@ -1,0 +1,58 @@
+"""Randomised soak: prove_partial / prove_partial_terms / evaluate / fold on random (field, k, D, n) against the CPU oracle and
+the big-int model, bit for bit.  Not part of the test-suite (minutes); run on the GPU box: python tools/soak.py [seconds] [seed]"""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import zk_amd
+from oracle import binding as orc
+from oracle import gkr_ref
+from zk_amd import MultiLinearPolynomial as MLE
+from zk_amd import ProductPoly, SumcheckProver, gkr
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctxs = {f: zk_amd.Context(f, 0) for f in (0, 1, 2)}
+t_end = time.time() + budget
+n_cases = 0
+while time.time() < t_end:
+    f = rng.randrange(3)
+    c = ctxs[f]
+    p = zk_amd.modulus(f)
+    kind = rng.choice(["prove", "prove", "terms", "evaluate", "fold"])
+    if kind == "prove":
+        k = rng.choice([1, 2, 2, 3, 3, 4, 5, 8])
+        D = rng.choice([max(1, k), k, k + 1, rng.randrange(1, 7)])
+        n = rng.choice([1, 2, 3, 5, 8, 10, 11, 12, 13, 14, 15, 16, 17] if k <= 3 else [1, 4, 9, 11, 13])
+        tabs = [orc.fill_random(f, rng.randrange(1 << 30), 1 << n) for _ in range(k)]
+        s = orc.fill_random(f, rng.randrange(1 << 30), 1)[0]   # any claimed sum: the transcript must still match
+        want_rp, want_ch = orc.sumcheck_prove(f, n, tabs, D, s, False)
+        pp = ProductPoly.new([MLE.new(c, n, t) for t in tabs])
+        proof, ch = SumcheckProver(D).prove_partial(pp, s, consume=rng.random() < 0.5)
+        assert np.array_equal(proof.round_polys, want_rp) and np.array_equal(ch, want_ch), ("prove", f, k, D, n)
+    elif kind == "terms":
+        shape = rng.choice([[2, 1], [2, 1], [3, 1], [1, 1], [2, 2], [2, 1, 1], [3, 2]])
+        D = max(shape) + rng.randrange(2)
+        n = rng.choice([1, 3, 6, 9, 10, 11, 12])
+        tabs = [[[rng.randrange(p) for _ in range(1 << n)] for _ in range(kk)] for kk in shape]
+        s = rng.randrange(p)
+        want = gkr_ref.prove_partial_terms(f, tabs, D, s)
+        poly = gkr.SumOfProductsPoly([[MLE.new(c, n, zk_amd.fe_from_ints(f, t)) for t in term] for term in tabs])
+        rp, ch, fin = gkr.prove_partial_terms(poly, D, zk_amd.fe_from_int(f, s))
+        assert [zk_amd.fe_to_ints(f, r) for r in rp] == want[0] and zk_amd.fe_to_ints(f, ch) == want[1], ("terms", f, shape, D, n)
+        assert zk_amd.fe_to_ints(f, fin) == want[2], ("terms finals", f, shape, D, n)
+    elif kind == "evaluate":
+        n = rng.randrange(0, 19)
+        t = orc.fill_random(f, rng.randrange(1 << 30), 1 << n)
+        pt = orc.fill_random(f, rng.randrange(1 << 30), max(n, 1))[:n]
+        got = MLE.new(c, n, t).evaluate(pt)
+        assert np.array_equal(got, orc.mle_evaluate(f, n, t, pt)), ("evaluate", f, n)
+    else:
+        n = rng.randrange(1, 17)
+        iv = rng.randrange(n)
+        na = rng.randrange(1, n - iv + 1)
+        t = orc.fill_random(f, rng.randrange(1 << 30), 1 << n)
+        a = orc.fill_random(f, rng.randrange(1 << 30), na)
+        got = MLE.new(c, n, t).partial_evaluate(iv, a).evaluation_slice()
+        assert np.array_equal(got, orc.mle_partial_evaluate(f, n, t, iv, a)), ("fold", f, n, iv, na)
+    n_cases += 1
+print(f"soak ok: {n_cases} random cases bit-exact in {budget:.0f} s")
