@@ -207,6 +207,21 @@ def main():
             o20 = zk_amd.MultiLinearPolynomial.alloc(ctx, 19)
             extra["fold_2p20_us"] = t20.bench_fold(r, o20, 50) * 1e3
             t20.free(); o20.free()
+            # the reference's own criterion bench (polynomial/benches/polynomial_evaluation.rs): evaluate at 18..21 variables
+            tr2 = zk_amd.Transcript()
+            tr2.append(b"zk_amd bench evaluate")
+            for n in (18, 19, 20, 21):
+                tn = zk_amd.MultiLinearPolynomial.random(ctx, n, 0x5EED0E00 + n, 0)
+                pt = tr2.sample_n_field_elements(field, n)
+                tn.evaluate(pt)
+                ts = []
+                for _ in range(11):
+                    ctx.synchronize()
+                    t1 = time.perf_counter()
+                    tn.evaluate(pt)
+                    ts.append(time.perf_counter() - t1)
+                extra[f"evaluate_us_n{n}"] = sorted(ts)[5] * 1e6
+                tn.free()
             # config[3]: GKR-shaped load -- no gkr crate exists in the reference; what it would call is
             # prove_partial on one ProductPoly per layer: depth 8, width 2^20, product of 3 MLEs, degree 3
             layers = []
