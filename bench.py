@@ -69,11 +69,18 @@ def cpu_baseline(field):
         t1 = time.perf_counter()
         orc.sumcheck_prove(field, ns, tabs, 2, orc.fill_random(field, 5, 1)[0], False)
         cpu_prove[ns] = (time.perf_counter() - t1) * 1e3
+    # the reference's own criterion bench on the CPU restatement: evaluate at 20 variables (n clone + fold + copy steps)
+    t20 = orc.fill_random(field, 0x5EED0E00 + 20, 1 << 20)
+    pt20 = orc.fill_random(field, 0xE7A1, 20)
+    t1 = time.perf_counter()
+    orc.mle_evaluate(field, 20, t20, pt20)
+    cpu_eval_ms = (time.perf_counter() - t1) * 1e3
     return {
         "value": ops / dt,
         "unit": "field-ops/s",
         "cores": 1,
         "kind": "port",
+        "evaluate_ms_n20": cpu_eval_ms,
         "sample": f"{reps} folds of a 2^{n}-element BN254-Fr table (clone + fold + copy as evaluation_form.rs:49-79), "
                   f"{dt:.1f} s, single thread (the reference is single-threaded)",
         "sumcheck_prove_partial_ms_n12_k2_d2": cpu_prove[12],
