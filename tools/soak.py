@@ -18,7 +18,7 @@ while time.time() < t_end:
     f = rng.randrange(3)
     c = ctxs[f]
     p = zk_amd.modulus(f)
-    kind = rng.choice(["prove", "prove", "terms", "evaluate", "fold"])
+    kind = rng.choice(["prove", "prove", "terms", "evaluate", "fold", "gkr"])
     if kind == "prove":
         k = rng.choice([1, 2, 2, 3, 3, 4, 5, 8])
         D = rng.choice([max(1, k), k, k + 1, rng.randrange(1, 7)])
@@ -40,6 +40,28 @@ while time.time() < t_end:
         rp, ch, fin = gkr.prove_partial_terms(poly, D, zk_amd.fe_from_int(f, s))
         assert [zk_amd.fe_to_ints(f, r) for r in rp] == want[0] and zk_amd.fe_to_ints(f, ch) == want[1], ("terms", f, shape, D, n)
         assert zk_amd.fe_to_ints(f, fin) == want[2], ("terms finals", f, shape, D, n)
+    elif kind == "gkr":
+        depth = rng.randrange(1, 4)
+        logs = [rng.randrange(0, 6)] + [rng.randrange(1, 7) for _ in range(depth)]
+        layers = []
+        for i in range(depth):
+            ng, nin = 1 << logs[i], 1 << logs[i + 1]
+            heavy = rng.random() < 0.2
+            layers.append((logs[i], logs[i + 1], [rng.randrange(2) for _ in range(ng)],
+                           [0 if heavy else rng.randrange(nin) for _ in range(ng)], [rng.randrange(nin) for _ in range(ng)]))
+        inputs = [rng.randrange(p) for _ in range(1 << logs[-1])]
+        seed = bytes(rng.randrange(256) for _ in range(32))
+        want_out, want_proof = gkr_ref.gkr_prove(f, layers, inputs, seed)
+        circ = gkr.Circuit(c)
+        for lo, li, op, left, right in layers:
+            circ.add_layer(lo, li, op, left, right)
+        x = MLE.new(c, logs[-1], zk_amd.fe_from_ints(f, inputs))
+        out, proof = gkr.gkr_prove(circ, x, seed)
+        assert zk_amd.fe_to_ints(f, proof) == want_proof and zk_amd.fe_to_ints(f, out.evaluation_slice()) == want_out, ("gkr", f, logs)
+        assert gkr.gkr_verify(circ, x, out, seed, proof), ("gkr verify", f, logs)
+        bad = proof.copy()
+        bad[rng.randrange(len(want_proof))] = zk_amd.fe_from_int(f, rng.randrange(p))
+        assert not gkr.gkr_verify(circ, x, out, seed, bad) or zk_amd.fe_to_ints(f, bad) == want_proof, ("gkr tamper", f, logs)
     elif kind == "evaluate":
         n = rng.randrange(0, 19)
         t = orc.fill_random(f, rng.randrange(1 << 30), 1 << n)
