@@ -273,6 +273,22 @@ def main():
                 extra["gkr_depth8_width2p20_addmul_verify_ms"] = (time.perf_counter() - t1) * 1e3
                 extra["gkr_depth8_width2p20_addmul_verified"] = bool(ok)
                 extra["gkr_proof_bytes"] = int(proof.size * 8)
+                out.free(); circ.free()
+                # the same depth and width with STRUCTURED wiring (butterfly: gate z reads z and z xor 2^(layer)): the bookkeeping
+                # gathers of the random circuit above are its worst case (every E[z], W[y] access is a random 32-byte read)
+                circ = gkr.Circuit(ctx)
+                zidx = np.arange(1 << w, dtype=np.uint32)
+                for layer in range(8):
+                    circ.add_layer(w, w, ((zidx >> 1) & 1).astype(np.uint8), zidx, zidx ^ np.uint32(1 << (layer + 3)))
+                out, proof = gkr.gkr_prove(circ, xin, seed)
+                ts = []
+                for _ in range(3):
+                    ctx.synchronize()
+                    t1 = time.perf_counter()
+                    out, proof = gkr.gkr_prove(circ, xin, seed)
+                    ts.append(time.perf_counter() - t1)
+                extra["gkr_depth8_width2p20_butterfly_prove_ms"] = sorted(ts)[1] * 1e3
+                extra["gkr_depth8_width2p20_butterfly_verified"] = bool(gkr.gkr_verify(circ, xin, out, seed, proof))
                 out.free(); xin.free(); circ.free()
             except Exception as e:
                 extra["gkr_error"] = repr(e)
