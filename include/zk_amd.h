@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ZK_AMD_ABI_VERSION 2   /* 2: + sum-of-products prover, GKR-shaped driver, eq tables, sharded-NTT pieces, root of unity */
+#define ZK_AMD_ABI_VERSION 3   /* 3: + zk_comm (RCCL / host), zk_shard_prover_run, zk_ntt_sharded, sample_n, zk_ctx_trim, zk_mle_equal */
 
 typedef enum zk_field {
     ZK_FIELD_BN254_FR = 0,     /* north-star field (not a dependency of the reference: SURVEY D2) */
@@ -56,7 +56,8 @@ typedef enum zk_status {
     ZK_ERR_ALLOC = -24,
     ZK_ERR_UNSUPPORTED = -25,
     ZK_ERR_CONTEXT_MISMATCH = -26,
-    ZK_ERR_GKR_REJECT = -27     /* GKR-shaped driver: a layer's wiring check or the input-layer check failed (no reference text) */
+    ZK_ERR_GKR_REJECT = -27,    /* GKR-shaped driver: a layer's wiring check or the input-layer check failed (no reference text) */
+    ZK_ERR_COMM = -28           /* a collective failed (RCCL error text in zk_last_hip_error) or librccl could not be loaded */
 } zk_status;
 
 typedef struct zk_ctx zk_ctx;               /* one device + stream + scratch */
@@ -78,6 +79,9 @@ int32_t zk_ctx_synchronize(zk_ctx *ctx);
 int32_t zk_ctx_set_stream(zk_ctx *ctx, void *hip_stream);
 int32_t zk_ctx_use_own_stream(zk_ctx *ctx);
 int32_t zk_ctx_field(const zk_ctx *ctx, int32_t *out_field);
+/* freed tables are kept in a per-context pool (hipMalloc/hipFree of a 512 MiB block costs more than a 2^24 fold); the pool
+ * is trimmed automatically when it exceeds half of the device's free memory or an allocation fails; this drops it now. */
+int32_t zk_ctx_trim(zk_ctx *ctx);
 /* modulus as 4 LE limbs; two-adicity s of p-1 */
 int32_t zk_field_modulus(int32_t field, uint64_t out_p[4]);
 int32_t zk_field_two_adicity(int32_t field, int32_t *out_s);
@@ -100,6 +104,8 @@ int32_t zk_mle_free(zk_ctx *ctx, zk_mle *t);
 int32_t zk_mle_n_vars(const zk_mle *t, uint64_t *out_n_vars);                         /* ::n_vars :30 */
 int32_t zk_mle_download(zk_ctx *ctx, const zk_mle *t, uint64_t *out_evals);           /* ::evaluation_slice :92 */
 int32_t zk_mle_device_ptr(const zk_mle *t, void **out_ptr);                           /* raw device pointer (interop) */
+/* #[derive(PartialEq)] :4 -- n_vars and every evaluation equal (compared on the device; canonical representation) */
+int32_t zk_mle_equal(zk_ctx *ctx, const zk_mle *a, const zk_mle *b, int32_t *out_equal);
 /* ::partial_evaluate(initial_var, assignments) :40-80 -> new table of n_vars - n_assign variables */
 int32_t zk_mle_partial_evaluate(zk_ctx *ctx, const zk_mle *t, uint64_t initial_var,
                                 const uint64_t *assignments, uint64_t n_assign, zk_mle **out);
@@ -141,6 +147,7 @@ int32_t zk_transcript_new(zk_transcript **out);                                 
 int32_t zk_transcript_free(zk_transcript *t);
 int32_t zk_transcript_append(zk_transcript *t, const uint8_t *data, size_t len);       /* ::append :16-18 */
 int32_t zk_transcript_sample_field_element(zk_transcript *t, int32_t field, uint64_t out[4]); /* :27-30 */
+int32_t zk_transcript_sample_n_field_elements(zk_transcript *t, int32_t field, uint64_t n, uint64_t *out); /* :32-34, n*4 u64 */
 int32_t zk_transcript_sample_challenge(zk_transcript *t, uint8_t out[32]);             /* :20-25 (private in the reference) */
 int32_t zk_keccak256(const uint8_t *data, size_t len, uint8_t out[32]);
 
@@ -185,6 +192,39 @@ int32_t zk_shard_prover_round_finish(zk_shard_prover *sp);
 int32_t zk_shard_prover_tail_ptr(zk_shard_prover *sp, void **out_device_ptr, uint64_t *out_n_elems);
 int32_t zk_shard_prover_tail_rounds(zk_shard_prover *sp, const void *gathered_device /* [world][k][2^s] elements */);
 int32_t zk_shard_prover_results(zk_shard_prover *sp, uint64_t *out_round_polys, uint64_t *out_challenges);
+/* ---- communicator: the exchange steps of the sharded paths, driven from inside the library --------------------------
+ * One zk_comm per rank (= per process = per GPU).  Two kinds:
+ *   RCCL (the product path, xGMI): zk_comm_unique_id on one rank, the 128 bytes distributed by the host's own means (the
+ *     Rust side: any channel it already has; Python: torch.distributed), then zk_comm_create_rccl on every rank
+ *     (ncclCommInitRank); or zk_comm_wrap_rccl around a ncclComm_t the host already owns.  librccl.so.1 is dlopen'ed on
+ *     first use, so single-GPU users never load it.  Collectives are enqueued on the context's stream: no host waits.
+ *   host callbacks (tests / hosts with their own transport): the library stages the buffer through pinned memory,
+ *     synchronises, and calls back; the callbacks return 0 on success.  Same control flow, different transport.
+ *       allreduce(user, buf, n)               : buf[i] <- sum over ranks of buf[i], n uint64 lanes (cannot overflow)
+ *       allgather(user, send, n, recv)        : recv[r*n .. r*n+n) <- rank r's send
+ *       alltoall (user, send, recv, n)        : recv[r*n .. ) <- rank r's send[me*n .. ), n uint64 per peer */
+typedef struct zk_comm zk_comm;
+typedef int32_t (*zk_host_allreduce_fn)(void *user, uint64_t *buf, uint64_t n);
+typedef int32_t (*zk_host_allgather_fn)(void *user, const uint64_t *send, uint64_t n, uint64_t *recv);
+typedef int32_t (*zk_host_alltoall_fn)(void *user, const uint64_t *send, uint64_t *recv, uint64_t n_per_peer);
+int32_t zk_comm_unique_id(uint8_t out_id[128]);
+int32_t zk_comm_create_rccl(zk_ctx *ctx, const uint8_t id[128], uint32_t world, uint32_t rank, zk_comm **out);
+int32_t zk_comm_wrap_rccl(zk_ctx *ctx, void *nccl_comm, uint32_t world, uint32_t rank, zk_comm **out);
+int32_t zk_comm_create_host(zk_ctx *ctx, uint32_t world, uint32_t rank, zk_host_allreduce_fn allreduce,
+                            zk_host_allgather_fn allgather, zk_host_alltoall_fn alltoall, void *user, zk_comm **out);
+int32_t zk_comm_destroy(zk_comm *comm);
+/* The WHOLE sharded prover (prove_partial, sumcheck/src/prover.rs:24-30,44-68) on a freshly created zk_shard_prover:
+ * per local round {round_begin -> all-reduce of the (D+1)*8 lanes -> round_finish} while more than `gather_below` local
+ * variables remain, then tail_ptr -> all-gather -> tail_rounds.  With an RCCL comm everything is enqueued on the context's
+ * stream with ZERO host synchronisations (the all-reduce is the round's one collective); fetch the proof with
+ * zk_shard_prover_results.  Every rank calls it with the same arguments. */
+int32_t zk_shard_prover_run(zk_shard_prover *sp, zk_comm *comm, uint32_t gather_below);
+/* fft / ifft (fft/src/lib.rs:4-19) of an N = world * 2^m point vector held as index-mod-world shards ("strided": rank r
+ * holds x[r + world*j]); ONE all-to-all.  forward: strided in -> "sliced" out (rank s holds X[k], k mod M in its slice of
+ * M / world, as world rows of M / world); inverse: sliced in -> strided out, scaled 1/N.  shard is not modified;
+ * out != shard, same size.  m >= log2 world.  Asynchronous with an RCCL comm. */
+int32_t zk_ntt_sharded(zk_ctx *ctx, zk_comm *comm, const zk_mle *shard, int32_t inverse, zk_mle *out);
+
 /* raw device buffers on the context (pooled) and synchronous copies: for hosts that drive the exchange themselves */
 int32_t zk_ctx_device_alloc(zk_ctx *ctx, uint64_t bytes, void **out_device_ptr);
 int32_t zk_ctx_device_free(zk_ctx *ctx, void *device_ptr, uint64_t bytes);

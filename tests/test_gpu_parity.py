@@ -528,3 +528,70 @@ def test_beyond_baseline_sizes_properties():
     assert zk_amd.fe_to_int(field, w.evaluate(pt)) == zk_amd.fe_to_int(field, x.evaluate(pt))
     assert zk_amd.fe_to_int(field, y.evaluate(pt)) != zk_amd.fe_to_int(field, x.evaluate(pt))
     x.free(); y.free(); w.free()
+
+
+# ---- round 2 additions ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("field", FIELDS)
+def test_partial_eq_on_device(field):
+    """#[derive(PartialEq)] (evaluation_form.rs:4) through zk_mle_equal"""
+    c = zk_amd.Context(field, 0)
+    t = orc.fill_random(field, 31, 1 << 11)
+    a, b = MLE.new(c, 11, t), MLE.new(c, 11, t)
+    assert a == b and a == a.clone()
+    t2 = t.copy()
+    t2[-1, 3] ^= np.uint64(1)   # one bit in the last limb of the last element
+    assert a != MLE.new(c, 11, t2)
+    assert a != MLE.new(c, 10, t[: 1 << 10])
+
+
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("k,D,n_vars", [(2, 2, 6), (2, 4, 7), (4, 4, 6), (3, 3, 9), (2, 2, 13)])
+def test_product_with_a_repeated_factor(field, k, D, n_vars):
+    """ProductPoly::new(vec![a.clone(), a, ..]) is legal in the reference (it owns clones); the same HANDLE listed twice
+    must give the same proof, also with consume (in-place folds would fold the shared buffer once per listing)."""
+    c = zk_amd.Context(field, 0)
+    t = orc.fill_random(field, 41, 1 << n_vars)
+    u = orc.fill_random(field, 42, 1 << n_vars)
+    tabs = [t, t] + [u] * (k - 2)
+    claimed = np.zeros(4, dtype=np.uint64)
+    for e in orc.prod_reduce(field, n_vars, tabs):
+        claimed = orc.add(field, claimed, e)
+    want_rp, want_ch = orc.sumcheck_prove(field, n_vars, tabs, D, claimed, False)
+    for consume in (False, True):
+        a, b = MLE.new(c, n_vars, t), MLE.new(c, n_vars, u)
+        pp = ProductPoly.new([a, a] + [b] * (k - 2))
+        proof, ch = zk_amd.SumcheckProver(D)._run(pp, claimed, False, consume)
+        assert np.array_equal(proof.round_polys, want_rp) and np.array_equal(ch, want_ch), consume
+
+
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("lg", [1, 2, 4, 6, 9])
+def test_fft_internal_with_a_non_primitive_omega(field, lg):
+    """fft_internal(values, omega) takes ANY omega (fft/src/lib.rs:21): the reference multiplies by omega^(i + n/2)
+    literally (:41), which is -omega^i only for a primitive n-th root.  Random omega, omega = 1, and a primitive root of
+    the wrong order, against the faithful recursive oracle."""
+    c = zk_amd.Context(field, 0)
+    n = 1 << lg
+    v = orc.fill_random(field, 51 + lg, n)
+    omegas = [orc.fill_random(field, 52, 1)[0], zk_amd.fe_from_int(field, 1), zk_amd.root_of_unity(field, lg + 2)]
+    for w in omegas:
+        want = np.zeros_like(v)
+        orc._check(orc._lib.orc_fft_internal(field, orc._p(v), orc._c.c_uint64(n), orc._p(w), orc._p(want)))
+        assert np.array_equal(zk_amd.fft_internal(c, v, w), want)
+
+
+def test_sample_n_and_trim():
+    field = zk_amd.BN254_FR
+    t1, t2 = zk_amd.Transcript(), zk_amd.Transcript()
+    t1.append(b"abc")
+    t2.append(b"abc")
+    many = t1.sample_n_field_elements(field, 5)                      # zk_transcript_sample_n_field_elements
+    assert np.array_equal(many, np.stack([t2.sample_field_element(field) for _ in range(5)]))
+    assert t1.sample_n_field_elements(field, 0).shape == (0, 4)
+    c = zk_amd.Context(field, 0)
+    a = MLE.random(c, 20, 1, 0)
+    want = a.evaluation_slice()
+    b = a.clone()
+    b.free()
+    c.trim()                                                         # zk_ctx_trim: the freed block goes back to the device
+    assert np.array_equal(a.evaluation_slice(), want)

@@ -146,3 +146,49 @@ def test_sharded_ntt_needs_world_elements_per_shard():
         GpuNttBackend(MLE.random(ctx, 2, 1), 0, 8)
     with pytest.raises(ValueError, match="power of two"):
         GpuNttBackend(MLE.random(ctx, 4, 1), 0, 3)
+
+
+# ---- the whole loop inside the library over RCCL (zk_shard_prover_run / zk_ntt_sharded), one rank ------------------------
+# The multi-rank form of the same calls runs in tests/test_gpu_multiproc.py over the host-callback transport (RCCL refuses
+# two ranks on one device); here the RCCL transport itself -- communicator creation from a unique id, ncclAllReduce /
+# ncclAllGather / ncclAllToAll enqueued on the context's stream -- runs at world 1 and must reproduce prove_partial.
+@pytest.mark.parametrize("field", [zk_amd.BN254_FR, zk_amd.BLS12_381_FR])
+def test_rccl_world1_run_matches_prove_partial_and_oracle(field):
+    from zk_amd.distributed import RcclComm, ntt_sharded
+
+    ctx = zk_amd.Context(field, 0)
+    comm = RcclComm(ctx)
+    assert (comm.world, comm.rank) == (1, 0)
+    for n, k, D, gather_below in [(12, 2, 2, 10), (14, 2, 2, 0), (16, 2, 2, 10), (13, 3, 3, 4), (18, 2, 2, 10)]:
+        tabs = [orc.fill_random(field, 1400 + 8 * n + f, 1 << n) for f in range(k)]
+        claimed = claimed_sum(field, n, tabs)
+        poly = ProductPoly.new([MLE.new(ctx, n, t) for t in tabs])
+        plain_proof, plain_ch = zk_amd.SumcheckProver(D).prove_partial(poly, claimed)
+        rp, ch = GpuShardBackend(poly, D, claimed, 1).run(comm, gather_below)
+        assert np.array_equal(rp, plain_proof.round_polys) and np.array_equal(ch, plain_ch), (n, k, D, gather_below)
+        if n <= 16:
+            want_rp, want_ch = orc.sumcheck_prove(field, n, tabs, D, claimed, False)
+            assert np.array_equal(rp, want_rp) and np.array_equal(ch, want_ch)
+    # at world 1 the sharded transform is the plain one (the all-to-all is the identity, the across-step a 1-point DFT)
+    x = orc.fill_random(field, 1500, 1 << 12)
+    xs = MLE.new(ctx, 12, x)
+    X = ntt_sharded(comm, xs, False)
+    assert np.array_equal(X.evaluation_slice(), orc.ntt_fast(field, x, False))
+    assert np.array_equal(ntt_sharded(comm, X, True).evaluation_slice(), x)
+    ctx.use_own_stream()
+    comm.close()
+    ctx.close()
+
+
+def test_comm_argument_checks():
+    from zk_amd._lib import ZkError, c, check, lib
+
+    ctx = zk_amd.Context(zk_amd.BN254_FR, 0)
+    h = c.c_void_p()
+    with pytest.raises(ZkError):   # world must be a power of two, rank < world
+        check(lib.zk_comm_create_rccl(ctx._h, bytes(128), 3, 0, c.byref(h)))
+    with pytest.raises(ZkError):
+        check(lib.zk_comm_create_rccl(ctx._h, bytes(128), 2, 2, c.byref(h)))
+    with pytest.raises(ZkError):   # host transport needs its callbacks
+        check(lib.zk_comm_create_host(ctx._h, 2, 0, None, None, None, None, c.byref(h)))
+    ctx.close()

@@ -65,6 +65,11 @@ def check(rc):
     return rc
 
 
+# host-transport callbacks of zk_comm_create_host (include/zk_amd.h)
+HOST_ALLREDUCE = c.CFUNCTYPE(c.c_int32, c.c_void_p, u64p, c.c_uint64)
+HOST_ALLGATHER = c.CFUNCTYPE(c.c_int32, c.c_void_p, u64p, c.c_uint64, u64p)
+HOST_ALLTOALL = c.CFUNCTYPE(c.c_int32, c.c_void_p, u64p, u64p, c.c_uint64)
+
 # explicit signatures (everything returns int32 status unless set above)
 _sig = {
     "zk_device_count": [c.POINTER(c.c_int32)],
@@ -74,6 +79,7 @@ _sig = {
     "zk_ctx_set_stream": [c.c_void_p, c.c_void_p],
     "zk_ctx_use_own_stream": [c.c_void_p],
     "zk_ctx_field": [c.c_void_p, c.POINTER(c.c_int32)],
+    "zk_ctx_trim": [c.c_void_p],
     "zk_field_modulus": [c.c_int32, u64p],
     "zk_field_two_adicity": [c.c_int32, c.POINTER(c.c_int32)],
     "zk_field_root_of_unity": [c.c_int32, c.c_uint64, u64p],
@@ -89,6 +95,7 @@ _sig = {
     "zk_mle_n_vars": [c.c_void_p, u64p],
     "zk_mle_download": [c.c_void_p, c.c_void_p, u64p],
     "zk_mle_device_ptr": [c.c_void_p, vpp],
+    "zk_mle_equal": [c.c_void_p, c.c_void_p, c.c_void_p, c.POINTER(c.c_int32)],
     "zk_mle_partial_evaluate": [c.c_void_p, c.c_void_p, c.c_uint64, u64p, c.c_uint64, vpp],
     "zk_mle_fold_into": [c.c_void_p, c.c_void_p, u64p, c.c_void_p],
     "zk_mle_evaluate": [c.c_void_p, c.c_void_p, u64p, c.c_uint64, u64p],
@@ -103,6 +110,7 @@ _sig = {
     "zk_transcript_free": [c.c_void_p],
     "zk_transcript_append": [c.c_void_p, c.c_char_p, c.c_size_t],
     "zk_transcript_sample_field_element": [c.c_void_p, c.c_int32, u64p],
+    "zk_transcript_sample_n_field_elements": [c.c_void_p, c.c_int32, c.c_uint64, u64p],
     "zk_transcript_sample_challenge": [c.c_void_p, c.c_char_p],
     "zk_keccak256": [c.c_char_p, c.c_size_t, c.c_char_p],
     "zk_sumcheck_prove": [c.c_void_p, vpp, c.c_uint64, c.c_uint32, u64p, c.c_int32, c.c_int32, u64p, u64p],
@@ -116,6 +124,13 @@ _sig = {
     "zk_shard_prover_tail_ptr": [c.c_void_p, vpp, u64p],
     "zk_shard_prover_tail_rounds": [c.c_void_p, c.c_void_p],
     "zk_shard_prover_results": [c.c_void_p, u64p, u64p],
+    "zk_comm_unique_id": [c.c_char_p],
+    "zk_comm_create_rccl": [c.c_void_p, c.c_char_p, c.c_uint32, c.c_uint32, vpp],
+    "zk_comm_wrap_rccl": [c.c_void_p, c.c_void_p, c.c_uint32, c.c_uint32, vpp],
+    "zk_comm_create_host": [c.c_void_p, c.c_uint32, c.c_uint32, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, vpp],
+    "zk_comm_destroy": [c.c_void_p],
+    "zk_shard_prover_run": [c.c_void_p, c.c_void_p, c.c_uint32],
+    "zk_ntt_sharded": [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_void_p],
     "zk_ctx_device_alloc": [c.c_void_p, c.c_uint64, vpp],
     "zk_ctx_device_free": [c.c_void_p, c.c_void_p, c.c_uint64],
     "zk_ctx_memcpy_dtoh": [c.c_void_p, c.c_void_p, c.c_void_p, c.c_uint64],

@@ -107,8 +107,10 @@ class Transcript:
         check(lib.zk_transcript_sample_field_element(self._h, field, _p(out)))
         return out
 
-    def sample_n_field_elements(self, field, n):
-        return np.stack([self.sample_field_element(field) for _ in range(n)]) if n else np.zeros((0, 4), np.uint64)
+    def sample_n_field_elements(self, field, n):   # transcript/src/lib.rs:32-34
+        out = np.zeros((n, 4), dtype=np.uint64)
+        check(lib.zk_transcript_sample_n_field_elements(self._h, field, n, _p(out)))
+        return out
 
 
 # ---- device context ------------------------------------------------------------------------------------------
@@ -137,6 +139,10 @@ class Context:
 
     def use_own_stream(self):
         check(lib.zk_ctx_use_own_stream(self._h))
+
+    def trim(self):
+        """drop the context's cache of freed device blocks (zk_ctx_trim)"""
+        check(lib.zk_ctx_trim(self._h))
 
     def use_torch_stream(self):
         """share torch's current stream on this device, so kernels and torch.distributed collectives are ordered"""
@@ -248,8 +254,15 @@ class MultiLinearPolynomial:
         return out.tobytes()
 
     def __eq__(self, other):  # #[derive(PartialEq)] (evaluation_form.rs:4)
-        return (isinstance(other, MultiLinearPolynomial) and self.n_vars() == other.n_vars()
-                and np.array_equal(self.evaluation_slice(), other.evaluation_slice()))
+        if not isinstance(other, MultiLinearPolynomial):
+            return NotImplemented
+        if other.ctx is not self.ctx:   # different contexts: compare on the host
+            return self.n_vars() == other.n_vars() and np.array_equal(self.evaluation_slice(), other.evaluation_slice())
+        eq = c.c_int32()
+        check(lib.zk_mle_equal(self.ctx._h, self._h, other._h, c.byref(eq)))
+        return bool(eq.value)
+
+    __hash__ = None
 
 
 class CoeffMultilinearPolynomial:

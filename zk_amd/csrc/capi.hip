@@ -41,7 +41,10 @@ struct zk_ctx {
     std::map<std::pair<uint32_t, int>, uint64_t *> twiddles;   // (log_n, inverse) -> omega^i table, i < n/2 (n < 2^8 path)
     std::map<std::pair<uint32_t, int>, NttPlan> ntt_plans;     // (log_n, inverse) -> pass plan + two-level twiddle tables
     std::map<size_t, std::vector<void *>> pool;                // freed device blocks by exact size (stream-ordered reuse)
-    size_t pool_bytes;
+    size_t pool_bytes, pool_checked;
+    uint8_t *h_absorb[2];   // pinned staging of absorb_tables (prove / verify), kept across calls
+    size_t h_absorb_bytes;
+    hipEvent_t ev_absorb[2];
 };
 struct zk_mle {
     zk_ctx *ctx;
@@ -87,6 +90,12 @@ static inline int32_t use_device(const zk_ctx *ctx) {
 // rate is high): hipMalloc/hipFree of a 256 MiB block costs milliseconds and synchronises the device, which is more
 // than a whole 2^24 fold.  All use is ordered on the context's stream, so a recycled block is safe to hand out again
 // without a synchronisation.
+static void pool_trim(zk_ctx *c) {   // hipFree synchronises the device, so blocks still in use by queued work are safe
+    for (auto &kv : c->pool)
+        for (void *q : kv.second) (void)hipFree(q);
+    c->pool.clear();
+    c->pool_bytes = 0;
+}
 static int32_t pool_alloc(zk_ctx *c, size_t bytes, void **out) {
     if (bytes == 0) bytes = 32;
     auto it = c->pool.find(bytes);
@@ -98,10 +107,8 @@ static int32_t pool_alloc(zk_ctx *c, size_t bytes, void **out) {
     }
     hipError_t e = hipMalloc(out, bytes);
     if (e != hipSuccess) {   // out of memory: drop the cache and retry once
-        for (auto &kv : c->pool)
-            for (void *q : kv.second) (void)hipFree(q);
-        c->pool.clear();
-        c->pool_bytes = 0;
+        (void)hipGetLastError();
+        pool_trim(c);
         e = hipMalloc(out, bytes);
     }
     if (e != hipSuccess) {
@@ -115,6 +122,31 @@ static void pool_free(zk_ctx *c, void *ptr, size_t bytes) {
     if (bytes == 0) bytes = 32;
     c->pool[bytes].push_back(ptr);
     c->pool_bytes += bytes;
+    // cap: idle blocks never hold more than half of what the device has left (other contexts, other libraries and this
+    // library's few raw hipMallocs must not fail while gigabytes sit here).  Checked only past 1 GiB: hipMemGetInfo is slow.
+    if (c->pool_bytes > ((size_t)1 << 30) && c->pool_bytes - c->pool_checked > ((size_t)1 << 30)) {
+        size_t fr = 0, tot = 0;
+        c->pool_checked = c->pool_bytes;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && c->pool_bytes > fr / 2) {
+            pool_trim(c);
+            c->pool_checked = 0;
+        }
+    }
+}
+// scratch that does not fit the pool's power-of-two habits still goes through it, so an allocation failure drops the cache
+// and retries instead of failing while the pool sits on idle gigabytes
+static int32_t raw_alloc(zk_ctx *c, size_t bytes, void **out) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        pool_trim(c);
+        e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess) {
+        g_hip_err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return ZK_ERR_ALLOC;
+    }
+    return ZK_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -144,6 +176,7 @@ extern "C" const char *zk_strerror(int32_t s) {
         case ZK_ERR_UNSUPPORTED: return "unsupported configuration";
         case ZK_ERR_CONTEXT_MISMATCH: return "handle belongs to a different context";
         case ZK_ERR_GKR_REJECT: return "gkr verifier check failed: layer wiring / input claim mismatch";
+        case ZK_ERR_COMM: return "collective failed (see zk_last_hip_error)";
         default: return "unknown status";
     }
 }
@@ -232,7 +265,10 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     c->d_partials = c->d_sums = c->h_pinned = nullptr;
     c->h_results = nullptr;
     c->h_results_bytes = 0;
-    c->pool_bytes = 0;
+    c->pool_bytes = c->pool_checked = 0;
+    c->h_absorb[0] = c->h_absorb[1] = nullptr;
+    c->h_absorb_bytes = 0;
+    c->ev_absorb[0] = c->ev_absorb[1] = nullptr;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -261,6 +297,10 @@ extern "C" int32_t zk_ctx_destroy(zk_ctx *c) {
     (void)hipFree(c->d_sums);
     (void)hipHostFree(c->h_pinned);
     if (c->h_results) (void)hipHostFree(c->h_results);
+    for (int b = 0; b < 2; ++b) {
+        if (c->h_absorb[b]) (void)hipHostFree(c->h_absorb[b]);
+        if (c->ev_absorb[b]) (void)hipEventDestroy(c->ev_absorb[b]);
+    }
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->own_stream);
@@ -285,6 +325,14 @@ extern "C" int32_t zk_ctx_use_own_stream(zk_ctx *c) {
     ZKCHK(use_device(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->stream = c->own_stream;
+    return ZK_OK;
+}
+extern "C" int32_t zk_ctx_trim(zk_ctx *c) {
+    if (!c) return ZK_ERR_BAD_ARG;
+    ZKCHK(use_device(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    pool_trim(c);
+    c->pool_checked = 0;
     return ZK_OK;
 }
 extern "C" int32_t zk_ctx_field(const zk_ctx *c, int32_t *out) {
@@ -373,6 +421,30 @@ extern "C" int32_t zk_mle_download(zk_ctx *c, const zk_mle *t, uint64_t *out) {
     ZKCHK(use_device(c));
     HIPCHK(hipMemcpyAsync(out, t->d, (size_t)32 << t->n_vars, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+// #[derive(PartialEq)] (evaluation_form.rs:4): same n_vars and the same evaluations.  Elements are canonical (< p), so
+// equality of representatives is equality in F_p.
+extern "C" int32_t zk_mle_equal(zk_ctx *c, const zk_mle *a, const zk_mle *b, int32_t *out) {
+    if (!c || !a || !b || !out) return ZK_ERR_BAD_ARG;
+    if (a->ctx != c || b->ctx != c) return ZK_ERR_CONTEXT_MISMATCH;
+    if (a->n_vars != b->n_vars) {
+        *out = 0;
+        return ZK_OK;
+    }
+    if (a->d == b->d) {
+        *out = 1;
+        return ZK_OK;
+    }
+    ZKCHK(use_device(c));
+    uint32_t *d_flag = reinterpret_cast<uint32_t *>(c->d_sums);
+    HIPCHK(hipMemsetAsync(d_flag, 0, 4, c->stream));
+    const uint64_t n16 = (uint64_t)2 << a->n_vars;
+    k_compare<<<grid_for(n16), kBlock, 0, c->stream>>>(reinterpret_cast<const uint4 *>(a->d), reinterpret_cast<const uint4 *>(b->d), n16, d_flag);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_pinned, d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = *reinterpret_cast<uint32_t *>(c->h_pinned) == 0 ? 1 : 0;
     return ZK_OK;
 }
 extern "C" int32_t zk_mle_device_ptr(const zk_mle *t, void **out) {
@@ -518,7 +590,7 @@ extern "C" int32_t zk_mle_to_bytes(zk_ctx *c, const zk_mle *t, uint8_t *out) {
     const uint64_t n = 1ull << t->n_vars;
     const uint64_t chunk = n < (1ull << 21) ? n : (1ull << 21);   // 64 MiB of bytes per chunk
     uint8_t *d_bytes = nullptr;
-    HIPCHK(hipMalloc(&d_bytes, (size_t)chunk * 32));
+    ZKCHK(raw_alloc(c, (size_t)chunk * 32, (void **)&d_bytes));
     int32_t rc = ZK_OK;
     for (uint64_t off = 0; off < n && rc == ZK_OK; off += chunk) {
         k_to_bytes<<<grid_for(chunk), kBlock, 0, c->stream>>>(t->d + 4 * off, d_bytes, chunk, c->fi->P);
@@ -840,6 +912,12 @@ extern "C" int32_t zk_transcript_sample_field_element(zk_transcript *t, int32_t 
     fe_to_u64limbs(fe_from_be_bytes_mod_order(h, 32, fi->P), out);       // :29
     return ZK_OK;
 }
+extern "C" int32_t zk_transcript_sample_n_field_elements(zk_transcript *t, int32_t field, uint64_t n, uint64_t *out) {
+    if (!t || (!out && n)) return ZK_ERR_BAD_ARG;
+    if (!field_info(field)) return ZK_ERR_BAD_FIELD;
+    for (uint64_t i = 0; i < n; ++i) ZKCHK(zk_transcript_sample_field_element(t, field, out + 4 * i));   // transcript/src/lib.rs:32-34
+    return ZK_OK;
+}
 extern "C" int32_t zk_keccak256(const uint8_t *data, size_t len, uint8_t out[32]) {
     if ((!data && len) || !out) return ZK_ERR_BAD_ARG;
     Sponge s;
@@ -861,28 +939,47 @@ static Fe squeeze_field_element(Sponge &sp, const FieldParams &P) {   // transcr
     sp.sample_challenge(h);
     return fe_from_be_bytes_mod_order(h, 32, P);
 }
-// absorb poly.to_bytes() (product_poly.rs:77-83) -- device serialiser, chunked D2H, host sponge
+// absorb poly.to_bytes() (product_poly.rs:77-83) -- device serialiser, chunked D2H, host sponge.  The Keccak sponge is
+// serial by construction and runs on the host (one GPU wave permutes 136 bytes in ~3 us = 45 MB/s; a host core does
+// several hundred MB/s), so it bounds `prove`; the serialiser kernel and the copy of chunk i+1 run while the host absorbs
+// chunk i (two device + two pinned buffers, one event each; the pinned buffers stay with the context).
 static int32_t absorb_tables(zk_ctx *c, Sponge &sp, zk_mle *const *f, uint64_t k) {
     const uint64_t n = 1ull << f[0]->n_vars;
-    const uint64_t chunk = n < (1ull << 21) ? n : (1ull << 21);
-    uint8_t *d_bytes = nullptr, *h_bytes = nullptr;
-    HIPCHK(hipMalloc(&d_bytes, (size_t)chunk * 32));
-    if (hipHostMalloc(&h_bytes, (size_t)chunk * 32, hipHostMallocDefault) != hipSuccess) {
-        (void)hipFree(d_bytes);
-        return ZK_ERR_ALLOC;
-    }
-    int32_t rc = ZK_OK;
-    for (uint64_t i = 0; i < k && rc == ZK_OK; ++i)
-        for (uint64_t off = 0; off < n && rc == ZK_OK; off += chunk) {
-            k_to_bytes<<<grid_for(chunk), kBlock, 0, c->stream>>>(f[i]->d + 4 * off, d_bytes, chunk, c->fi->P);
-            if (hipMemcpyAsync(h_bytes, d_bytes, (size_t)chunk * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                hipStreamSynchronize(c->stream) != hipSuccess)
-                rc = ZK_ERR_HIP;
-            else
-                sp.update(h_bytes, (size_t)chunk * 32);
+    const uint64_t chunk = n < (1ull << 19) ? n : (1ull << 19);   // 16 MiB of bytes per chunk
+    const size_t cb = (size_t)chunk * 32;
+    const uint64_t per_table = n / chunk, total = per_table * k;
+    if (c->h_absorb_bytes < cb) {
+        for (int b = 0; b < 2; ++b) {
+            if (c->h_absorb[b]) (void)hipHostFree(c->h_absorb[b]);
+            c->h_absorb[b] = nullptr;
         }
-    (void)hipFree(d_bytes);
-    (void)hipHostFree(h_bytes);
+        c->h_absorb_bytes = 0;
+        for (int b = 0; b < 2; ++b) HIPCHK(hipHostMalloc((void **)&c->h_absorb[b], cb, hipHostMallocDefault));
+        c->h_absorb_bytes = cb;
+    }
+    if (!c->ev_absorb[0])
+        for (int b = 0; b < 2; ++b) HIPCHK(hipEventCreateWithFlags(&c->ev_absorb[b], hipEventDisableTiming));
+    uint8_t *d_bytes[2] = {nullptr, nullptr};
+    ZKCHK(pool_alloc(c, cb, (void **)&d_bytes[0]));
+    int32_t rc = pool_alloc(c, cb, (void **)&d_bytes[1]);
+    auto enqueue = [&](uint64_t i) -> int32_t {
+        const int b = (int)(i & 1);
+        const uint64_t *src = f[i / per_table]->d + 4 * (i % per_table) * chunk;
+        k_to_bytes<<<grid_for(chunk), kBlock, 0, c->stream>>>(src, d_bytes[b], chunk, c->fi->P);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(c->h_absorb[b], d_bytes[b], cb, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipEventRecord(c->ev_absorb[b], c->stream) != hipSuccess)
+            return ZK_ERR_HIP;
+        return ZK_OK;
+    };
+    if (rc == ZK_OK) rc = enqueue(0);
+    for (uint64_t i = 0; i < total && rc == ZK_OK; ++i) {
+        if (i + 1 < total) rc = enqueue(i + 1);   // its buffers were released when chunk i-1 was absorbed
+        if (rc == ZK_OK && hipEventSynchronize(c->ev_absorb[i & 1]) != hipSuccess) rc = ZK_ERR_HIP;
+        if (rc == ZK_OK) sp.update(c->h_absorb[i & 1], cb);
+    }
+    if (rc != ZK_OK) (void)hipStreamSynchronize(c->stream);
+    pool_free(c, d_bytes[0], cb);
+    if (d_bytes[1]) pool_free(c, d_bytes[1], cb);
     return rc;
 }
 
@@ -1071,6 +1168,12 @@ static int32_t sponge_to_device(zk_ctx *c, const Sponge &host, WordSponge *d_spo
     return ZK_OK;
 }
 
+static bool has_duplicate_handles(zk_mle *const *f, uint64_t k) {
+    for (uint64_t i = 0; i < k; ++i)
+        for (uint64_t j = i + 1; j < k; ++j)
+            if (f[i] == f[j]) return true;
+    return false;
+}
 // The prover for sum_i prod_{f in term i} T_f (one term = the reference's ProductPoly).  out_final (optional): the k
 // factors evaluated at the challenge point.
 // d_keep_ch / d_keep_final (optional, DEVICE buffers of n / k elements): device-resident copies of the challenges and of the
@@ -1093,6 +1196,9 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
             for (uint64_t i = 0; i < k; ++i) ZKCHK(zk_mle_download(c, f[i], out_final + 4 * i));
         return ZK_OK;
     }
+    // the reference takes the polynomial by value and clones per fold, so a table may appear twice (A * A): in-place folds
+    // would then fold the shared buffer once per listing -- such a product is proved out of place (own scratch per factor)
+    if (has_duplicate_handles(f, k)) consume = 0;
     RoundState st;
     ZKCHK(round_state_init(st, c, f, k, D, consume != 0, n));
     st.terms = ts;
@@ -1197,6 +1303,8 @@ struct zk_shard_prover {
     size_t tail_bytes;
     uint32_t tail_s;      // variables left in the local tables when gathered
     bool tail_done;
+    uint64_t *d_gathered; // zk_shard_prover_run: the all-gathered tails [world][k][2^tail_s]
+    size_t gathered_bytes;
 };
 extern "C" int32_t zk_shard_prover_create(zk_ctx *c, zk_mle *const *f, uint64_t k, uint32_t D, const uint64_t sum[4],
                                           uint32_t world, zk_shard_prover **out) {
@@ -1215,7 +1323,10 @@ extern "C" int32_t zk_shard_prover_create(zk_ctx *c, zk_mle *const *f, uint64_t 
     sp->tail_bytes = 0;
     sp->tail_s = 0;
     sp->tail_done = false;
-    int32_t rc = round_state_init(sp->st, c, f, k, D, /*consume=*/true, sp->total_rounds);
+    sp->d_gathered = nullptr;
+    sp->gathered_bytes = 0;
+    // the shard tables are consumed (folded in place) unless one is listed twice (see prove_core)
+    int32_t rc = round_state_init(sp->st, c, f, k, D, /*consume=*/!has_duplicate_handles(f, k), sp->total_rounds);
     if (rc == ZK_OK) rc = pool_alloc(c, (size_t)kMaxSums * 8 * sizeof(uint64_t), (void **)&sp->d_lanes);
     if (rc == ZK_OK) {
         Sponge host;
@@ -1237,6 +1348,7 @@ extern "C" int32_t zk_shard_prover_destroy(zk_shard_prover *sp) {
     round_state_release(sp->st);
     pool_free(c, sp->d_lanes, (size_t)kMaxSums * 8 * sizeof(uint64_t));
     pool_free(c, sp->d_tail, sp->tail_bytes);
+    pool_free(c, sp->d_gathered, sp->gathered_bytes);
     delete sp;
     return ZK_OK;
 }
@@ -1466,10 +1578,10 @@ extern "C" int32_t zk_sumcheck_verify(zk_ctx *c, const zk_mle *const *f, uint64_
 // ------------------------------------------------------------------------------------------------------------
 // fft crate
 // ------------------------------------------------------------------------------------------------------------
-static int32_t make_twiddles(zk_ctx *c, uint32_t log_n, const Fe &omega, uint64_t **out) {
-    const uint64_t count = log_n ? (1ull << (log_n - 1)) : 1;
+static int32_t make_twiddles(zk_ctx *c, uint32_t log_n, const Fe &omega, uint64_t **out, bool full = false) {
+    const uint64_t count = full ? (1ull << log_n) : (log_n ? (1ull << (log_n - 1)) : 1);
     uint64_t *tw = nullptr;
-    HIPCHK(hipMalloc(&tw, (size_t)count * 32));
+    ZKCHK(raw_alloc(c, (size_t)count * 32, (void **)&tw));
     k_twiddle_table<<<grid_for((count + 63) / 64), kBlock, 0, c->stream>>>(tw, count, omega, c->fi->P);
     if (hipGetLastError() != hipSuccess) {
         (void)hipFree(tw);
@@ -1504,8 +1616,8 @@ static int32_t ntt_build_tables(zk_ctx *c, NttPlan &pl, const Fe &omega) {
     const uint32_t hi_bits = pl.log_n - pl.lo_bits;
     uint32_t *lo = nullptr;
     uint64_t *hi = nullptr;
-    HIPCHK(hipMalloc(&lo, ((size_t)kTw29Words * 4) << pl.lo_bits));
-    if (hipMalloc(&hi, (size_t)32 << hi_bits) != hipSuccess) {
+    ZKCHK(raw_alloc(c, ((size_t)kTw29Words * 4) << pl.lo_bits, (void **)&lo));
+    if (raw_alloc(c, (size_t)32 << hi_bits, (void **)&hi) != ZK_OK) {
         (void)hipFree(lo);
         return ZK_ERR_ALLOC;
     }
@@ -1523,7 +1635,7 @@ static int32_t ntt_build_tables(zk_ctx *c, NttPlan &pl, const Fe &omega) {
         const uint32_t log_entries = pl.log_n - lo_sum;   // R_p * I_p = n / O_p
         if (log_entries <= 24) {
             uint64_t *t = nullptr;
-            if (hipMalloc(&t, (size_t)32 << log_entries) == hipSuccess) {
+            if (raw_alloc(c, (size_t)32 << log_entries, (void **)&t) == ZK_OK) {
                 k_ntt_full_table<<<grid_for(1ull << log_entries), kBlock, 0, c->stream>>>(t, pl, log_entries - pl.l[p], pl.l[p], lo_sum, c->fi->P);
                 if (hipGetLastError() == hipSuccess) pl.w_full[p] = t;
                 else (void)hipFree(t);
@@ -1646,7 +1758,25 @@ static int32_t fft_host_common(zk_ctx *c, const uint64_t *in, uint64_t n, uint64
     ZKCHK(zk_mle_upload(c, log_n, in, n, &a));
     int32_t rc = mle_alloc(c, log_n, &b);
     if (rc == ZK_OK) {
-        if (mode == 2 && log_n >= 8) {
+        // every other path uses the (u + t, u - t) butterfly, i.e. assumes omega^(n/2) = -1; fft_internal's caller may pass
+        // any omega (fft/src/lib.rs:21), for which the reference's literal omega^(i + n/2) differs: full-table stages
+        bool primitive = true;
+        if (mode == 2 && log_n >= 1) {
+            const FieldParams &P = c->fi->P;
+            primitive = fe_eq(fe_pow_u64(fe_from_u64limbs(omega_user), n / 2, P), fe_sub(fe_zero(), fe_one(P), P));
+        }
+        if (mode == 2 && !primitive) {
+            uint64_t *tw = nullptr;
+            rc = make_twiddles(c, log_n, fe_from_u64limbs(omega_user), &tw, /*full=*/true);
+            if (rc == ZK_OK) {
+                k_bitrev_copy<<<grid_for(n), kBlock, 0, c->stream>>>(a->d, b->d, log_n);
+                for (uint32_t s = 0; s < log_n; ++s)
+                    k_ntt_stage_generic<<<grid_for(n / 2), kBlock, 0, c->stream>>>(b->d, tw, log_n, s, c->fi->P);
+                if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+            }
+            if (hipStreamSynchronize(c->stream) != hipSuccess && rc == ZK_OK) rc = ZK_ERR_HIP;
+            if (tw) (void)hipFree(tw);
+        } else if (mode == 2 && log_n >= 8) {
             NttPlan pl;
             ntt_make_plan(log_n, pl);
             rc = ntt_build_tables(c, pl, fe_from_u64limbs(omega_user));
@@ -1747,4 +1877,5 @@ extern "C" int32_t zk_bench_copy(zk_ctx *c, uint64_t bytes, int32_t reps, double
     return ZK_OK;
 }
 
+#include "comm_host.inc"
 #include "gkr_host.inc"

@@ -918,6 +918,21 @@ __global__ __launch_bounds__(kBlock) void k_ntt_stage(uint64_t *__restrict__ dat
         fe_store(data, base + j + h, fe_sub(u, t, P));
     }
 }
+// fft_internal with an omega that is NOT a primitive n-th root (fft/src/lib.rs:39-43 computes even[i] + omega^i * odd[i] and
+// even[i] + omega^(i + m/2) * odd[i] literally; omega^(m/2) = -1 only for primitive roots): both twiddles are read from a
+// full table tw[i] = omega^i, i < n.  Stage s has sub-transforms of size m = 2h, h = 2^s, whose omega is omega^(n/m).
+__global__ __launch_bounds__(kBlock) void k_ntt_stage_generic(uint64_t *__restrict__ data, const uint64_t *__restrict__ tw,
+                                                              uint32_t log_n, uint32_t s, FieldParams P) {
+    const uint64_t half = 1ull << (log_n - 1), stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t h = 1ull << s;
+    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < half; b += stride) {
+        const uint64_t j = b & (h - 1), base = (b >> s) << (s + 1);
+        const Fe w0 = fe_load(tw, j << (log_n - 1 - s)), w1 = fe_load(tw, (j + h) << (log_n - 1 - s));
+        const Fe u = fe_load(data, base + j), o = fe_load(data, base + j + h);
+        fe_store(data, base + j, fe_add(u, fe_mul(w0, o, P), P));
+        fe_store(data, base + j + h, fe_add(u, fe_mul(w1, o, P), P));
+    }
+}
 // tw[i] = omega^i for i < count: chunked -- each thread starts from omega^(first) via square-and-multiply
 __global__ __launch_bounds__(kBlock) void k_twiddle_table(uint64_t *__restrict__ tw, uint64_t count, Fe omega,
                                                           FieldParams P) {
@@ -943,6 +958,18 @@ __global__ __launch_bounds__(kBlock) void k_scale(uint64_t *__restrict__ data, u
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride)
         fe_store(data, j, fe_mul(fe_load(data, j), s, P));
+}
+
+// ---- PartialEq on tables: any differing 16-byte word raises the flag ------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_compare(const uint4 *__restrict__ a, const uint4 *__restrict__ b, uint64_t n16,
+                                                    uint32_t *__restrict__ flag) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    bool diff = false;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n16; j += stride) {
+        const uint4 x = a[j], y = b[j];
+        diff |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+    }
+    if (diff) atomicOr(flag, 1u);
 }
 
 // ---- measurement kernels -----------------------------------------------------------------------------------------

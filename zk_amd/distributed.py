@@ -15,12 +15,17 @@ RCCL has no mod-p reduction).  After n-w rounds every rank holds one element per
 elements gives the w-variable remainder (indexed by rank = the low index bits, i.e. in the reference's own order)
 and every rank finishes the last w rounds redundantly -- W elements, no further collective.
 
-`ShardedSumcheckProver` is the orchestration (host logic, backend-agnostic: tests drive it over gloo on CPU with a
-checker backend); `GpuShardBackend` is the product backend over the C ABI (zk_shard_prover_*).
+Two drivers of the same protocol:
+  * `GpuShardBackend.run(comm, gather_below)` -- the product path: the WHOLE loop inside the library
+    (zk_shard_prover_run), collectives issued by the library itself on the context's stream (`RcclComm`: RCCL over xGMI, no
+    host synchronisation between rounds; `HostComm`: the same control flow with the transport called back into the host,
+    used by the multi-process tests that put several ranks on one GPU, where RCCL cannot run).
+  * `ShardedSumcheckProver` -- the stepwise orchestration in Python over torch.distributed (backend-agnostic: tests drive
+    it over gloo on CPU with a checker backend, and over gloo with `GpuShardBackend`, staging the lanes through the host).
 """
 import numpy as np
 
-from ._lib import c, check, lib, u64p
+from ._lib import HOST_ALLGATHER, HOST_ALLREDUCE, HOST_ALLTOALL, c, check, lib, u64p
 
 
 def shard_of(table, rank, world):
@@ -45,8 +50,104 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (n_int64,), "typestr": "<i8", "data": (ptr, False), "version": 2}
 
 
+class RcclComm:
+    """zk_comm over RCCL (xGMI): one per rank.  The 128-byte unique id is created on rank 0 and broadcast through the
+    already-initialised torch.distributed group (any backend) -- a Rust host would use whatever channel it has."""
+
+    def __init__(self, ctx, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.ctx = ctx
+        if dist.is_available() and dist.is_initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        buf = c.create_string_buffer(128)
+        if self.rank == 0:
+            check(lib.zk_comm_unique_id(buf))
+        if self.world > 1:
+            obj = [buf.raw]
+            dist.broadcast_object_list(obj, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            buf = c.create_string_buffer(obj[0], 128)
+        h = c.c_void_p()
+        check(lib.zk_comm_create_rccl(ctx._h, buf, self.world, self.rank, c.byref(h)))
+        self._h = h
+        del torch
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.zk_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class HostComm:
+    """zk_comm whose transport is called back into this process: the library stages each buffer through pinned memory and
+    the callbacks run the collective over a torch.distributed group on CPU tensors (gloo).  Same control flow as RcclComm;
+    exists so that several ranks can share ONE GPU in the multi-process tests (RCCL refuses two ranks on a device)."""
+
+    def __init__(self, ctx, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.ctx, self.group = ctx, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        world = self.world
+
+        def _view(ptr, n):
+            return torch.from_numpy(np.ctypeslib.as_array(ptr, shape=(n,)).view(np.int64))
+
+        def allreduce(_user, buf, n):
+            try:
+                dist.all_reduce(_view(buf, n), op=dist.ReduceOp.SUM, group=group)
+                return 0
+            except Exception:   # never let an exception cross the C boundary
+                return 1
+
+        def allgather(_user, send, n, recv):
+            try:
+                dist.all_gather(list(_view(recv, n * world).chunk(world)), _view(send, n), group=group)
+                return 0
+            except Exception:
+                return 1
+
+        def alltoall(_user, send, recv, n):
+            try:
+                dist.all_to_all_single(_view(recv, n * world), _view(send, n * world), group=group)
+                return 0
+            except Exception:
+                return 1
+
+        self._cbs = (HOST_ALLREDUCE(allreduce), HOST_ALLGATHER(allgather), HOST_ALLTOALL(alltoall))   # keep alive
+        h = c.c_void_p()
+        check(lib.zk_comm_create_host(ctx._h, self.world, self.rank, c.cast(self._cbs[0], c.c_void_p), c.cast(self._cbs[1], c.c_void_p),
+                                      c.cast(self._cbs[2], c.c_void_p), None, c.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.zk_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def ntt_sharded(comm, shard, inverse=False):
+    """fft / ifft of the vector held as index-mod-world shards, inside the library (zk_ntt_sharded): returns a new table."""
+    from .api import MultiLinearPolynomial
+
+    out = MultiLinearPolynomial.alloc(shard.ctx, shard.n_vars())
+    check(lib.zk_ntt_sharded(shard.ctx._h, comm._h, shard._h, int(inverse), out._h))
+    return out
+
+
 class GpuShardBackend:
-    """One rank's share of the prover on its GPU (zk_shard_prover_* in include/zk_amd.h)."""
+    """One rank's share of the prover on its GPU (zk_shard_prover_* in include/zk_amd.h).  The factor tables of `poly` are
+    CONSUMED (folded in place; only a product that lists one table twice is proved out of place)."""
 
     def __init__(self, poly, max_var_degree, claimed_sum, world):
         import torch
@@ -75,6 +176,11 @@ class GpuShardBackend:
 
     def __del__(self):
         self.close()
+
+    def run(self, comm, gather_below=10):
+        """the whole prover inside the library (zk_shard_prover_run): per-round all-reduce, tail all-gather, tail rounds"""
+        check(lib.zk_shard_prover_run(self._h, comm._h, gather_below))
+        return self.results()
 
     def local_vars_left(self):
         """variables of the local shard tables that no completed round has consumed yet"""
@@ -125,18 +231,25 @@ class ShardedSumcheckProver:
 
         b = self.backend
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        # a CPU-only group (gloo) under device tensors: stage the lanes / tail through the host
+        stage = multi and dist.get_backend(self.group) == "gloo"
         while b.local_vars_left() > self.gather_below:
             lanes = b.round_begin()
-            if multi:
+            if multi and stage and lanes.is_cuda:
+                h = lanes.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                lanes.copy_(h)
+            elif multi:
                 dist.all_reduce(lanes, op=dist.ReduceOp.SUM, group=self.group)   # the round's one collective
             b.round_finish()
         tail = b.tail()
         if multi:
             import torch
 
-            parts = [torch.empty_like(tail) for _ in range(dist.get_world_size(self.group))]
-            dist.all_gather(parts, tail, group=self.group)                       # once, W*k elements, rank-major
-            gathered = torch.cat(parts)
+            src = tail.cpu() if (stage and tail.is_cuda) else tail
+            parts = [torch.empty_like(src) for _ in range(dist.get_world_size(self.group))]
+            dist.all_gather(parts, src, group=self.group)                        # once, W*k elements, rank-major
+            gathered = torch.cat(parts).to(tail.device)
         else:
             gathered = tail
         b.tail_rounds(gathered)
@@ -172,6 +285,14 @@ class ShardedNtt:
         b = self.backend
         send, recv = b.send_tensor(), b.recv_tensor()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            if dist.get_backend(self.group) == "gloo" and send.is_cuda:   # CPU-only group under device tensors
+                import torch
+
+                hs = send.cpu()
+                hr = torch.empty_like(hs)
+                dist.all_to_all_single(hr, hs, group=self.group)
+                recv.copy_(hr)
+                return
             dist.all_to_all_single(recv, send, group=self.group)   # the transform's one collective: M/W elements per pair
         else:
             recv.copy_(send)
