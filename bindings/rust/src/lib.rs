@@ -201,9 +201,7 @@ impl<F: GpuField> MultiLinearPolynomial<F> {
         let mut h: *mut zk_mle = std::ptr::null_mut();
         let rc = unsafe { zk_mle_upload(c.raw, n_vars as u64, limbs(&evaluations), evaluations.len() as u64, &mut h) };
         if rc != 0 { return Err(err(rc)); } // "evaluation vec len should equal 2^n_vars"
-        let t = Self { ctx: c, h, n_vars, host: OnceCell::new() };
-        let _ = t.host.set(evaluations); // the caller's Vec IS the host mirror: evaluation_slice never downloads it
-        Ok(t)
+        Ok(Self { ctx: c, h, n_vars, host: OnceCell::from(evaluations) }) // the caller's Vec IS the host mirror
     }
     /// evaluation_form.rs:30
     pub fn n_vars(&self) -> usize { self.n_vars }
