@@ -311,6 +311,17 @@ def sumcheck_prove(field, n_vars, tables, D, claimed_sum, absorb_table):
     return rp, ch
 
 
+def sumcheck_prove_fused_parallel(field, n_vars, tables, D, claimed_sum, threads=0):
+    """bench 'optimised CPU' row: prove_partial outputs via fused rounds + OpenMP -> (round_polys, challenges, threads)"""
+    tabs, ptrs = _table_ptrs(tables, n_vars)
+    s = _arr(claimed_sum, 1)
+    rp = np.zeros((n_vars, D + 1, 4), dtype=np.uint64)
+    ch = np.zeros((n_vars, 4), dtype=np.uint64)
+    used = _check(_lib.orc_sumcheck_prove_fused_parallel(field, _c.c_uint64(len(tabs)), _c.c_uint64(n_vars), ptrs, _c.c_uint(D),
+                                                         _p(s), _p(rp), _p(ch), int(threads)))
+    return rp, ch, used
+
+
 def sumcheck_verify_partial(field, D, claimed_sum, round_polys, table_bytes=None):
     rp = _arr(round_polys).reshape(-1, D + 1, 4)
     n = rp.shape[0]

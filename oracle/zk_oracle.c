@@ -600,6 +600,84 @@ int orc_sumcheck_prove(int field, u64 k, u64 n_vars, const u64 *const *tables, u
     return rc;
 }
 
+/* "optimised CPU" row of the bench -- NOT a restatement: the same round polynomials and challenges as
+ * orc_sumcheck_prove (prove_partial semantics) computed the way a tuned CPU prover would: per round ONE pass over the
+ * pairs that forms all D+1 products from (lo, hi) and a second parallel pass that folds in place; OpenMP over all cores.
+ * Field sums are exact, so per-thread partial sums added in any order give the reference's canonical result. */
+int orc_sumcheck_prove_fused_parallel(int field, u64 k, u64 n_vars, const u64 *const *tables, unsigned D, const u64 sum[4],
+                                      u64 *round_polys_out, u64 *challenges_out, int threads) {
+    const fparams *F = field_get(field);
+    if (!F) return ORC_ERR_BAD_FIELD;
+    if (k == 0 || k > 8 || D > 15) return ORC_ERR_EMPTY_PRODUCT;
+    int used = 1;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    used = omp_get_max_threads();
+#endif
+    (void)threads;
+    const u64 len = 1ULL << n_vars;
+    u64 *cur[8];
+    for (u64 f = 0; f < k; ++f) {
+        cur[f] = (u64 *)malloc(len * 32);
+        if (!cur[f]) return ORC_ERR_ALLOC;
+        memcpy(cur[f], tables[f], len * 32);
+    }
+    orc_transcript *tr = orc_transcript_new();
+    append_elems(tr, field, sum, 1);
+    u64 *part = (u64 *)calloc((size_t)used * 16 * 4, 8);
+    for (u64 round = 0; round < n_vars; ++round) {
+        const long half = (long)(1ULL << (n_vars - round - 1));
+        memset(part, 0, (size_t)used * 16 * 32);
+#pragma omp parallel
+        {
+            int tid = 0;
+#ifdef _OPENMP
+            tid = omp_get_thread_num();
+#endif
+            u64 *acc = part + (size_t)tid * 16 * 4;
+#pragma omp for schedule(static)
+            for (long j = 0; j < half; ++j) {
+                u64 prod[16][4], v[4], diff[4];
+                for (u64 f = 0; f < k; ++f) {
+                    const u64 *lo = cur[f] + 4 * j, *hi = cur[f] + 4 * (j + half);
+                    f_sub(F, hi, lo, diff);
+                    memcpy(v, lo, 32);
+                    for (unsigned t = 0; t <= D; ++t) {
+                        if (t == 1) memcpy(v, hi, 32);
+                        else if (t > 1) f_add(F, v, diff, v);
+                        if (f == 0) memcpy(prod[t], v, 32);
+                        else f_mul(F, prod[t], v, prod[t]);
+                    }
+                }
+                for (unsigned t = 0; t <= D; ++t) f_add(F, acc + 4 * t, prod[t], acc + 4 * t);
+            }
+        }
+        u64 *rp = round_polys_out + round * (D + 1) * 4;
+        for (unsigned t = 0; t <= D; ++t) {
+            u64 s[4] = {0, 0, 0, 0};
+            for (int w = 0; w < used; ++w) f_add(F, s, part + ((size_t)w * 16 + t) * 4, s);
+            memcpy(rp + 4 * t, s, 32);
+        }
+        append_elems(tr, field, rp, D + 1);
+        u64 *ch = challenges_out + 4 * round;
+        orc_transcript_sample_field_element(tr, field, ch);
+        for (u64 f = 0; f < k; ++f) {
+            u64 *T = cur[f];
+#pragma omp parallel for schedule(static)
+            for (long j = 0; j < half; ++j) {   /* in place: index j is written after j and j+half are read by the same thread */
+                u64 d[4], m[4];
+                f_sub(F, T + 4 * j, T + 4 * (j + half), d);
+                f_mul(F, ch, d, m);
+                f_sub(F, T + 4 * j, m, T + 4 * j);
+            }
+        }
+    }
+    for (u64 f = 0; f < k; ++f) free(cur[f]);
+    free(part);
+    orc_transcript_free(tr);
+    return used;
+}
+
 /* ------------------------------------------------------------------------------------------
  * polynomial/src/univariate_poly.rs (:29-80, :157-209) -- only what the verifier needs
  * ---------------------------------------------------------------------------------------- */

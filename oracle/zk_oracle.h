@@ -113,6 +113,11 @@ void orc_transcript_sample_field_element(orc_transcript *t, int field, uint64_t 
 int orc_sumcheck_prove(int field, uint64_t k, uint64_t n_vars, const uint64_t *const *tables,
                        unsigned max_var_degree, const uint64_t sum[4], int absorb_table,
                        uint64_t *round_polys_out, uint64_t *challenges_out);
+/* bench "optimised CPU" row (not a restatement): same outputs as orc_sumcheck_prove with absorb_table = 0, fused rounds,
+ * OpenMP.  Returns the number of threads used (> 0) or a negative error. */
+int orc_sumcheck_prove_fused_parallel(int field, uint64_t k, uint64_t n_vars, const uint64_t *const *tables,
+                                      unsigned max_var_degree, const uint64_t sum[4], uint64_t *round_polys_out,
+                                      uint64_t *challenges_out, int threads);
 /* verify_partial (verifier.rs:38-41 -> :44-78): returns ORC_OK and the subclaim, or the Err code. */
 int orc_sumcheck_verify_partial(int field, uint64_t n_rounds, unsigned max_var_degree,
                                 const uint64_t sum[4], const uint64_t *round_polys,

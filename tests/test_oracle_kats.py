@@ -213,3 +213,15 @@ def test_keccak256_public_vectors():
     for n in (1, 31, 32, 135, 136, 137, 271, 272, 273, 1000):
         msg = bytes((i * 7 + 3) & 0xFF for i in range(n))
         assert orc.keccak256(msg) == pyref.keccak256(msg)
+
+
+@pytest.mark.parametrize("field", [0, 1, 2])
+@pytest.mark.parametrize("n,k,D", [(1, 1, 1), (5, 1, 1), (8, 3, 3), (10, 2, 2), (9, 2, 4)])
+def test_bench_fused_parallel_prover_equals_the_restatement(field, n, k, D):
+    """bench.py's "optimised CPU" prover row (fused rounds, OpenMP) must produce the restatement's proof bit for bit"""
+    tabs = [orc.fill_random(field, 300 + i, 1 << n) for i in range(k)]
+    s = orc.fill_random(field, 5, 1)[0]
+    want_rp, want_ch = orc.sumcheck_prove(field, n, tabs, D, s, False)
+    for threads in (1, 3):
+        rp, ch, used = orc.sumcheck_prove_fused_parallel(field, n, tabs, D, s, threads)
+        assert used >= 1 and np.array_equal(rp, want_rp) and np.array_equal(ch, want_ch)

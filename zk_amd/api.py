@@ -234,6 +234,13 @@ class MultiLinearPolynomial:
         check(lib.zk_bench_fold(self.ctx._h, self._h, _p(r), out._h, reps, c.byref(ms)))
         return ms.value
 
+    def bench_fold_samples(self, r, out, reps):
+        """per-launch durations (ms) of `reps` folds, one HIP event per launch boundary"""
+        r = _elems(r, 1)
+        ms = np.zeros(reps, dtype=np.float64)
+        check(lib.zk_bench_fold_samples(self.ctx._h, self._h, _p(r), out._h, reps, ms.ctypes.data_as(c.POINTER(c.c_double))))
+        return ms
+
     # evaluate (evaluation_form.rs:83-89)
     def evaluate(self, assignments):
         a = _elems(assignments)

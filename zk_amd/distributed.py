@@ -149,11 +149,12 @@ class GpuShardBackend:
     """One rank's share of the prover on its GPU (zk_shard_prover_* in include/zk_amd.h).  The factor tables of `poly` are
     CONSUMED (folded in place; only a product that lists one table twice is proved out of place)."""
 
-    def __init__(self, poly, max_var_degree, claimed_sum, world):
+    def __init__(self, poly, max_var_degree, claimed_sum, world, torch_stream=True):
         import torch
 
         self.ctx, self.poly = poly.ctx, poly
-        self.ctx.use_torch_stream()   # kernels, lane all-reduce and tail all-gather are ordered on one stream
+        if torch_stream:   # stepwise driver: kernels and torch's collectives are ordered on torch's current stream;
+            self.ctx.use_torch_stream()   # run(comm) needs no torch stream (the library enqueues its own collectives)
         self.k, self.D, self.world = len(poly.polynomials), max_var_degree, world
         s = np.ascontiguousarray(claimed_sum, dtype=np.uint64).reshape(4)
         arr = (c.c_void_p * self.k)(*[q._h for q in poly.polynomials])
