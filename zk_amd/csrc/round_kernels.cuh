@@ -2,6 +2,7 @@
 // (rounds.hip): these are the heavy instantiations.
 #pragma once
 #include "common.cuh"
+#include "quad.cuh"
 
 namespace zk {
 
@@ -227,22 +228,6 @@ __global__ __launch_bounds__(kBlock, (K + EXTRA <= 2 ? 2 : 1)) void k_round_kd(F
 // lanes of a quad share pair index j: lane f folds factor f (2 multiplies), the quad transposes the (factor, point) values
 // with DPP quad_perm broadcasts, and lane t forms the product for evaluation point t (k - 1 multiplies).  Same arithmetic
 // per pair index, spread over 4x the lanes: the per-lane chain drops to ~1100-1400 instructions.  K + EXTRA <= 4, D <= 3.
-template <int SRC>
-ZK_D Fe quad_bcast(const Fe &x) {   // every lane of a quad reads lane SRC of the quad
-    Fe o;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o.v[i] = __builtin_amdgcn_mov_dpp(x.v[i], SRC | (SRC << 2) | (SRC << 4) | (SRC << 6), 0xF, 0xF, true);
-    return o;
-}
-template <int G, int NF, int NS>
-ZK_D void quad_transpose(const Fe (&v)[NS], Fe (&w)[NF], uint32_t l4) {   // w[g] of lane t <- v[t] of lane g
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-        const Fe b = quad_bcast<G>(v[t]);
-        if (l4 == (uint32_t)t) w[G] = b;
-    }
-    if constexpr (G + 1 < NF) quad_transpose<G + 1, NF, NS>(v, w, l4);
-}
 template <int K, int D, int EXTRA>
 __global__ __launch_bounds__(kBlock) void k_round_quad(FactorPtrs fp, uint64_t q, FieldParams P, const uint64_t *__restrict__ rptr,
                                                        uint64_t *__restrict__ partials) {
