@@ -28,11 +28,48 @@ def _fold(field, table, r):
     return [(table[j] - r * (table[j] - table[j + h])) % p for j in range(h)]
 
 
-def prove_partial_terms(field, terms, D, claimed_sum):
-    """prove_partial (prover.rs:24-30, :33-73) on sum_i prod_{f in terms[i]} table_f.  terms: list of lists of tables
-    (lists of ints).  Returns (round_polys, challenges, finals) with finals = every factor at the challenge point."""
+def fork(tr):
+    """an independent continuation of a transcript (same absorbed history)"""
+    t = pyref.Transcript()
+    t.buf = bytearray(tr.buf)
+    return t
+
+
+def tree_digest(data: bytes) -> bytes:
+    """Keccak-256 tree hash the driver binds its statement with (a single sponge over 2^20 elements would be serial and
+    cost more than the whole proof): 128-byte leaves (the last may be shorter; no data = one empty leaf), then 4-ary nodes
+    Keccak256(child digests concatenated) until one digest is left."""
+    leaves = [data[i:i + 128] for i in range(0, len(data), 128)] or [b""]
+    nodes = [pyref.keccak256(leaf) for leaf in leaves]
+    while len(nodes) > 1:
+        nodes = [pyref.keccak256(b"".join(nodes[i:i + 4])) for i in range(0, len(nodes), 4)]
+    return nodes[0]
+
+
+def table_digest(field, table) -> bytes:
+    """tree_digest of MultiLinearPolynomial::to_bytes (evaluation_form.rs:97-103): 32-byte big-endian canonical elements"""
     p = pyref.modulus(field)
-    tr = pyref.Transcript()
+    return tree_digest(b"".join((v % p).to_bytes(32, "big") for v in table))
+
+
+def circuit_digest(layers) -> bytes:
+    """Keccak256 over the layers of [log_out u64le | log_in u64le | tree(op bytes) | tree(left u32le) | tree(right u32le)]"""
+    h = b""
+    for log_out, log_in, op, left, right in layers:
+        h += int(log_out).to_bytes(8, "little") + int(log_in).to_bytes(8, "little")
+        h += tree_digest(bytes(int(o) for o in op))
+        h += tree_digest(b"".join(int(x).to_bytes(4, "little") for x in left))
+        h += tree_digest(b"".join(int(x).to_bytes(4, "little") for x in right))
+    return pyref.keccak256(h)
+
+
+def prove_partial_terms(field, terms, D, claimed_sum, tr=None):
+    """prove_partial (prover.rs:24-30, :33-73) on sum_i prod_{f in terms[i]} table_f.  terms: list of lists of tables
+    (lists of ints).  Returns (round_polys, challenges, finals) with finals = every factor at the challenge point.
+    tr: transcript to continue (the GKR driver chains its sumchecks onto its own transcript); None = a fresh one, which is
+    exactly the reference's prove_partial."""
+    p = pyref.modulus(field)
+    tr = pyref.Transcript() if tr is None else tr
     tr.append((claimed_sum % p).to_bytes(32, "big"))
     terms = [[list(t) for t in term] for term in terms]
     n = len(terms[0][0]).bit_length() - 1
@@ -76,11 +113,32 @@ def _mle_eval(field, table, point):
     return table[0]
 
 
-def _start(field, seed, log_out0):
+def _start(field, seed, layers, inputs, outputs):
+    """The driver's transcript binds the whole statement BEFORE the output point g is drawn: caller's seed (32 bytes), the
+    circuit, the inputs and the claimed outputs (digests, see tree_digest)."""
     tr = pyref.Transcript()
     tr.append(bytes(seed))
-    g = [tr.sample_field_element(field) for _ in range(log_out0)]
+    tr.append(circuit_digest(layers))
+    tr.append(table_digest(field, inputs))
+    tr.append(table_digest(field, outputs))
+    g = [tr.sample_field_element(field) for _ in range(layers[0][0])]
     return tr, g
+
+
+def _verify_partial_from(tr, field, claimed_sum, round_polys):
+    """verify_partial (verifier.rs:44-78) continuing the transcript tr -> (subclaim sum, challenges); ValueError on a failed
+    round check"""
+    p = pyref.modulus(field)
+    tr.append((claimed_sum % p).to_bytes(32, "big"))
+    claimed, challenges = claimed_sum % p, []
+    for rp in round_polys:
+        tr.append(b"".join(v.to_bytes(32, "big") for v in rp))
+        if claimed != (pyref._interp_eval(field, rp, 0) + pyref._interp_eval(field, rp, 1)) % p:
+            raise ValueError("verifier check failed: claimed_sum != p(0) + p(1)")
+        c = tr.sample_field_element(field)
+        claimed = pyref._interp_eval(field, rp, c)
+        challenges.append(c)
+    return claimed, challenges
 
 
 def _E(field, claim, log_out):
@@ -92,9 +150,13 @@ def _E(field, claim, log_out):
     return [(claim["alpha"] * a + claim["beta"] * b) % p for a, b in zip(e1, e2)]
 
 
+def _absorb(tr, elems):
+    tr.append(b"".join(int(x).to_bytes(32, "big") for x in elems))
+
+
 def _next_claim(field, tr, layer_proof, u, v):
+    """the layer's messages have been absorbed as they were produced ([rp1 | W(u)] then [rp2 | W(v)]): draw alpha, beta"""
     p = pyref.modulus(field)
-    tr.append(b"".join(x.to_bytes(32, "big") for x in layer_proof))
     alpha = tr.sample_field_element(field)
     beta = tr.sample_field_element(field)
     wu, wv = layer_proof[-2], layer_proof[-1]
@@ -105,7 +167,7 @@ def gkr_prove(field, layers, inputs, seed):
     """-> (outputs, proof) with proof a flat list of ints, per layer [rp1 (log_in*3) | rp2 (log_in*3) | W(u) | W(v)]."""
     p = pyref.modulus(field)
     vals = evaluate_circuit(field, layers, inputs)
-    tr, g = _start(field, seed, layers[0][0])
+    tr, g = _start(field, seed, layers, inputs, vals[0])
     claim = {"g1": g, "g2": None, "alpha": 1, "beta": 0, "c": _mle_eval(field, vals[0], g)}
     proof = []
     for i, (log_out, log_in, op, left, right) in enumerate(layers):
@@ -119,8 +181,9 @@ def gkr_prove(field, layers, inputs, seed):
             else:
                 H[x] = (H[x] + E[z]) % p
                 B1[x] = (B1[x] + E[z] * W[y]) % p
-        rp1, u, fin1 = prove_partial_terms(field, [[W, H], [B1]], 2, claim["c"])
+        rp1, u, fin1 = prove_partial_terms(field, [[W, H], [B1]], 2, claim["c"], fork(tr))   # chained onto the driver transcript
         wu = fin1[0]
+        _absorb(tr, [x for rp in rp1 for x in rp] + [wu])
         sub1 = (fin1[0] * fin1[1] + fin1[2]) % p
         equ = eq_table(field, u)
         A2, M2 = [0] * n_in, [0] * n_in
@@ -132,8 +195,9 @@ def gkr_prove(field, layers, inputs, seed):
                 A2[y] = (A2[y] + t) % p
         H2 = [(a + wu * m) % p for a, m in zip(A2, M2)]
         C2 = [wu * a % p for a in A2]
-        rp2, v, fin2 = prove_partial_terms(field, [[W, H2], [C2]], 2, sub1)
+        rp2, v, fin2 = prove_partial_terms(field, [[W, H2], [C2]], 2, sub1, fork(tr))      # W(u) is bound before v is drawn
         wv = fin2[0]
+        _absorb(tr, [x for rp in rp2 for x in rp] + [wv])
         layer_proof = [x for rp in rp1 for x in rp] + [x for rp in rp2 for x in rp] + [wu, wv]
         proof += layer_proof
         claim = _next_claim(field, tr, layer_proof, u, v)
@@ -143,7 +207,7 @@ def gkr_prove(field, layers, inputs, seed):
 def gkr_verify(field, layers, inputs, outputs, seed, proof):
     """True = accept.  Independent of the prover above except for the shared transcript schedule."""
     p = pyref.modulus(field)
-    tr, g = _start(field, seed, layers[0][0])
+    tr, g = _start(field, seed, layers, inputs, outputs)
     claim = {"g1": g, "g2": None, "alpha": 1, "beta": 0, "c": _mle_eval(field, [o % p for o in outputs], g)}
     pos = 0
     u = v = None
@@ -156,8 +220,10 @@ def gkr_verify(field, layers, inputs, outputs, seed, proof):
         rp2 = [layer_proof[3 * s + 3 * r:3 * s + 3 * r + 3] for r in range(s)]
         wu, wv = layer_proof[-2], layer_proof[-1]
         try:
-            sub1, u = pyref.sumcheck_verify_partial(field, claim["c"], rp1)
-            sub2, v = pyref.sumcheck_verify_partial(field, sub1, rp2)
+            sub1, u = _verify_partial_from(fork(tr), field, claim["c"], rp1)
+            _absorb(tr, [x for rp in rp1 for x in rp] + [wu])
+            sub2, v = _verify_partial_from(fork(tr), field, sub1, rp2)
+            _absorb(tr, [x for rp in rp2 for x in rp] + [wv])
         except ValueError:
             return False
         E = _E(field, claim, log_out)

@@ -9,7 +9,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-assert os.environ.get("ZK_QUAD_MAX_PAIRS") == "0"   # with ZK_SKIP1_MIN_PAIRS=1: the SKIP1 kernels; without: plain k_round_kd
+# the caller selects the kernel path with ZK_SKIP1_MIN_PAIRS / ZK_QUAD_MAX_PAIRS / ZK_PIPE_MAX_PAIRS (read once per process by
+# the library) and the table sizes with ZK_CHECK_SIZES
+SIZES = tuple(int(x) for x in os.environ.get("ZK_CHECK_SIZES", "2,3,7,11,13").split(","))
 
 import numpy as np  # noqa: E402
 
@@ -24,7 +26,7 @@ for field in (zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR):
     ctx = zk_amd.Context(field, 0)
     p = zk_amd.modulus(field)
     for k, D in ((2, 2), (3, 3), (1, 1), (2, 3)):
-        for n in (2, 3, 7, 11, 13):
+        for n in SIZES:
             tabs = [orc.fill_random(field, 7000 + 10 * k + f, 1 << n) for f in range(k)]
             claimed = np.zeros(4, dtype=np.uint64)
             for e in orc.prod_reduce(field, n, tabs):
@@ -39,7 +41,7 @@ for field in (zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR):
                 checked += 1
     # the two-term GKR layer shape through the merged kernel
     rng = random.Random(field)
-    for n in (3, 8, 12):
+    for n in (3, 8, 12) + tuple(x for x in SIZES if x > 12):
         tabs = [[[rng.randrange(p) for _ in range(1 << n)] for _ in range(kk)] for kk in (2, 1)]
         s = sum(a * b + c for a, b, c in zip(tabs[0][0], tabs[0][1], tabs[1][0])) % p
         want = gkr_ref.prove_partial_terms(field, tabs, 2, s)
@@ -48,4 +50,5 @@ for field in (zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR):
         assert [zk_amd.fe_to_ints(field, r) for r in rp] == want[0] and zk_amd.fe_to_ints(field, ch) == want[1]
         assert zk_amd.fe_to_ints(field, fin) == want[2]
         checked += 1
-print(f"skip1 ok: {checked} proofs bit-exact (ZK_SKIP1_MIN_PAIRS={os.environ.get('ZK_SKIP1_MIN_PAIRS')})")
+print(f"skip1 ok: {checked} proofs bit-exact (ZK_SKIP1_MIN_PAIRS={os.environ.get('ZK_SKIP1_MIN_PAIRS')} "
+      f"ZK_QUAD_MAX_PAIRS={os.environ.get('ZK_QUAD_MAX_PAIRS')} ZK_PIPE_MAX_PAIRS={os.environ.get('ZK_PIPE_MAX_PAIRS')})")

@@ -101,3 +101,45 @@ def test_known_small_circuit():
     assert vals[1] == [3, 12] and vals[0] == [36]
     outputs, proof = gkr_ref.gkr_prove(field, layers, [1, 2, 3, 4], bytes(32))
     assert outputs == [36] and gkr_ref.gkr_verify(field, layers, [1, 2, 3, 4], outputs, bytes(32), proof)
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_statement_is_bound_before_the_output_point(field):
+    """with the output point g drawn from the caller's seed alone, outputs + delta with delta~(g) = 0 verified
+    with the honest proof.  The transcript now absorbs digests of circuit, inputs and OUTPUTS before g: the forged outputs
+    move g and are rejected; so are a changed gate and a changed wire."""
+    p = pyref.modulus(field)
+    rng = random.Random(99 + field)
+    logs = [2, 3, 2]
+    layers = rand_circuit(rng, logs)
+    inputs = [rng.randrange(p) for _ in range(1 << logs[-1])]
+    seed = bytes(32)
+    outputs, proof = gkr_ref.gkr_prove(field, layers, inputs, seed)
+    assert gkr_ref.gkr_verify(field, layers, inputs, outputs, seed, proof)
+    # delta with MLE zero at the point the OLD protocol would have used (seed only): eq(g, .)-orthogonal vector
+    tr = pyref.Transcript()
+    tr.append(seed)
+    g_old = [tr.sample_field_element(field) for _ in range(logs[0])]
+    eq = gkr_ref.eq_table(field, g_old)
+    delta = [eq[1], (-eq[0]) % p, 0, 0]                     # sum_x eq(g,x) delta[x] = 0
+    assert sum(a * b for a, b in zip(eq, delta)) % p == 0 and any(delta)
+    forged = [(o + d) % p for o, d in zip(outputs, delta)]
+    assert not gkr_ref.gkr_verify(field, layers, inputs, forged, seed, proof)
+    lo, li, op, left, right = layers[1]
+    flipped = list(layers)
+    flipped[1] = (lo, li, [1 - op[0]] + list(op[1:]), left, right)
+    assert not gkr_ref.gkr_verify(field, flipped, inputs, outputs, seed, proof)
+    rewired = list(layers)
+    rewired[1] = (lo, li, op, [(left[0] + 1) % (1 << li)] + list(left[1:]), right)
+    assert not gkr_ref.gkr_verify(field, rewired, inputs, outputs, seed, proof)
+
+
+def test_tree_digest_shape():
+    """leaves of 128 bytes, 4-ary nodes; pinned against direct Keccak compositions"""
+    k = pyref.keccak256
+    assert gkr_ref.tree_digest(b"") == k(b"")
+    assert gkr_ref.tree_digest(b"a" * 100) == k(b"a" * 100)
+    d = bytes(range(256)) * 3                                # 768 bytes = 6 leaves -> 2 nodes -> root
+    leaves = [k(d[i:i + 128]) for i in range(0, 768, 128)]
+    assert gkr_ref.tree_digest(d) == k(k(b"".join(leaves[:4])) + k(b"".join(leaves[4:])))
+    assert gkr_ref.tree_digest(d[:129]) == k(k(d[:128]) + k(d[128:129]))

@@ -480,16 +480,23 @@ def test_skip1_rounds_bit_exact():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0")   # no quad kernel: it would take the small rounds
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "skip1_check.py")], env=env, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0 and "skip1 ok" in r.stdout, r.stdout + r.stderr
-    # the same grid through plain k_round_kd at small sizes (by default the four-lanes-per-pair kernel takes those rounds)
-    env = dict(os.environ, ZK_QUAD_MAX_PAIRS="0")
-    env.pop("ZK_SKIP1_MIN_PAIRS", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "skip1_check.py")], env=env, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0 and "skip1 ok" in r.stdout, r.stdout + r.stderr
+    base = {k: v for k, v in os.environ.items() if k not in ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES")}
+    runs = [
+        # SKIP1 kernels everywhere (no quad kernel, no pipeline: they would take the small rounds)
+        dict(ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0"),
+        # plain k_round_kd at small sizes
+        dict(ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0"),
+        # the four-lanes-per-pair kernel + classic tails (the pipeline off)
+        dict(ZK_PIPE_MAX_PAIRS="0", ZK_CHECK_SIZES="7,11,13,15"),
+        # the pipeline from 2^17 pairs down, entered right after SKIP1 rounds (the transcript block derives S(1))
+        dict(ZK_PIPE_MAX_PAIRS="131072", ZK_SKIP1_MIN_PAIRS="1", ZK_CHECK_SIZES="11,12,13,15,17"),
+        # the pipeline with defaults at more sizes
+        dict(ZK_CHECK_SIZES="10,12,14,16,18"),
+    ]
+    for extra in runs:
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "skip1_check.py")], env=dict(base, **extra), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0 and "skip1 ok" in r.stdout, str(extra) + r.stdout + r.stderr
 
 
 def test_beyond_baseline_sizes_properties():

@@ -6,6 +6,7 @@
 //   fft/src/lib.rs:4-19.  There is no CPU compute fallback: every table operation is a gfx950 kernel.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <map>
 #include <new>
 #include <string>
@@ -35,13 +36,16 @@ struct zk_ctx {
     uint64_t *d_sums;       // final round sums (kMaxSums elements) + lanes area
     uint64_t *h_pinned;     // pinned staging: kMaxSums*8 u64
     uint8_t *h_results;     // pinned staging for proofs (grown on demand)
-    std::map<uint32_t, std::vector<Fe>> lagrange_w;   // interp_weights(D), cached (a field inversion per node)
+    std::map<uint32_t, uint64_t *> lagrange_w;   // interp_weights(D) in device memory, cached (a field inversion per node)
     size_t h_results_bytes;
     hipEvent_t ev0, ev1;
     std::map<std::pair<uint32_t, int>, uint64_t *> twiddles;   // (log_n, inverse) -> omega^i table, i < n/2 (n < 2^8 path)
     std::map<std::pair<uint32_t, int>, NttPlan> ntt_plans;     // (log_n, inverse) -> pass plan + two-level twiddle tables
     std::map<size_t, std::vector<void *>> pool;                // freed device blocks by exact size (stream-ordered reuse)
     size_t pool_bytes, pool_checked;
+    Fe inv2;                // 1/2 (pipelined rounds interpolate on the nodes 0, 1, -1, inf)
+    uint64_t *d_dbg;        // ZK_PIPE_DEBUG: phase timestamps of the pipelined launches (64 launches x 32 slots + finisher)
+    uint32_t dbg_launch;
     uint8_t *h_absorb[2];   // pinned staging of absorb_tables (prove / verify), kept across calls
     size_t h_absorb_bytes;
     hipEvent_t ev_absorb[2];
@@ -266,6 +270,9 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     c->h_results = nullptr;
     c->h_results_bytes = 0;
     c->pool_bytes = c->pool_checked = 0;
+    c->inv2 = fe_inverse(fe_from_u32(2, fi->P), fi->P);
+    c->d_dbg = nullptr;
+    c->dbg_launch = 0;
     c->h_absorb[0] = c->h_absorb[1] = nullptr;
     c->h_absorb_bytes = 0;
     c->ev_absorb[0] = c->ev_absorb[1] = nullptr;
@@ -285,6 +292,7 @@ extern "C" int32_t zk_ctx_destroy(zk_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &kv : c->twiddles) (void)hipFree(kv.second);
+    for (auto &kv : c->lagrange_w) (void)hipFree(kv.second);
     for (auto &kv : c->ntt_plans) {
         (void)hipFree((void *)kv.second.w_lo);
         (void)hipFree((void *)kv.second.w_hi);
@@ -726,9 +734,12 @@ extern "C" int32_t zk_product_evaluate(zk_ctx *c, const zk_mle *const *f, uint64
 // ---- round machinery ------------------------------------------------------------------------------------------
 // Per-prover device scratch: the word sponge, the current challenge, and the proof being assembled.  Nothing in the
 // round loop waits on the host: k_round (+fold) -> k_round_tail (reduce + transcript) -> k_round (+fold) -> ...
+constexpr size_t kChalWords = kChallengeBytes / 8;                                   // one challenge record, in u64
+constexpr size_t kEpartBytes = (size_t)(kPipeMaxWorkBlocks + 2) * 16 * 32;         // E partials of one pipelined round (+ total + counter)
 struct ProverScratch {
     WordSponge *d_sponge;
-    uint64_t *d_challenge;   // 1 element, Montgomery
+    uint64_t *d_challenge;   // TWO challenge records (round s uses slot s & 1): a pipelined launch reads r_{s-2} while r_{s-1} is written
+    uint64_t *d_epart;       // two E-partial buffers (pipelined rounds), same alternation
     uint64_t *d_rp;          // rounds * (D+1) elements
     uint64_t *d_ch;          // rounds elements
     uint64_t *d_final;       // kMaxFactors elements (same block as d_rp, d_ch)
@@ -741,7 +752,9 @@ static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint
     ps.rp_bytes = (size_t)(rounds ? rounds : 1) * (D + 1) * 32;
     ps.ch_bytes = (size_t)(rounds ? rounds : 1) * 32;
     ZKCHK(pool_alloc(c, sizeof(WordSponge), (void **)&ps.d_sponge));
-    ZKCHK(pool_alloc(c, kChallengeBytes, (void **)&ps.d_challenge));
+    ZKCHK(pool_alloc(c, 2 * kChallengeBytes, (void **)&ps.d_challenge));
+    ZKCHK(pool_alloc(c, 2 * kEpartBytes, (void **)&ps.d_epart));
+    HIPCHK(hipMemsetAsync(ps.d_epart, 0, 2 * kEpartBytes, c->stream));   // the last-block-done counters start at zero
     ZKCHK(pool_alloc(c, ps.rp_bytes + ps.ch_bytes + kMaxFactors * 32, (void **)&ps.d_rp));
     ps.d_ch = ps.d_rp + ps.rp_bytes / 8;
     ps.d_final = ps.d_ch + ps.ch_bytes / 8;
@@ -749,7 +762,8 @@ static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint
 }
 static void scratch_free(zk_ctx *c, ProverScratch &ps) {
     pool_free(c, ps.d_sponge, sizeof(WordSponge));
-    pool_free(c, ps.d_challenge, kChallengeBytes);
+    pool_free(c, ps.d_challenge, 2 * kChallengeBytes);
+    pool_free(c, ps.d_epart, 2 * kEpartBytes);
     pool_free(c, ps.d_rp, ps.rp_bytes + ps.ch_bytes + kMaxFactors * 32);
     ps = {};
 }
@@ -799,8 +813,15 @@ static inline TermSpec single_term(int k) {
 // sums of the current tables (already folded) -> targets.  Handles every degree.  With several terms each term's round
 // kernel writes its own range of block partials and the one tail reduction adds them all (the sum over terms is free).
 // dv (optional): previous round polynomial + Lagrange weights; allows the big fused rounds to skip the t = 1 sums.
+// defer (optional): when the sums take the one-launch fast path, do NOT launch k_round_tail; report what it would have
+// reduced (the caller merges the tail into the next pipelined launch).  defer->blocks stays 0 when the tail was launched.
+struct DeferredTail {
+    uint32_t blocks;
+    bool skip1;
+};
 static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, uint64_t q, uint32_t D, bool fused,
-                           const uint64_t *d_r, const TailTargets &tt, const TailDerive *dv = nullptr) {
+                           const uint64_t *d_r, const TailTargets &tt, const TailDerive *dv = nullptr, DeferredTail *defer = nullptr) {
+    if (defer) defer->blocks = 0;
     const FieldParams &P = c->fi->P;
     if (fast_degree(D)) {
         uint32_t total = 0;
@@ -814,6 +835,11 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
                 return ZK_ERR_HIP;
             }
             if (lrc == kLaunchOk) {
+                if (defer) {
+                    defer->blocks = g;
+                    defer->skip1 = skip1;
+                    return ZK_OK;
+                }
                 k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, g, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
                                                           tt.lanes, P, skip1 ? *dv : TailDerive{});
                 HIPCHK(hipGetLastError());
@@ -839,6 +865,11 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
             }
             total += g;
             first += ts.term_k[i];
+        }
+        if (defer) {
+            defer->blocks = total;
+            defer->skip1 = skip1;
+            return ZK_OK;
         }
         k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, total, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
                                                   tt.lanes, P, skip1 ? *dv : TailDerive{});
@@ -1001,7 +1032,19 @@ struct RoundState {
     TermSpec terms;                   // how the k flat factors group into products (one term = ProductPoly)
     uint64_t *d_final;                // optional (= ps.d_final when requested): the factors at the challenge point
     TailDerive dv;                    // Lagrange weights on 0..D (prev_rp is set per round)
+    // pipelined rounds (pipe_kernels.cuh): the E partials of round `round` already exist (computed from `cur`, the table of
+    // round - 1, before its challenge was known); `cur` still awaits that fold (pending_fold is true)
+    bool pipe_active;
+    uint32_t pipe_blocks;             // work blocks that wrote them
 };
+// challenge records alternate between two slots: round s publishes into slot s & 1
+static inline uint64_t *chal_of_round(const RoundState &st, uint64_t round) { return st.ps.d_challenge + (round & 1) * kChalWords; }
+static inline uint64_t *chal_cur(const RoundState &st) { return chal_of_round(st, st.round); }        // this round's (to be written)
+static inline uint64_t *chal_prev(const RoundState &st) { return chal_of_round(st, st.round + 1); }   // round - 1 (same parity as round + 1)
+static inline uint64_t *epart_of_round(const RoundState &st, uint64_t round) { return st.ps.d_epart + (round & 1) * (kEpartBytes / 8); }
+static inline uint32_t *epart_counter(const RoundState &st, uint64_t round) {
+    return reinterpret_cast<uint32_t *>(epart_of_round(st, round) + (size_t)(kPipeMaxWorkBlocks + 1) * 16 * 4);
+}
 static void round_state_release(RoundState &st) {
     for (uint64_t i = 0; i < (uint64_t)kMaxFactors; ++i)
         if (st.scratch[i]) {
@@ -1024,17 +1067,31 @@ static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uin
     st.terms = single_term((int)k);
     st.d_final = nullptr;
     st.dv = {};
-    if (D >= 1 && D <= (uint32_t)kMaxSkipDegree) {
-        auto it = c->lagrange_w.find(D);
-        if (it == c->lagrange_w.end()) it = c->lagrange_w.emplace(D, interp_weights(D, c->fi->P)).first;
-        for (uint32_t t = 0; t <= D; ++t) st.dv.w[t] = it->second[t];
-    }
+    st.pipe_active = false;
+    st.pipe_blocks = 0;
     for (uint64_t i = 0; i < (uint64_t)kMaxFactors; ++i) {
         st.cur[i] = i < k ? f[i]->d : nullptr;
         st.scratch[i] = nullptr;
         st.scratch_bytes[i] = 0;
     }
     int32_t rc = scratch_alloc(c, st.ps, total_rounds, D);
+    if (rc == ZK_OK && D >= 1 && D <= (uint32_t)kMaxSkipDegree) {
+        auto it = c->lagrange_w.find(D);
+        if (it == c->lagrange_w.end()) {
+            const std::vector<Fe> w = interp_weights(D, c->fi->P);
+            std::vector<uint64_t> limbs(4 * (size_t)(D + 1));
+            for (uint32_t t = 0; t <= D; ++t) fe_to_u64limbs(w[t], limbs.data() + 4 * t);
+            uint64_t *d_w = nullptr;
+            rc = raw_alloc(c, limbs.size() * 8, (void **)&d_w);
+            if (rc == ZK_OK && hipMemcpy(d_w, limbs.data(), limbs.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(d_w);
+                d_w = nullptr;
+                rc = ZK_ERR_HIP;
+            }
+            if (rc == ZK_OK) it = c->lagrange_w.emplace(D, d_w).first;
+        }
+        if (rc == ZK_OK) st.dv.w = it->second;
+    }
     if (rc == ZK_OK && !consume && st.vars_left >= 2)
         for (uint64_t i = 0; i < k && rc == ZK_OK; ++i) {
             st.scratch_bytes[i] = (size_t)32 << (st.vars_left - 1);
@@ -1045,7 +1102,7 @@ static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uin
 }
 // Enqueue the next round: apply the pending fold (prover.rs:64 of the previous round, fused) and compute this round's
 // sums (prover.rs:49-56).  `lanes` selects the sharded form (sums -> digit lanes, transcript deferred).
-static int32_t round_enqueue(RoundState &st, uint64_t *lanes) {
+static int32_t round_enqueue(RoundState &st, uint64_t *lanes, DeferredTail *defer = nullptr) {
     zk_ctx *c = st.c;
     if (st.pending_fold) st.vars_left -= 1;           // tables shrink by the fold fused into this launch
     const uint64_t m = st.vars_left;                  // variables of this round's table
@@ -1060,7 +1117,7 @@ static int32_t round_enqueue(RoundState &st, uint64_t *lanes) {
     tt.sponge = lanes ? nullptr : st.ps.d_sponge;
     tt.out_rp = st.ps.d_rp + st.round * (st.D + 1) * 4;
     tt.out_ch = st.ps.d_ch + st.round * 4;
-    tt.d_challenge = st.ps.d_challenge;
+    tt.d_challenge = chal_cur(st);
     tt.lanes = lanes;
     int32_t rc;
     if (st.pending_fold && !fast_degree(st.D)) {
@@ -1069,7 +1126,7 @@ static int32_t round_enqueue(RoundState &st, uint64_t *lanes) {
         (void)r;
         rc = ZK_OK;
         for (uint64_t i = 0; i < st.k && rc == ZK_OK; ++i) {
-            k_fold_dev<<<grid_for(q * 2), kBlock, 0, c->stream>>>(fp.in[i], fp.out[i], q * 2, (uint32_t)m, c->fi->P, st.ps.d_challenge);
+            k_fold_dev<<<grid_for(q * 2), kBlock, 0, c->stream>>>(fp.in[i], fp.out[i], q * 2, (uint32_t)m, c->fi->P, chal_prev(st));
             if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
         }
         FactorPtrs g = {};
@@ -1077,7 +1134,8 @@ static int32_t round_enqueue(RoundState &st, uint64_t *lanes) {
         if (rc == ZK_OK) rc = launch_sums(c, g, st.terms, q, st.D, false, nullptr, tt);
     } else {
         st.dv.prev_rp = st.round ? tt.out_rp - (size_t)(st.D + 1) * 4 : nullptr;
-        rc = launch_sums(c, fp, st.terms, q, st.D, st.pending_fold, st.ps.d_challenge, tt, &st.dv);
+        st.dv.prev_chal = chal_prev(st);
+        rc = launch_sums(c, fp, st.terms, q, st.D, st.pending_fold, chal_prev(st), tt, &st.dv, defer);
     }
     if (st.pending_fold) {
         for (uint64_t i = 0; i < st.k; ++i) st.cur[i] = fp.out[i];
@@ -1086,6 +1144,212 @@ static int32_t round_enqueue(RoundState &st, uint64_t *lanes) {
     st.pending_fold = true;    // this round's challenge gets applied by the next launch
     return rc;
 }
+
+// ---- pipelined rounds (pipe_kernels.cuh): host schedule -------------------------------------------------------------------
+// Rounds with at most this many pairs have their sums prepared before their challenge exists (0 switches the pipeline
+// off; ZK_PIPE_MAX_PAIRS overrides; the accumulators hold at most kMaxLazy products per lane, hence the cap).
+static uint64_t pipe_max_pairs() {
+    static const uint64_t v = [] {
+        const char *e = getenv("ZK_PIPE_MAX_PAIRS");
+        uint64_t x = e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)1 << 12;
+        const uint64_t cap = (uint64_t)kPipeMaxWorkBlocks * 16 * kMaxLazy;   // products a lane may accumulate unreduced (16 rows per block)
+        return x > cap ? cap : x;
+    }();
+    return v;
+}
+static bool pipe_shape(const RoundState &st, int *k, int *extra) {
+    if (st.terms.n_terms == 1) {
+        *k = st.terms.term_k[0];
+        *extra = 0;
+    } else if (st.terms.n_terms == 2 && st.terms.term_k[1] == 1) {
+        *k = st.terms.term_k[0];
+        *extra = 1;
+    } else {
+        return false;
+    }
+    return pipe_shape_ok(*k, st.D, *extra);
+}
+static constexpr size_t kDbgWords = 64 * 32 + 64 * 16;
+static uint64_t *pipe_dbg_slot(zk_ctx *c, bool finisher) {
+    static const bool on = getenv("ZK_PIPE_DEBUG") != nullptr;
+    if (!on) return nullptr;
+    if (!c->d_dbg) {
+        if (hipMalloc(&c->d_dbg, kDbgWords * 8) != hipSuccess) return nullptr;
+        (void)hipMemset(c->d_dbg, 0, kDbgWords * 8);
+    }
+    if (finisher) return c->d_dbg + 64 * 32;
+    const uint32_t i = c->dbg_launch++ % 64;
+    return c->d_dbg + (size_t)i * 32;
+}
+static void pipe_dbg_dump(zk_ctx *c) {
+    if (!c->d_dbg) return;
+    std::vector<uint64_t> h(kDbgWords);
+    if (hipMemcpy(h.data(), c->d_dbg, kDbgWords * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    uint64_t t0 = 0;
+    for (uint32_t i = 0; i < c->dbg_launch && i < 64; ++i) {
+        const uint64_t *d = h.data() + (size_t)i * 32;
+        if (!t0) t0 = d[0];
+        fprintf(stderr, "[pipe %2u] tail: start %7.2f red %5.2f eval %5.2f transcript %5.2f publish %5.2f | work: start %7.2f loop %5.2f close %5.2f store %5.2f\n", i,
+                (d[0] - t0) / 100.0, (d[1] - d[0]) / 100.0, (d[2] - d[1]) / 100.0, (d[3] - d[2]) / 100.0, (d[4] - d[3]) / 100.0,
+                d[8] ? (d[8] - t0) / 100.0 : 0.0, (d[9] - d[8]) / 100.0, (d[10] - d[9]) / 100.0, (d[11] - d[10]) / 100.0);
+    }
+    const uint64_t *f = h.data() + 64 * 32;
+    for (uint32_t r = 0; r < 24 && f[16 * r]; ++r) {
+        const uint64_t *d = f + 16 * r;
+        fprintf(stderr, "[fin %2u] start %7.2f gather %5.2f eval %5.2f transcript %5.2f barrier %5.2f | work %5.2f (from %5.2f)\n", r, (d[0] - t0) / 100.0,
+                (d[1] - d[0]) / 100.0, (d[2] - d[1]) / 100.0, (d[3] - d[2]) / 100.0, (d[4] - d[3]) / 100.0, d[8] ? (d[9] - d[8]) / 100.0 : 0.0,
+                d[8] ? (d[8] - d[0]) / 100.0 : 0.0);
+    }
+    (void)hipMemset(c->d_dbg, 0, kDbgWords * 8);
+    c->dbg_launch = 0;
+}
+// the pipelined finisher takes over from every state when the tables it would hold fit LDS (ZK_FINISH_PIPE=0: classic one)
+static bool finish_pipe_on() {
+    static const bool v = [] {
+        const char *e = getenv("ZK_FINISH_PIPE");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+static bool finish_pipe_applies(const RoundState &st) {
+    int k, extra;
+    if (!finish_pipe_on() || !pipe_shape(st, &k, &extra)) return false;
+    return st.vars_left >= 3 && st.vars_left - 1 <= (uint64_t)finish_pipe_max_vars(k + extra);
+}
+// May round (st.round + 1) be prepared by the pipeline, given that round st.round's table has m_s variables?
+static bool pipe_wants_next(const RoundState &st, uint64_t m_s) {
+    int k, extra;
+    if (!pipe_max_pairs() || !pipe_shape(st, &k, &extra)) return false;
+    if (m_s < 3) return false;                                                       // the launches after it need 8 elements
+    if (!finish_pipe_on() && m_s - 1 <= (uint64_t)kFinishVars) return false;          // the classic finisher takes round + 1
+    return ((uint64_t)1 << (m_s - 2)) <= pipe_max_pairs();
+}
+// every remaining round in one launch of the pipelined finisher, from whatever state the loop is in
+static int32_t finish_pipe_enqueue(RoundState &st) {
+    zk_ctx *c = st.c;
+    int k = 0, extra = 0;
+    (void)pipe_shape(st, &k, &extra);
+    FinishPipeLaunch fl = {};
+    fl.k = k;
+    fl.extra = extra;
+    fl.D = st.D;
+    fl.m_in = (uint32_t)st.vars_left;
+    fl.entry = st.pipe_active ? 2 : (st.pending_fold ? 1 : 0);
+    fl.e_partials = epart_of_round(st, st.round);
+    fl.e_blocks = 1;   // slot 0 of the buffer holds the total
+    fl.inv2 = c->inv2;
+    fl.chal_in = chal_prev(st);
+    const uint64_t remaining = st.pending_fold ? st.vars_left - 1 : st.vars_left;
+    fl.chal_last = chal_of_round(st, st.round + remaining - 1);
+    fl.sponge = st.ps.d_sponge;
+    fl.out_rp = st.ps.d_rp + st.round * (st.D + 1) * 4;
+    fl.out_ch = st.ps.d_ch + st.round * 4;
+    fl.out_final = st.d_final;
+    fl.dbg = pipe_dbg_slot(c, true);
+    FactorPtrs fp = {};
+    for (uint64_t i = 0; i < st.k; ++i) fp.in[i] = st.cur[i];
+    const int lrc = launch_finish_pipe(launch_ctx(c), fp, fl);
+    if (lrc != kLaunchOk) {
+        g_hip_err = "pipelined finisher launch failed";
+        return lrc == kLaunchUnsupported ? ZK_ERR_UNSUPPORTED : ZK_ERR_HIP;
+    }
+    st.round += remaining;
+    st.vars_left = 0;
+    st.pending_fold = false;
+    st.pipe_active = false;
+    return ZK_OK;
+}
+static PipeTailArgs pipe_tail_args(const RoundState &st, int mode, const uint64_t *partials, uint32_t nblocks, uint32_t n_in) {
+    PipeTailArgs ta = {};
+    ta.dbg = pipe_dbg_slot(st.c, false);
+    ta.partials = partials;
+    ta.nblocks = nblocks;
+    ta.n_in = n_in;
+    ta.mode = mode;
+    ta.chal_in = chal_prev(st);
+    ta.chal_out = chal_cur(st);
+    ta.sponge = st.ps.d_sponge;
+    ta.out_rp = st.ps.d_rp + st.round * (st.D + 1) * 4;
+    ta.out_ch = st.ps.d_ch + st.round * 4;
+    ta.inv2 = st.c->inv2;
+    return ta;
+}
+// Classic round st.round whose sums kernel has just been launched with its tail deferred (dt): ONE launch closes it
+// (transcript block) and prepares round + 1 from the table of this round (already folded: `cur`).
+static int32_t pipe_enter(RoundState &st, const DeferredTail &dt) {
+    zk_ctx *c = st.c;
+    int k = 0, extra = 0;
+    (void)pipe_shape(st, &k, &extra);
+    PipeLaunch pl = {};
+    pl.k = k;
+    pl.extra = extra;
+    pl.D = st.D;
+    pl.fold = false;
+    pl.emit = 1;
+    pl.q = (uint64_t)1 << (st.vars_left - 2);   // vars_left = variables of this round's table (after its fold)
+    pl.chal_fold = nullptr;
+    pl.e_partials = epart_of_round(st, st.round + 1);
+    pl.done_counter = epart_counter(st, st.round + 1);
+    pl.tail = pipe_tail_args(st, 0, c->d_partials, dt.blocks, st.D + 1);
+    if (dt.skip1) {
+        pl.tail.dv = st.dv;
+        pl.tail.dv.prev_rp = pl.tail.out_rp - (size_t)(st.D + 1) * 4;
+        pl.tail.dv.prev_chal = chal_prev(st);
+    }
+    FactorPtrs fp = {};
+    for (uint64_t i = 0; i < st.k; ++i) fp.in[i] = fp.out[i] = st.cur[i];
+    uint32_t g = 0;
+    const int lrc = launch_round_pipe(launch_ctx(c), fp, pl, &g);
+    if (lrc != kLaunchOk) {
+        g_hip_err = "pipelined round launch failed";
+        return lrc == kLaunchUnsupported ? ZK_ERR_UNSUPPORTED : ZK_ERR_HIP;
+    }
+    st.pipe_active = true;
+    st.pipe_blocks = g;
+    return ZK_OK;
+}
+// Pipelined state at round s = st.round: cur = table of round s-1 (vars_left variables), its challenge r_{s-1} pending, E_s
+// partials ready.  ONE launch: transcript block closes round s; work blocks fold cur at r_{s-1} and, when round s+1 stays in
+// the pipeline, prepare E_{s+1}.
+static int32_t pipe_step(RoundState &st) {
+    zk_ctx *c = st.c;
+    int k = 0, extra = 0;
+    (void)pipe_shape(st, &k, &extra);
+    const uint64_t m = st.vars_left;             // variables of cur = table of round s - 1
+    const bool stay = pipe_wants_next(st, m - 1);
+    PipeLaunch pl = {};
+    pl.k = k;
+    pl.extra = extra;
+    pl.D = st.D;
+    pl.fold = true;
+    pl.emit = stay ? 1 : 0;
+    pl.q = m >= 3 ? (uint64_t)1 << (m - 3) : 0;
+    if (pl.q == 0) return ZK_ERR_BAD_ARG;        // cannot happen: the finisher takes tables this small
+    pl.chal_fold = chal_prev(st);
+    pl.e_partials = epart_of_round(st, st.round + 1);
+    pl.done_counter = epart_counter(st, st.round + 1);
+    pl.tail = pipe_tail_args(st, 1, epart_of_round(st, st.round), 1, pipe_values_per_block(k, st.D));   // slot 0: the total
+    FactorPtrs fp = {};
+    for (uint64_t i = 0; i < st.k; ++i) {
+        fp.in[i] = st.cur[i];
+        fp.out[i] = (st.first_out_of_place && st.scratch[i]) ? st.scratch[i] : st.cur[i];
+    }
+    uint32_t g = 0;
+    const int lrc = launch_round_pipe(launch_ctx(c), fp, pl, &g);
+    if (lrc != kLaunchOk) {
+        g_hip_err = "pipelined round launch failed";
+        return lrc == kLaunchUnsupported ? ZK_ERR_UNSUPPORTED : ZK_ERR_HIP;
+    }
+    for (uint64_t i = 0; i < st.k; ++i) st.cur[i] = fp.out[i];
+    st.first_out_of_place = false;
+    st.vars_left = m - 1;                        // cur = table of round s, r_s pending
+    st.pipe_active = stay;
+    st.pipe_blocks = g;
+    ++st.round;
+    return ZK_OK;
+}
+// One step of the single-GPU round loop (prover.rs:44-68): everything that can be enqueued for round st.round.
+static int32_t prover_step(RoundState &st, bool *finished_in_kernel);
 
 // ---- finisher: every remaining round in one single-workgroup launch (k_finish) ----
 template <int K, int D>
@@ -1121,7 +1385,7 @@ static int32_t finish_enqueue(RoundState &st) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_finish_terms<DD>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds) != hipSuccess)                                                                        \
             return ZK_ERR_HIP;                                                                                                  \
-        k_finish_terms<DD><<<1, kBlock, lds, c->stream>>>(fp, st.terms, m_in, pending, P, st.ps.d_challenge, st.ps.d_sponge,     \
+        k_finish_terms<DD><<<1, kBlock, lds, c->stream>>>(fp, st.terms, m_in, pending, P, chal_prev(st), st.ps.d_sponge,     \
                                                           out_rp, out_ch, st.d_final);                                          \
         break;
         switch (st.D) {
@@ -1135,13 +1399,13 @@ static int32_t finish_enqueue(RoundState &st) {
         rc = hipGetLastError() == hipSuccess ? ZK_OK : ZK_ERR_HIP;
     } else {
         switch ((int)st.k * 10 + (int)st.D) {
-            case 11: rc = launch_finish<1, 1>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
-            case 12: rc = launch_finish<1, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
-            case 21: rc = launch_finish<2, 1>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
-            case 22: rc = launch_finish<2, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
-            case 23: rc = launch_finish<2, 3>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
-            case 32: rc = launch_finish<3, 2>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
-            case 33: rc = launch_finish<3, 3>(c, fp, m_in, pending, st.ps.d_challenge, st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+            case 11: rc = launch_finish<1, 1>(c, fp, m_in, pending, chal_prev(st), st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+            case 12: rc = launch_finish<1, 2>(c, fp, m_in, pending, chal_prev(st), st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+            case 21: rc = launch_finish<2, 1>(c, fp, m_in, pending, chal_prev(st), st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+            case 22: rc = launch_finish<2, 2>(c, fp, m_in, pending, chal_prev(st), st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+            case 23: rc = launch_finish<2, 3>(c, fp, m_in, pending, chal_prev(st), st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+            case 32: rc = launch_finish<3, 2>(c, fp, m_in, pending, chal_prev(st), st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
+            case 33: rc = launch_finish<3, 3>(c, fp, m_in, pending, chal_prev(st), st.ps.d_sponge, out_rp, out_ch, st.d_final); break;
             default: break;
         }
     }
@@ -1156,6 +1420,30 @@ static inline bool finish_applies(const RoundState &st) {
     if (st.terms.n_terms == 1 ? !finish_shape_ok(st.k, st.D) : !fast_degree(st.D)) return false;
     const uint64_t after = st.pending_fold ? st.vars_left - 1 : st.vars_left;
     return after >= 1 && after <= (uint64_t)kFinishVars;
+}
+
+static int32_t prover_step(RoundState &st, bool *finished_in_kernel) {
+    if (finish_pipe_applies(st)) {                                       // (covers the pipelined state as well)
+        *finished_in_kernel = true;
+        return finish_pipe_enqueue(st);
+    }
+    if (st.pipe_active) return pipe_step(st);
+    if (finish_applies(st)) {
+        *finished_in_kernel = true;
+        return finish_enqueue(st);                                       // all remaining rounds in one launch
+    }
+    // the table of this round has m_s variables; if the NEXT round belongs to the pipeline, this round's tail is merged
+    // into the launch that prepares it
+    const uint64_t m_s = st.pending_fold ? st.vars_left - 1 : st.vars_left;
+    DeferredTail dt = {0, false};
+    const bool enter = fast_degree(st.D) && pipe_wants_next(st, m_s);
+    ZKCHK(round_enqueue(st, nullptr, enter ? &dt : nullptr));
+    if (enter && dt.blocks) ZKCHK(pipe_enter(st, dt));
+    else if (enter) {   // the sums did not take the one-launch path: their tail has not been launched yet
+        return ZK_ERR_UNSUPPORTED;
+    }
+    ++st.round;
+    return ZK_OK;
 }
 
 // host byte sponge (table + claimed sum absorbed) -> device word sponge.  The 208-byte state travels as a kernel argument:
@@ -1206,21 +1494,13 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
     if (out_final) st.d_final = st.ps.d_final;
     if (rc == ZK_OK) rc = sponge_to_device(c, sp, st.ps.d_sponge);
     bool finished_in_kernel = false;
-    while (st.round < n && rc == ZK_OK) {                                // prover.rs:44-68, all on device
-        if (finish_applies(st)) {
-            rc = finish_enqueue(st);                                     // all remaining rounds in one launch
-            finished_in_kernel = true;
-        } else {
-            rc = round_enqueue(st, nullptr);
-            ++st.round;
-        }
-    }
+    while (st.round < n && rc == ZK_OK) rc = prover_step(st, &finished_in_kernel);   // prover.rs:44-68, all on device
     // prover.rs:64 after the LAST round folds to a 0-variable polynomial the reference drops: computed only on request.
     if (rc == ZK_OK && out_final) {
         if (!finished_in_kernel) {
             FactorPtrs fp = {};
             for (uint64_t i = 0; i < k; ++i) fp.in[i] = st.cur[i];
-            k_final_evals<<<1, 64, 0, c->stream>>>(fp, (uint32_t)k, st.ps.d_challenge, st.d_final, P);
+            k_final_evals<<<1, 64, 0, c->stream>>>(fp, (uint32_t)k, chal_prev(st), st.d_final, P);
             if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
         }
     }
@@ -1238,6 +1518,7 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
         g_hip_err = "sumcheck: stream synchronize failed";
         rc = ZK_ERR_HIP;
     }
+    if (c->d_dbg) pipe_dbg_dump(c);
     if (rc == ZK_OK) {
         memcpy(out_rp, stage, (size_t)n * (D + 1) * 32);
         memcpy(out_ch, stage + st.ps.rp_bytes, (size_t)n * 32);
@@ -1381,7 +1662,7 @@ extern "C" int32_t zk_shard_prover_round_finish(zk_shard_prover *sp) {
     if (st.round >= sp->local_rounds || !st.pending_fold) return ZK_ERR_BAD_ARG;
     ZKCHK(use_device(c));
     k_lanes_transcript<<<1, 64, 0, c->stream>>>(sp->d_lanes, st.D + 1, st.ps.d_sponge, st.ps.d_rp + st.round * (st.D + 1) * 4,
-                                                st.ps.d_ch + st.round * 4, st.ps.d_challenge, c->fi->P);
+                                                st.ps.d_ch + st.round * 4, chal_cur(st), c->fi->P);
     HIPCHK(hipGetLastError());
     ++st.round;
     return ZK_OK;
@@ -1405,7 +1686,7 @@ extern "C" int32_t zk_shard_prover_tail_ptr(zk_shard_prover *sp, void **out_ptr,
             uint64_t *dst = sp->d_tail + ((uint64_t)i << s) * 4;
             if (st.pending_fold) {
                 const uint64_t pairs = 1ull << s;
-                k_fold_dev<<<grid_for(pairs), kBlock, 0, c->stream>>>(st.cur[i], dst, pairs, (uint32_t)(s + 1), c->fi->P, st.ps.d_challenge);
+                k_fold_dev<<<grid_for(pairs), kBlock, 0, c->stream>>>(st.cur[i], dst, pairs, (uint32_t)(s + 1), c->fi->P, chal_prev(st));
                 HIPCHK(hipGetLastError());
             } else {
                 HIPCHK(hipMemcpyAsync(dst, st.cur[i], (size_t)32 << s, hipMemcpyDeviceToDevice, c->stream));
@@ -1449,14 +1730,8 @@ extern "C" int32_t zk_shard_prover_tail_rounds(zk_shard_prover *sp, const void *
     st.first_out_of_place = false;
     st.vars_left = vars;
     int32_t rc = ZK_OK;
-    while (st.round < sp->total_rounds && rc == ZK_OK) {
-        if (finish_applies(st)) {
-            rc = finish_enqueue(st);
-        } else {
-            rc = round_enqueue(st, nullptr);
-            ++st.round;
-        }
-    }
+    bool fin = false;
+    while (st.round < sp->total_rounds && rc == ZK_OK) rc = prover_step(st, &fin);
     return rc;
 }
 // download what has been proven so far (synchronises): total_rounds*(D+1) and total_rounds elements

@@ -83,11 +83,12 @@ ZK_D void run_store(uint64_t *run, uint32_t lane, const Fe &e) {
 
 // Big fused rounds leave out the t = 1 sums; the tail derives S_i(1) = S_{i-1}(r_{i-1}) - S_i(0) (k_round_kd, SKIP1).
 // prev_rp: the previous round polynomial (D + 1 elements, device); w[t] = 1 / prod_{u != t} (t - u), the Lagrange weights
-// on the nodes 0..D (Montgomery form, computed by the host once per proof).
+// on the nodes 0..D (Montgomery form, computed by the host once per context and degree, kept in device memory).
 constexpr int kMaxSkipDegree = 4;
 struct TailDerive {
     const uint64_t *prev_rp;   // null: nothing to derive
-    Fe w[kMaxSkipDegree + 1];
+    const uint64_t *prev_chal; // challenge record of the previous round (r_{i-1})
+    const uint64_t *w;         // the D + 1 weights, device memory (one buffer per context and degree)
 };
 
 // Sum of one field element per lane over a wave, entirely on the VALU: v_permlane32_swap / v_permlane16_swap (gfx950)

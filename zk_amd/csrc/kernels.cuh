@@ -181,16 +181,13 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
         if (derive1 && t == 1) {
             // this wave would own t = 1: it evaluates the previous round polynomial at the previous challenge instead,
             //   claim = sum_t prev[t] * w[t] * prod_{u != t} (r - u)   (lane t takes term t; D + 1 multiplies deep)
-            const Fe r = fe_load(d_challenge, 0);
+            const Fe r = fe_load(dv.prev_chal, 0);
             Fe term = fe_zero();
             if ((uint32_t)lane < ns) {
                 Fe one;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
-                Fe wt = dv.w[0];   // static indices only: the weights live in the kernel arguments
-#pragma unroll
-                for (int i = 1; i <= kMaxSkipDegree; ++i)
-                    if (lane == i) wt = dv.w[i];
+                const Fe wt = fe_load(dv.w, lane);
                 term = fe_mul(fe_load(dv.prev_rp, lane), wt, P);
                 Fe node = fe_zero();   // Montgomery form of u
                 for (uint32_t u = 0; u < ns; ++u) {

@@ -26,4 +26,45 @@ int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, ui
 // One evaluation point (any degree): sums of prod_f (lo - t*(lo-hi)) -> per-block partials (1 sum per block).
 int launch_round_single_t(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, const Fe &tval, uint32_t *out_grid);
 
+
+// ---- pipelined rounds (pipe_kernels.cuh / pipe.hip): sums of round s as a polynomial in the pending challenge -------------
+constexpr uint32_t kPipeMaxWorkBlocks = 512;
+}  // namespace zk
+#include "pipe_args.hpp"
+namespace zk {
+struct PipeLaunch {
+    int k, extra;             // shape: k-factor product (+ one single-factor term)
+    uint32_t D;
+    bool fold;                // work blocks first fold fp.in (8q elements) -> fp.out (4q) at *chal_fold
+    int emit;                 // 1: write the E partials of the round with q pairs; 0: fold only (leaving the pipeline)
+    uint64_t q;               // pairs of the round whose E is prepared
+    const uint64_t *chal_fold;
+    uint64_t *e_partials;     // out: slot 0 = total, slot 1 + b = work block b; (D+1)*(k+1) elements each
+    uint32_t *done_counter;   // device word, zero between launches (last-block-done reduction of the partials)
+    PipeTailArgs tail;        // the transcript block's job (the round before)
+};
+bool pipe_shape_ok(int k, uint32_t D, int extra);
+uint32_t pipe_values_per_block(int k, uint32_t D);
+uint32_t pipe_rows_per_block(int k, uint32_t D, int extra);
+uint32_t pipe_work_blocks(int k, uint32_t D, int extra, uint64_t q);
+int launch_round_pipe(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t *out_work_blocks);
+// the pipelined finisher (k_finish_pipe): every remaining round in one launch; entry = kFinEntry* of pipe_kernels.cuh
+// (0 fresh tables, 1 tables with *chal_in pending, 2 the same with the E partials of the first round ready)
+struct FinishPipeLaunch {
+    int k, extra;
+    uint32_t D;
+    uint32_t m_in;            // variables of the tables in fp.in (3 .. finish_pipe_max_vars(k + extra) + 1)
+    int entry;
+    const uint64_t *e_partials;
+    uint32_t e_blocks;
+    Fe inv2;
+    const uint64_t *chal_in;
+    uint64_t *chal_last;      // record the last challenge is published in
+    WordSponge *sponge;
+    uint64_t *out_rp, *out_ch, *out_final;
+    uint64_t *dbg;            // optional timestamps (ZK_PIPE_DEBUG)
+};
+int launch_finish_pipe(const RoundLaunchCtx &lc, const FactorPtrs &fp, const FinishPipeLaunch &fl);
+uint32_t finish_pipe_max_vars(int n_factors);   // largest after-fold table (variables) the pipelined finisher keeps in LDS
+
 }  // namespace zk

@@ -1,0 +1,22 @@
+// pipe_args.hpp -- argument block of the transcript block of a pipelined round kernel (shared by host and device code).
+#pragma once
+#include "common.cuh"
+#include "keccak.hpp"
+
+namespace zk {
+
+struct PipeTailArgs {
+    const uint64_t *partials;   // per-block partials of the round being closed: [block][n_in] elements
+    uint32_t nblocks;
+    uint32_t n_in;              // values per block: NS (mode 0; SKIP1 leaves slot 1 unwritten) or NS * NR (mode 1)
+    int mode;                   // 0: plain sums   1: E(t; rho), evaluated at *chal_in
+    const uint64_t *chal_in;    // challenge record of the previous round (mode 1, and SKIP1's derive)
+    uint64_t *chal_out;         // challenge record this round's challenge is published in
+    WordSponge *sponge;
+    uint64_t *out_rp, *out_ch;
+    Fe inv2;
+    TailDerive dv;              // mode 0 after a SKIP1 round kernel
+    uint64_t *dbg;              // optional: 100 MHz timestamps of the phases (ZK_PIPE_DEBUG), 32 slots per launch
+};
+
+}  // namespace zk

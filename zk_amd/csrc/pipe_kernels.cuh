@@ -20,16 +20,25 @@
 // work blocks read r_{s-2} while the transcript block writes r_{s-1}.
 // k_finish_pipe: all remaining rounds in one 1024-thread workgroup with the same overlap (wave 0 = transcript, the other
 // waves fold in LDS and prepare the next round's E), one barrier per round.
+//
+// Work layout ("hex"): these rounds are latency-bound, so ONE pair index gets the 16 lanes of a DPP row and every lane does
+// one multiplication per phase, exchanging through a per-row LDS buffer (same wave: LDS operations execute in order):
+//   A  lane (factor f, slot l): loads T[j + l*q] (and T[j + (l+4)*q], folding them at the challenge: 1 multiply), the four
+//      values a_l = table of the round before the prepared one, restricted to the pair index;
+//   B1 lane (factor f, point t): u = a0 + t(a1 - a0) (value if the pending challenge were 0), w = a2 + t(a3 - a2) (if it
+//      were 1), and from them the factor's value at every node: u, w - u (inf), w, 2u - w (-1);
+//   B2 lane (point t, node rho): the product over the factors (1 multiply, unreduced accumulation).
 #pragma once
 #include "common.cuh"
 #include "quad.cuh"
 #include "transcript.cuh"
+#include "pipe_args.hpp"
 
 namespace zk {
 
 constexpr int kPipeNodeZero = 0, kPipeNodeInf = 1, kPipeNodeOne = 2, kPipeNodeMinus = 3;
 constexpr int kPipeThreads = 256;
-constexpr int kFinishPipeThreads = 1024;
+constexpr int kFinishPipeThreads = 256;
 
 template <int K, int D, int EXTRA>
 struct PipeShape {
@@ -37,121 +46,158 @@ struct PipeShape {
     static constexpr int NF = K + EXTRA, NS = D + 1, NR = K + 1, NE = NS * NR;
 };
 
-// Per-lane accumulators of the work lanes (lane l4 = evaluation point t of its quad).
+
+// ---- the work lanes --------------------------------------------------------------------------------------------------------
 template <int K, int D, int EXTRA, bool PLAIN>
-struct PipeAcc {
-    WideAcc e[K >= 2 ? K + 1 : 1];      // unreduced E(t; node) products (K >= 2)
-    WideAcc s[(PLAIN && K >= 2) ? 1 : 1];   // plain S(t) of the table itself (fresh / pending entry of the finisher)
-    Fe su, sw;                          // K == 1: sum u, sum w of factor 0;  EXTRA: of the single-factor term
-    Fe ps;                              // PLAIN, K == 1 or EXTRA: modular part of the plain sum
+struct HexCfg {
+    static constexpr int NF = K + EXTRA, NS = D + 1, NR = K + 1;
+    static constexpr int XW = NR + (PLAIN ? 2 : 0);          // values a (factor, point) lane publishes
+    static constexpr int ROW_FE = NF * NS * XW > NF * 4 ? NF * NS * XW : NF * 4;   // the a's alias the x's (read before written)
+    static constexpr int ROW_BYTES = ROW_FE * 32;
 };
-template <int K, int D, int EXTRA, bool PLAIN>
-ZK_D void pipe_acc_zero(PipeAcc<K, D, EXTRA, PLAIN> &A) {
-#pragma unroll
-    for (int i = 0; i < (K >= 2 ? K + 1 : 1); ++i) wide_zero(A.e[i]);
-    wide_zero(A.s[0]);
-    A.su = fe_zero();
-    A.sw = fe_zero();
+template <bool PLAIN>
+struct HexAcc {
+    WideAcc e;            // K >= 2: unreduced products of this lane's (t, node)
+    WideAcc p;            // PLAIN: products of the table's own pairs (node 0: pairs (a0, a2); node 1: pairs (a1, a3))
+    Fe s, ps;             // K == 1 / the single-factor term: modular sums
+};
+template <bool PLAIN>
+ZK_D void hex_acc_zero(HexAcc<PLAIN> &A) {
+    wide_zero(A.e);
+    wide_zero(A.p);
+    A.s = fe_zero();
     A.ps = fe_zero();
 }
-
-// value of a0 + t*(a1 - a0) on the lane whose evaluation point is t = l4 (0..3)
-ZK_D Fe pipe_point(const Fe &a0, const Fe &a1, uint32_t l4, const FieldParams &P) {
+ZK_D Fe fe_and(const Fe &a, uint32_t mask) {
+    Fe o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = a.v[i] & mask;
+    return o;
+}
+// a0 + t * (a1 - a0) for a lane-dependent t in 0..D, as D masked additions (no selects: the compiler turns chains of
+// selects over lane-dependent conditions into scratch-memory tables)
+template <int D>
+ZK_D Fe hex_point(const Fe &a0, const Fe &a1, uint32_t t, const FieldParams &P) {
     const Fe d = fe_sub(a1, a0, P);
-    Fe v = l4 == 0 ? a0 : a1;
-    const Fe v2 = fe_add(a1, d, P);
-    v = l4 >= 2 ? v2 : v;
-    const Fe v3 = fe_add(v2, d, P);
-    v = l4 >= 3 ? v3 : v;
+    Fe v = a0;
+#pragma unroll
+    for (int s = 1; s <= D; ++s) v = fe_add(v, fe_and(d, t >= (uint32_t)s ? 0xffffffffu : 0u), P);
     return v;
 }
-
-// One pair index of round s on a quad: lane f holds a[0..4) = T_{s-1}[j + l*q] of factor f (already folded); every lane ends
-// up with its evaluation point's contribution added to A.  EMIT: the E(t; rho) part;  PLAIN: the plain sums of T_{s-1} itself
-// (its pairs are (a0, a2) and (a1, a3)).
-template <int K, int D, int EXTRA, bool PLAIN, int F = 0>
-ZK_D void pipe_products(PipeAcc<K, D, EXTRA, PLAIN> &A, const Fe (&a)[4], uint32_t l4, bool emit, const FieldParams &P, Fe (&pe)[4],
-                        Fe (&pp)[2]) {
-    constexpr int NF = K + EXTRA;
-    const Fe b0 = quad_bcast<F>(a[0]), b1 = quad_bcast<F>(a[1]), b2 = quad_bcast<F>(a[2]), b3 = quad_bcast<F>(a[3]);
-    if (emit) {
-        const Fe u = pipe_point(b0, b1, l4, P), w = pipe_point(b2, b3, l4, P);
-        if constexpr (F < K) {
-            const Fe v = fe_sub(w, u, P);
-            if constexpr (K == 1) {
-                A.su = fe_add(A.su, u, P);
-                A.sw = fe_add(A.sw, w, P);
-            } else if constexpr (F == 0) {
-                pe[kPipeNodeZero] = u;
-                pe[kPipeNodeInf] = v;
-                pe[kPipeNodeOne] = w;
-                if constexpr (K == 3) pe[kPipeNodeMinus] = fe_sub(u, v, P);
-            } else if constexpr (F < K - 1) {
-                pe[kPipeNodeZero] = fe_mul(pe[kPipeNodeZero], u, P);
-                pe[kPipeNodeInf] = fe_mul(pe[kPipeNodeInf], v, P);
-                pe[kPipeNodeOne] = fe_mul(pe[kPipeNodeOne], w, P);
-                if constexpr (K == 3) pe[kPipeNodeMinus] = fe_mul(pe[kPipeNodeMinus], fe_sub(u, v, P), P);
-            } else {
-                wide_mac(A.e[kPipeNodeZero], pe[kPipeNodeZero].v, u.v);
-                wide_mac(A.e[kPipeNodeInf], pe[kPipeNodeInf].v, v.v);
-                wide_mac(A.e[kPipeNodeOne], pe[kPipeNodeOne].v, w.v);
-                if constexpr (K == 3) {
-                    const Fe m = fe_sub(u, v, P);
-                    wide_mac(A.e[kPipeNodeMinus], pe[kPipeNodeMinus].v, m.v);
-                }
-            }
-        } else {   // the single-factor term: linear in r, only sums
-            A.su = fe_add(A.su, u, P);
-            A.sw = fe_add(A.sw, w, P);
-        }
-    }
-    if constexpr (PLAIN) {
-        const Fe x = pipe_point(b0, b2, l4, P), y = pipe_point(b1, b3, l4, P);   // the table's own pairs (j, j+2q), (j+q, j+3q)
-        if constexpr (F < K) {
-            if constexpr (K == 1) {
-                A.ps = fe_add(A.ps, fe_add(x, y, P), P);
-            } else if constexpr (F == 0) {
-                pp[0] = x;
-                pp[1] = y;
-            } else if constexpr (F < K - 1) {
-                pp[0] = fe_mul(pp[0], x, P);
-                pp[1] = fe_mul(pp[1], y, P);
-            } else {
-                wide_mac(A.s[0], pp[0].v, x.v);
-                wide_mac(A.s[0], pp[1].v, y.v);
-            }
-        } else {
-            A.ps = fe_add(A.ps, fe_add(x, y, P), P);
-        }
-    }
-    if constexpr (F + 1 < NF) pipe_products<K, D, EXTRA, PLAIN, F + 1>(A, a, l4, emit, P, pe, pp);
+ZK_D Fe lds_fe_load(const Fe *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    const uint4 a = q[0], b = q[1];
+    Fe r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+    return r;
+}
+ZK_D void lds_fe_store(Fe *p, const Fe &r) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
 }
 
-// Close the accumulators: out[node] = this lane's E(t; node) (NR values), plain = its plain S(t).
-template <int K, int D, int EXTRA, bool PLAIN>
-ZK_D void pipe_acc_close(const PipeAcc<K, D, EXTRA, PLAIN> &A, Fe (&out)[K + 1], Fe &plain, const FieldParams &P) {
-    if constexpr (K == 1) {
-        out[kPipeNodeZero] = A.su;
-        out[kPipeNodeInf] = fe_sub(A.sw, A.su, P);
-    } else {
-#pragma unroll
-        for (int i = 0; i <= K; ++i) out[i] = redc_wide(A.e[i], P);
-        if constexpr (EXTRA) {
-            out[kPipeNodeZero] = fe_add(out[kPipeNodeZero], A.su, P);
-            out[kPipeNodeOne] = fe_add(out[kPipeNodeOne], A.sw, P);
-            if constexpr (K == 3) out[kPipeNodeMinus] = fe_add(out[kPipeNodeMinus], fe_sub(fe_add(A.su, A.su, P), A.sw, P), P);   // u - v = 2u - w
+// One pair index j (of q) on one 16-lane row.  src / dst: this lane's phase-A factor table (lanes of quad f: factor f).
+// live: j < q (dead rows carry zeros through every phase and add nothing).
+template <int K, int D, int EXTRA, bool FOLD, bool PLAIN, bool EMIT>
+ZK_D void hex_step(HexAcc<PLAIN> &A, const uint64_t *src, uint64_t *dst, uint64_t j, uint64_t q, bool live, const Mul29 &r, const FieldParams &P,
+                   Fe *row /* LDS: this row's exchange buffer */, uint32_t lane16) {
+    using C = HexCfg<K, D, EXTRA, PLAIN>;
+    const uint32_t hi2 = lane16 >> 2, lo2 = lane16 & 3;
+    // ---- A: (factor hi2, slot lo2) ----
+    {
+        Fe a = fe_zero();
+        if (live && hi2 < (uint32_t)C::NF) {
+            const Fe x = fe_load(src, j + (uint64_t)lo2 * q);
+            if constexpr (FOLD) {
+                const Fe y = fe_load(src, j + (uint64_t)(lo2 + 4) * q);
+                a = fe_sub(x, fe_mul29(fe_sub(x, y, P), r, P), P);   // evaluation_form.rs:68
+                fe_store(dst, j + (uint64_t)lo2 * q, a);
+            } else {
+                a = x;
+            }
+        }
+        if (hi2 < (uint32_t)C::NF) lds_fe_store(row + hi2 * 4 + lo2, a);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- B1: (factor hi2, point lo2) ----
+    {
+        const bool role = hi2 < (uint32_t)C::NF && lo2 < (uint32_t)C::NS;
+        const uint32_t f = role ? hi2 : 0, t = lo2;
+        const Fe a0 = lds_fe_load(row + f * 4 + 0), a1 = lds_fe_load(row + f * 4 + 1), a2 = lds_fe_load(row + f * 4 + 2),
+                 a3 = lds_fe_load(row + f * 4 + 3);
+        __builtin_amdgcn_wave_barrier();   // every lane has read its a's before anybody overwrites them with x's
+        Fe *x = row + (f * C::NS + (role ? t : 0)) * C::XW;
+        if constexpr (EMIT) {
+            const Fe u = hex_point<D>(a0, a1, t, P), w = hex_point<D>(a2, a3, t, P);
+            Fe v = fe_sub(w, u, P);
+            if constexpr (EXTRA) v = fe_and(v, f == (uint32_t)K ? 0u : 0xffffffffu);   // the single-factor term has no r^K part
+            if (role) {
+                lds_fe_store(x + kPipeNodeZero, u);
+                lds_fe_store(x + kPipeNodeInf, v);
+                if constexpr (K >= 2) lds_fe_store(x + kPipeNodeOne, w);
+                if constexpr (K == 3) lds_fe_store(x + kPipeNodeMinus, fe_sub(fe_add(u, u, P), w, P));   // u - v = 2u - w
+            }
+        }
+        if constexpr (PLAIN) {
+            const Fe xp = hex_point<D>(a0, a2, t, P), yp = hex_point<D>(a1, a3, t, P);   // the table's own pairs (j, j+2q), (j+q, j+3q)
+            if (role) {
+                lds_fe_store(x + C::NR, xp);
+                lds_fe_store(x + C::NR + 1, yp);
+            }
         }
     }
+    __builtin_amdgcn_wave_barrier();
+    // ---- B2: (point hi2, node lo2) ----
+    {
+        const uint32_t t = hi2 < (uint32_t)C::NS ? hi2 : 0, node = lo2 < (uint32_t)C::NR ? lo2 : 0;
+        const Fe *x = row + t * C::XW + node;
+        constexpr int FS = C::NS * C::XW;   // stride between factors
+        if constexpr (EMIT) {
+            const Fe x0 = lds_fe_load(x);
+            if constexpr (K == 1) {
+                A.s = fe_add(A.s, x0, P);
+            } else if constexpr (K == 2) {
+                const Fe x1 = lds_fe_load(x + FS);
+                wide_mac(A.e, x0.v, x1.v);
+            } else {
+                const Fe x1 = lds_fe_load(x + FS), x2 = lds_fe_load(x + 2 * FS);
+                const Fe m = fe_mul(x0, x1, P);
+                wide_mac(A.e, m.v, x2.v);
+            }
+            if constexpr (EXTRA) A.s = fe_add(A.s, lds_fe_load(x + K * FS), P);
+        }
+        if constexpr (PLAIN) {
+            const Fe *y = row + t * C::XW + C::NR + (lo2 & 1);
+            const Fe y0 = lds_fe_load(y);
+            if constexpr (K == 1) {
+                A.ps = fe_add(A.ps, y0, P);
+            } else if constexpr (K == 2) {
+                const Fe y1 = lds_fe_load(y + FS);
+                wide_mac(A.p, y0.v, y1.v);
+            } else {
+                const Fe y1 = lds_fe_load(y + FS), y2 = lds_fe_load(y + 2 * FS);
+                const Fe m = fe_mul(y0, y1, P);
+                wide_mac(A.p, m.v, y2.v);
+            }
+            if constexpr (EXTRA) A.ps = fe_add(A.ps, lds_fe_load(y + K * FS), P);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();   // the row buffer is free for the next pair index
+}
+// this lane's E(t; node) (lane16 = 4t + node) and, PLAIN, its share of the plain S(t) (nodes 0 and 1 hold the two halves)
+template <int K, bool PLAIN>
+ZK_D void hex_close(const HexAcc<PLAIN> &A, Fe &e, Fe &plain, const FieldParams &P) {
+    if constexpr (K == 1) e = A.s;
+    else e = fe_add(redc_wide(A.e, P), A.s, P);
     if constexpr (PLAIN) {
         if constexpr (K == 1) plain = A.ps;
-        else plain = fe_add(redc_wide(A.s[0], P), A.ps, P);
+        else plain = fe_add(redc_wide(A.p, P), A.ps, P);
     } else {
         plain = fe_zero();
     }
 }
-
-// wave sum that keeps the four quad positions apart: every level of fe_wave_sum except the two inside a quad
-ZK_D Fe quad_wave_sum(Fe s, const FieldParams &P) {
+// sum over the four rows of a wave: lanes 0..15 end up with the totals of their (t, node)
+ZK_D Fe hex_rows_sum(Fe s, const FieldParams &P) {
     Fe a, b;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -166,10 +212,7 @@ ZK_D Fe quad_wave_sum(Fe s, const FieldParams &P) {
         a.v[i] = x[0];
         b.v[i] = x[1];
     }
-    s = fe_add(a, b, P);
-    s = fe_add(s, fe_dpp<0x128>(s), P);
-    s = fe_add(s, fe_dpp<0x12C>(s), P);
-    return s;
+    return fe_add(a, b, P);
 }
 
 // S(t) from E(t; .) once the challenge r is known.  r29 = prepared multiplier form of r; inv2 = 1/2 (K == 3).
@@ -190,44 +233,28 @@ ZK_D Fe pipe_eval(const Fe (&e)[K + 1], const Mul29 &r29, const Fe &inv2, const 
     }
 }
 
+ZK_D void dbg_stamp(uint64_t *dbg, int slot) {
+    if (dbg && (threadIdx.x & 63) == 0) dbg[slot] = wall_clock64();
+}
+
 // ---- the transcript block ----------------------------------------------------------------------------------------------
-struct PipeTailArgs {
-    const uint64_t *partials;   // per-block partials of the round being closed: [block][n_in] elements
-    uint32_t nblocks;
-    uint32_t n_in;              // values per block: NS (mode 0; SKIP1 leaves slot 1 unwritten) or NS * NR (mode 1)
-    int mode;                   // 0: plain sums   1: E(t; rho), evaluated at *chal_in
-    const uint64_t *chal_in;    // challenge record of the previous round (mode 1, and SKIP1's derive)
-    uint64_t *chal_out;         // challenge record this round's challenge is published in
-    WordSponge *sponge;
-    uint64_t *out_rp, *out_ch;
-    Fe inv2;
-    TailDerive dv;              // mode 0 after a SKIP1 round kernel
-};
 // Reduce the block partials: value idx (< n_in <= 16) summed over the blocks -> red[idx].  256 threads: thread (idx =
 // tid % 16, slice = tid / 16) adds its share, lanes 16/32 apart combine on the VALU, the four waves through LDS.
 ZK_D void pipe_reduce_partials(const uint64_t *__restrict__ partials, uint32_t nblocks, uint32_t n_in, Fe *red /* LDS, 16 */, Fe (*stage)[16] /* LDS [4][16] */,
                                const FieldParams &P) {
     const uint32_t tid = threadIdx.x, idx = tid & 15, slice = tid >> 4, lane = tid & 63, wave = tid >> 6;
     Fe s = fe_zero();
-    if (idx < n_in)
-        for (uint32_t b = slice; b < nblocks; b += kPipeThreads / 16) s = fe_add(s, fe_load(partials, (uint64_t)b * n_in + idx), P);
-    {
-        Fe a, b;
+    if (idx < n_in) {
+        constexpr uint32_t kStep = kPipeThreads / 16;
+        for (uint32_t b = slice; b < nblocks; b += 8 * kStep) {   // eight independent loads in flight
+            Fe x[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const auto x = __builtin_amdgcn_permlane32_swap(s.v[i], s.v[i], false, false);
-            a.v[i] = x[0];
-            b.v[i] = x[1];
+            for (int u = 0; u < 8; ++u) x[u] = b + u * kStep < nblocks ? fe_load(partials, (uint64_t)(b + u * kStep) * n_in + idx) : fe_zero();
+            const Fe lo = fe_add(fe_add(x[0], x[1], P), fe_add(x[2], x[3], P), P), hi = fe_add(fe_add(x[4], x[5], P), fe_add(x[6], x[7], P), P);
+            s = fe_add(s, fe_add(lo, hi, P), P);
         }
-        s = fe_add(a, b, P);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const auto x = __builtin_amdgcn_permlane16_swap(s.v[i], s.v[i], false, false);
-            a.v[i] = x[0];
-            b.v[i] = x[1];
-        }
-        s = fe_add(a, b, P);
     }
+    s = hex_rows_sum(s, P);
     if (lane < 16) stage[wave][lane] = s;
     __syncthreads();
     if (tid < 16) red[tid] = fe_add(fe_add(stage[0][tid], stage[1][tid], P), fe_add(stage[2][tid], stage[3][tid], P), P);
@@ -244,9 +271,17 @@ ZK_D void pipe_tail_block(const PipeTailArgs &ta, const FieldParams &P) {
     const bool wave0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
     const LaneKeccak L = lane_keccak_init();
     LaneSponge sp = {0, 0};
+    if (wave0) dbg_stamp(ta.dbg, 0);
     if (wave0) sp = lane_sponge_load(ta.sponge, L);   // in flight while the partials are reduced
-    pipe_reduce_partials(ta.partials, ta.nblocks, ta.n_in, red, stage, P);
+    if (ta.nblocks == 1) {   // already reduced (the last work block of the launch before did it): no barrier, no other wave
+        if (!wave0) return;
+        if (lane < 16 && lane < ta.n_in) red[lane] = fe_load(ta.partials, lane);
+    } else {
+        pipe_reduce_partials(ta.partials, ta.nblocks, ta.n_in, red, stage, P);
+    }
     if (wave0) {
+        __builtin_amdgcn_s_setprio(3);
+        dbg_stamp(ta.dbg, 1);
         Fe s = fe_zero();
         if (ta.mode == 1) {
             const Mul29 r29 = load_challenge29(ta.chal_in);
@@ -259,13 +294,10 @@ ZK_D void pipe_tail_block(const PipeTailArgs &ta, const FieldParams &P) {
             s = red[lane < (uint32_t)NS ? lane : 0];
             if (ta.dv.prev_rp) {
                 // S(1) = S_prev(r_prev) - S(0): the round kernel left the t = 1 products out (k_round_kd SKIP1)
-                const Fe r = fe_load(ta.chal_in, 0);
+                const Fe r = fe_load(ta.dv.prev_chal, 0);
                 Fe term = fe_zero();
                 if (lane < (uint32_t)NS) {
-                    Fe wt = ta.dv.w[0];
-#pragma unroll
-                    for (int i = 1; i <= kMaxSkipDegree; ++i)
-                        if (lane == (uint32_t)i) wt = ta.dv.w[i];
+                    const Fe wt = fe_load(ta.dv.w, lane);
                     term = fe_mul(fe_load(ta.dv.prev_rp, lane), wt, P);
                     Fe node = fe_zero();
                     const Fe one = fe_one(P);
@@ -286,97 +318,378 @@ ZK_D void pipe_tail_block(const PipeTailArgs &ta, const FieldParams &P) {
             fin[lane] = s;
             fe_store(ta.out_rp, lane, s);
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): fin[] written by this wave is read back by transcript_step
+        dbg_stamp(ta.dbg, 2);
         Mul29 ch29;
         const Fe ch = transcript_step(sp, L, fin, NS, P, ch29);
+        dbg_stamp(ta.dbg, 3);
         publish_challenge(ta.chal_out, ta.out_ch, ch, ch29, L.lane);
         lane_sponge_store(ta.sponge, sp, L);
+        dbg_stamp(ta.dbg, 4);
     }
 }
 
 // ---- the pipelined round kernel ------------------------------------------------------------------------------------------
-// q = pairs of round s.  Work blocks 0 .. gridDim.x-2, transcript block gridDim.x-1.
+// q = pairs of round s.  Transcript block 0, work blocks 1 .. gridDim.x-1 (16 pair indices per block and pass).
 //   FOLD : fp.in = tables of round s-2 (8q elements), folded at *chal_fold (= r_{s-2}) into fp.out (tables of round s-1, 4q
-//          elements, may alias fp.in: a lane reads and writes only its own positions);
+//          elements, may alias fp.in: a lane reads and writes only positions of its own pair index);
 //   !FOLD: fp.in = tables of round s-1 (4q elements), already materialised.
 //   emit : compute the E_s partials (0: fold only -- the launch that leaves the pipeline).
+// e_partials: slot 0 = the total over the work blocks (written by the block that finishes last), slot 1 + b = block b;
+// each slot [t * (K+1) + node].  done_counter: zero on entry, zero again on exit.
+template <int K, int D, int EXTRA>
+constexpr int pipe_block_threads() {
+    return kPipeThreads;   // one wave per SIMD: a work wave is a latency-bound chain, four of them on a SIMD run 4x slower each
+}
 template <int K, int D, int EXTRA, bool FOLD>
-__global__ __launch_bounds__(kPipeThreads) void k_round_pipe(FactorPtrs fp, uint64_t q, int emit, FieldParams P, const uint64_t *__restrict__ chal_fold,
-                                                             uint64_t *__restrict__ e_partials, PipeTailArgs ta) {
+__global__ __launch_bounds__((pipe_block_threads<K, D, EXTRA>())) void k_round_pipe(FactorPtrs fp, uint64_t q, int emit, FieldParams P,
+                                                                                  const uint64_t *__restrict__ chal_fold,
+                                                                                  uint64_t *__restrict__ e_partials, uint32_t *done_counter,
+                                                                                  PipeTailArgs ta) {
     using S = PipeShape<K, D, EXTRA>;
-    if (blockIdx.x == gridDim.x - 1) {
-        pipe_tail_block<K, D>(ta, P);
+    using C = HexCfg<K, D, EXTRA, false>;
+    constexpr int kThreads = pipe_block_threads<K, D, EXTRA>(), kPipeRows = kThreads / 16, kWaves = kThreads / 64;
+    if (blockIdx.x == 0) {   // dispatched first: the serial transcript step is the launch's critical path
+        if (threadIdx.x < (uint32_t)kPipeThreads) pipe_tail_block<K, D>(ta, P);   // (its barriers: the other waves have left)
         return;
     }
-    __shared__ uint32_t redw[kPipeThreads / 64][4][S::NR][8];
+    __shared__ __attribute__((aligned(16))) Fe rows[kPipeRows][C::ROW_FE];
+    __shared__ Fe redw[kWaves][16];
+    const uint32_t wb = blockIdx.x - 1, nwork = gridDim.x - 1;
     Mul29 r = {};
     if (FOLD) r = load_challenge29(chal_fold);
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l4 = lane & 3;
-    const bool has_factor = l4 < (uint32_t)S::NF;
-    const uint64_t *in = fp.in[0];
-    uint64_t *out = fp.out[0];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lane16 = threadIdx.x & 15, rowi = threadIdx.x >> 4;
+    const uint32_t fa = lane16 >> 2;   // phase-A factor of this lane
+    const uint64_t *src = fp.in[0];
+    uint64_t *dst = fp.out[0];
 #pragma unroll
-    for (int f = 1; f < S::NF; ++f)
-        if (l4 == (uint32_t)f) {
-            in = fp.in[f];
-            out = fp.out[f];
-        }
-    constexpr int NL = FOLD ? 8 : 4;
-    const uint64_t nwork = gridDim.x - 1, stride = nwork * (kPipeThreads / 4);
-    uint64_t j = (uint64_t)blockIdx.x * (kPipeThreads / 4) + (threadIdx.x >> 2);
-    PipeAcc<K, D, EXTRA, false> A;
-    pipe_acc_zero(A);
-    Fe cur[NL];
-#pragma unroll
-    for (int l = 0; l < NL; ++l) cur[l] = fe_zero();
-    if (j < q && has_factor) {
-#pragma unroll
-        for (int l = 0; l < NL; ++l) cur[l] = fe_load(in, j + (uint64_t)l * q);
+    for (int f = 1; f < S::NF; ++f) {   // pointer select by arithmetic masks (see hex_point)
+        const uint64_t m = fa == (uint32_t)f ? ~0ull : 0ull;
+        src = reinterpret_cast<const uint64_t *>((reinterpret_cast<uint64_t>(src) & ~m) | (reinterpret_cast<uint64_t>(fp.in[f]) & m));
+        dst = reinterpret_cast<uint64_t *>((reinterpret_cast<uint64_t>(dst) & ~m) | (reinterpret_cast<uint64_t>(fp.out[f]) & m));
     }
-    while (j < q) {
-        const uint64_t jn = j + stride;
-        Fe a[4];
-        if constexpr (FOLD) {
-#pragma unroll
-            for (int l = 0; l < 4; ++l) a[l] = fe_sub(cur[l], fe_mul29(fe_sub(cur[l], cur[l + 4], P), r, P), P);   // evaluation_form.rs:68
-            if (has_factor) {
-#pragma unroll
-                for (int l = 0; l < 4; ++l) fe_store(out, j + (uint64_t)l * q, a[l]);
-            }
-        } else {
-#pragma unroll
-            for (int l = 0; l < 4; ++l) a[l] = cur[l];
-        }
-        if (has_factor && jn < q) {
-#pragma unroll
-            for (int l = 0; l < NL; ++l) cur[l] = fe_load(in, jn + (uint64_t)l * q);
-        }
-        Fe pe[4], pp[2];
-        pipe_products<K, D, EXTRA, false>(A, a, l4, emit != 0, P, pe, pp);
-        j = jn;
+    uint64_t *wdbg = (wb == 0 && ta.dbg) ? ta.dbg + 8 : nullptr;
+    if (threadIdx.x < 64) dbg_stamp(wdbg, 0);
+    HexAcc<false> A;
+    hex_acc_zero(A);
+    const uint64_t stride = (uint64_t)nwork * kPipeRows;
+    for (uint64_t j0 = (uint64_t)wb * kPipeRows; j0 < q; j0 += stride) {   // j0 is block-uniform
+        const uint64_t j = j0 + rowi;
+        if (emit) hex_step<K, D, EXTRA, FOLD, false, true>(A, src, dst, j, q, j < q, r, P, rows[rowi], lane16);
+        else hex_step<K, D, EXTRA, FOLD, false, false>(A, src, dst, j, q, j < q, r, P, rows[rowi], lane16);
     }
+    if (threadIdx.x < 64) dbg_stamp(wdbg, 1);
     if (!emit) return;
-    Fe e[S::NR], plain;
-    pipe_acc_close<K, D, EXTRA, false>(A, e, plain, P);
+    Fe e, plain;
+    hex_close<K, false>(A, e, plain, P);
+    e = hex_rows_sum(e, P);
+    if (lane < 16) redw[wave][lane] = e;
+    if (threadIdx.x < 64) dbg_stamp(wdbg, 2);
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const uint32_t t = threadIdx.x >> 2, node = threadIdx.x & 3;
+        if (t < (uint32_t)S::NS && node < (uint32_t)S::NR) {
+            Fe tot = redw[0][threadIdx.x];
 #pragma unroll
-    for (int i = 0; i < S::NR; ++i) {
-        const Fe s = quad_wave_sum(e[i], P);
-        if (lane < 4) {
+            for (int w = 1; w < kWaves; ++w) tot = fe_add(tot, redw[w][threadIdx.x], P);
+            fe_store(e_partials, (uint64_t)(wb + 1) * S::NE + t * S::NR + node, tot);   // slot 0 is the total
+        }
+    }
+    if (threadIdx.x < 64) dbg_stamp(wdbg, 3);
+    // The block that finishes last adds the partials up (slot 0), so the NEXT launch's transcript block -- the critical path --
+    // reads NE values instead of reducing nwork * NE.  Release / acquire at agent scope: the other blocks may sit on other XCDs.
+    __shared__ uint32_t is_last;
+    __shared__ Fe lred[16];
+    __shared__ Fe lstage[4][16];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        is_last = atomicAdd(done_counter, 1u) == nwork - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    pipe_reduce_partials(e_partials + S::NE * 4, nwork, S::NE, lred, lstage, P);
+    if (threadIdx.x < 16) {
+        const uint32_t t = threadIdx.x / S::NR, node = threadIdx.x % S::NR;
+        if (threadIdx.x < (uint32_t)S::NE) fe_store(e_partials, t * S::NR + node, lred[threadIdx.x]);
+    }
+    if (threadIdx.x == 0) *done_counter = 0;   // ready for the next launch that uses this buffer
+    if (threadIdx.x < 64) dbg_stamp(wdbg, 4);
+}
+
+// ---- the pipelined finisher: all remaining rounds in ONE 1024-thread workgroup --------------------------------------------
+// Wave 0 runs the transcript steps; waves 1..15 (60 rows) fold the tables in LDS and prepare the next round's E while it
+// does; one barrier per round.  Entry (the tables in fp.in have m_in >= 3 variables):
+//   kFinEntryFresh  : fp.in = tables of round s, nothing pending: a first, unpipelined round computes their plain sums
+//   kFinEntryPending: fp.in = tables of round s-1 with r_{s-1} (*chal_in) pending: the same after folding them into LDS
+//   kFinEntryPipe   : fp.in = tables of round s-1, r_{s-1} pending, E_s partials ready (from k_round_pipe): fully pipelined
+// Rounds are numbered from 0 at the first round this kernel closes (out_rp / out_ch point at that round's slots).
+enum { kFinEntryFresh = 0, kFinEntryPending = 1, kFinEntryPipe = 2 };
+constexpr int kFinWorkWaves = kFinishPipeThreads / 64 - 1;
+constexpr int kFinRows = kFinWorkWaves * 4;
+constexpr int kFinStageBytes = 24 * 1024;   // exchange buffers of the work rows
+// The finisher takes over when the tables it folds into LDS have at most 2^8 elements: its first prepared round then has
+// 2^6 pair indices = two passes of the work rows, about one transcript step; bigger rounds are faster as k_round_pipe
+// launches spread over many CUs.
+constexpr int finish_pipe_vars(int nf) { return nf <= 4 ? 7 : 7; }
+
+struct FinLds {   // carved from the dynamic region (32-byte aligned offsets)
+    uint64_t *tab[4];
+    Fe *stage;                       // kFinStageBytes
+    Fe (*ew)[kFinWorkWaves][16];     // [parity][wave][4t + node]
+    Fe (*pw)[16];                    // [wave][4t + node] plain sums (entry rounds)
+    Fe (*st16)[16];                  // [16 waves][16]
+    Fe *red;                         // [16]
+    Fe *fin;                         // [4]
+    Mul29 *r29;                      // [2] by round parity
+    ZK_D uint32_t *red_u32() const { return reinterpret_cast<uint32_t *>(red); }
+};
+constexpr size_t kFinMiscBytes = kFinStageBytes + sizeof(Fe) * (2 * kFinWorkWaves * 16 + kFinWorkWaves * 16 + 16 * 16 + 16 + 4) + 2 * sizeof(Mul29) + 64;
+
+// One pass set of the work rows over the pair indices j < q of the NEXT round.  src: tables with 8q (FOLD: folded at r into
+// the 4q-element tables dst first) or 4q elements per factor.
+template <int K, int D, int EXTRA, bool FOLD, bool PLAIN>
+ZK_D uint32_t fin_rows(uint32_t n_work_waves) {
+    using C = HexCfg<K, D, EXTRA, PLAIN>;
+    constexpr uint32_t kBuf = kFinStageBytes / C::ROW_BYTES;   // rows with an exchange buffer
+    return n_work_waves * 4 < kBuf ? n_work_waves * 4 : kBuf;
+}
+template <int K, int D, int EXTRA, bool FOLD, bool PLAIN>
+ZK_D void fin_work(const uint64_t *src, uint64_t *dst, uint32_t q, const Mul29 &r, const FieldParams &P, Fe *stage, Fe (*ew)[16], Fe (*pw)[16],
+                   uint32_t wl /* work lane */, uint32_t n_work_waves) {
+    using C = HexCfg<K, D, EXTRA, PLAIN>;
+    const uint32_t kRows = fin_rows<K, D, EXTRA, FOLD, PLAIN>(n_work_waves);
+    const uint32_t lane = wl & 63, wwave = wl >> 6, lane16 = wl & 15, rowi = wl >> 4;
+    if (__builtin_amdgcn_readfirstlane(wwave * 4) >= (q < kRows ? q : kRows)) return;   // no row of this wave ever works: its slots are not read
+    const bool has_buf = rowi < kRows;
+    Fe *row = stage + (size_t)(has_buf ? rowi : 0) * C::ROW_FE;
+    HexAcc<PLAIN> A;
+    hex_acc_zero(A);
+    for (uint32_t j0 = 0; j0 < q; j0 += kRows) {
+        const uint32_t j = j0 + rowi;
+        if (has_buf) hex_step<K, D, EXTRA, FOLD, PLAIN, true>(A, src, dst, j, q, j < q, r, P, row, lane16);
+    }
+    Fe e, plain;
+    hex_close<K, PLAIN>(A, e, plain, P);
+    e = hex_rows_sum(e, P);
+    if (lane < 16) ew[wwave][lane] = e;
+    if constexpr (PLAIN) {
+        plain = hex_rows_sum(plain, P);
+        if (lane < 16) pw[wwave][lane] = plain;
+    }
+}
+template <int K, int D, int EXTRA, bool PLAIN>
+ZK_D uint32_t fin_active_waves(uint32_t q, uint32_t n_work_waves) {
+    const uint32_t kRows = fin_rows<K, D, EXTRA, true, PLAIN>(n_work_waves);
+    const uint32_t rows = q < kRows ? q : kRows;
+    return (rows + 3) / 4;
+}
+// wave 0: total over the active work waves of ew[.][4t + node] -> e[node] on lane t (< NS); through LDS `red`
+template <int K, int D>
+ZK_D void fin_gather_e(Fe (*ew)[16], uint32_t nactive, Fe *red, Fe (&e)[K + 1], uint32_t lane, const FieldParams &P) {
+    constexpr int NS = D + 1, NR = K + 1;
+    const uint32_t idx = lane & 15, g = lane >> 4;
+    Fe s = fe_zero();
+    for (uint32_t w = g; w < nactive; w += 4) s = fe_add(s, ew[w][idx], P);
+    s = hex_rows_sum(s, P);
+    if (lane < 16) red[lane] = s;
+    const uint32_t t = lane < (uint32_t)NS ? lane : 0;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) redw[wave][lane][i][w] = s.v[w];
+    for (int i = 0; i < NR; ++i) e[i] = red[4 * t + i];
+}
+
+template <int K, int D, int EXTRA>
+__global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs fp, uint32_t m_in, int entry, const uint64_t *__restrict__ e_partials,
+                                                                    uint32_t e_blocks, FieldParams P, Fe inv2, const uint64_t *__restrict__ chal_in,
+                                                                    uint64_t *__restrict__ chal_last, WordSponge *gsponge, uint64_t *out_rp,
+                                                                    uint64_t *out_ch, uint64_t *out_final, uint64_t *dbg) {
+    constexpr int NF = K + EXTRA, NS = D + 1, NR = K + 1, NE = NS * NR;
+    extern __shared__ __attribute__((aligned(32))) unsigned char fp_smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool wave0 = __builtin_amdgcn_readfirstlane(wave) == 0;
+    const uint32_t cap = 1u << (m_in - 1);   // elements per factor ever held in LDS
+    FinLds S;
+    unsigned char *carve = fp_smem;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        S.tab[f] = reinterpret_cast<uint64_t *>(carve);
+        carve += (size_t)cap * 32;
+    }
+    S.stage = reinterpret_cast<Fe *>(carve);
+    carve += kFinStageBytes;
+    S.ew = reinterpret_cast<Fe(*)[kFinWorkWaves][16]>(carve);
+    carve += sizeof(Fe) * 2 * kFinWorkWaves * 16;
+    S.pw = reinterpret_cast<Fe(*)[16]>(carve);
+    carve += sizeof(Fe) * kFinWorkWaves * 16;
+    S.st16 = reinterpret_cast<Fe(*)[16]>(carve);
+    carve += sizeof(Fe) * 16 * 16;
+    S.red = reinterpret_cast<Fe *>(carve);
+    carve += sizeof(Fe) * 16;
+    S.fin = reinterpret_cast<Fe *>(carve);
+    carve += sizeof(Fe) * 4;
+    S.r29 = reinterpret_cast<Mul29 *>(carve);
+
+    const LaneKeccak L = lane_keccak_init();
+    LaneSponge sp = {0, 0};
+    if (wave0) sp = lane_sponge_load(gsponge, L);
+    // The transcript wave must have its SIMD to itself: a wave issues at most one VALU instruction per 4 cycles, and four
+    // busy waves on one SIMD get a quarter of that each (measured: the transcript step took 6.8 us next to three work waves,
+    // 3.7 us alone).  Waves that landed on wave 0's SIMD (HW_ID.SIMD_ID) stay idle; the others take work-wave numbers.
+    {
+        const uint32_t simd = __builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));   // hwreg(HW_REG_HW_ID, 4, 2)
+        if (lane == 0) S.red_u32()[wave] = simd;
+    }
+    __syncthreads();
+    uint32_t my_work_wave = 0xffffffffu, n_work_waves = 0;   // dense numbering of the waves that work
+    {
+        const uint32_t simd0 = S.red_u32()[0];
+        for (uint32_t w = 1; w < (uint32_t)kFinishPipeThreads / 64; ++w) {
+            if (S.red_u32()[w] == simd0) continue;
+            if (w == wave) my_work_wave = n_work_waves;
+            ++n_work_waves;
         }
     }
     __syncthreads();
-    if (threadIdx.x < (uint32_t)S::NE) {
-        const uint32_t t = threadIdx.x / S::NR, i = threadIdx.x % S::NR;
-        Fe tot = fe_zero();
-        for (int wv = 0; wv < kPipeThreads / 64; ++wv) {
-            Fe o;
+    const bool worker = my_work_wave != 0xffffffffu;
+    const uint32_t wl = my_work_wave * 64 + lane;   // work lane
+    // this lane's phase-A factor: its global source and its LDS table
+    const uint32_t fa = (wl & 15) >> 2;
+    const uint64_t *gsrc = fp.in[0];
+    uint64_t *ltab = S.tab[0];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) o.v[w] = redw[wv][t][i][w];
-            tot = fe_add(tot, o, P);
+    for (int f = 1; f < NF; ++f) {
+        const uint64_t msk = fa == (uint32_t)f ? ~0ull : 0ull;
+        gsrc = reinterpret_cast<const uint64_t *>((reinterpret_cast<uint64_t>(gsrc) & ~msk) | (reinterpret_cast<uint64_t>(fp.in[f]) & msk));
+        ltab = reinterpret_cast<uint64_t *>((reinterpret_cast<uint64_t>(ltab) & ~msk) | (reinterpret_cast<uint64_t>(S.tab[f]) & msk));
+    }
+    uint32_t m;            // variables of the table the NEXT work pass reads (the "previous" table of the uniform loop)
+    bool src_global;       // ... and whether it is still in global memory
+    uint32_t round = 0;    // rounds closed so far
+    int par = 0;           // parity of the ew buffer that holds the E of round `round`
+    uint32_t nact = 0;     // work waves that wrote it
+    Mul29 rprev = {};
+    if (entry != kFinEntryFresh) rprev = load_challenge29(chal_in);
+
+    // ---- entry ----
+    if (entry == kFinEntryPipe) {
+        // E of round 0 (of this kernel) comes from the pipelined launch before: reduce its block partials with everybody
+        {
+            const uint32_t idx = tid & 15, slice = tid >> 4;
+            const uint32_t t = idx >> 2, node = idx & 3;
+            Fe s = fe_zero();
+            if (t < (uint32_t)NS && node < (uint32_t)NR)
+                for (uint32_t b = slice; b < e_blocks; b += kFinishPipeThreads / 16) s = fe_add(s, fe_load(e_partials, (uint64_t)b * NE + t * NR + node), P);
+            s = hex_rows_sum(s, P);
+            if (lane < 16) S.st16[wave][lane] = s;
         }
-        fe_store(e_partials, (uint64_t)blockIdx.x * S::NE + threadIdx.x, tot);
+        __syncthreads();
+        if (tid < 16) {
+            Fe tot = fe_zero();
+            for (int w = 0; w < kFinishPipeThreads / 64; ++w) tot = fe_add(tot, S.st16[w][tid], P);
+            S.ew[0][0][tid] = tot;   // as if ONE work wave had produced it
+        }
+        __syncthreads();
+        par = 0;
+        nact = 1;
+        m = m_in;
+        src_global = true;
+    } else {
+        // unpipelined first round: plain sums of the round's own table (+ E of the next round)
+        const uint32_t q = 1u << (m_in - (entry == kFinEntryPending ? 3 : 2));
+        if (worker) {
+            if (entry == kFinEntryPending) fin_work<K, D, EXTRA, true, true>(gsrc, ltab, q, rprev, P, S.stage, S.ew[1], S.pw, wl, n_work_waves);
+            else fin_work<K, D, EXTRA, false, true>(gsrc, ltab, q, rprev, P, S.stage, S.ew[1], S.pw, wl, n_work_waves);
+        }
+        __syncthreads();
+        const uint32_t na = fin_active_waves<K, D, EXTRA, true>(q, n_work_waves);
+        if (wave0) {
+            // plain S(t) = (node 0 part) + (node 1 part), summed over the active waves
+            Fe s = fe_zero();
+            if (lane < (uint32_t)NS)
+                for (uint32_t w = 0; w < na; ++w) s = fe_add(s, fe_add(S.pw[w][4 * lane], S.pw[w][4 * lane + 1], P), P);
+            if (lane < (uint32_t)NS) {
+                S.fin[lane] = s;
+                fe_store(out_rp, lane, s);
+            }
+            Mul29 ch29;
+            const Fe ch = transcript_step(sp, L, S.fin, NS, P, ch29);
+            if (lane == 0) {
+                fe_store(out_ch, 0, ch);
+                S.r29[0] = ch29;
+            }
+        }
+        __syncthreads();
+        round = 1;
+        par = 1;
+        nact = na;
+        if (entry == kFinEntryPending) {
+            m = m_in - 1;
+            src_global = false;
+        } else {
+            m = m_in;
+            src_global = true;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) rprev.l[i] = __builtin_amdgcn_readfirstlane(S.r29[0].l[i]);
+    }
+
+    // ---- uniform loop: close round `round` (its table has m - 1 variables) while the next one is prepared ----
+    // rprev = challenge of round - 1 (folds the m-variable table into this round's)
+    if (wave0) __builtin_amdgcn_s_setprio(3);   // the transcript wave is the critical path: first pick of issue slots / LDS
+    while (m >= 2) {
+        uint64_t *rdbg = dbg ? dbg + 16 * round : nullptr;
+        if (wave0) {
+            dbg_stamp(rdbg, 0);
+            Fe e[NR];
+            fin_gather_e<K, D>(S.ew[par], nact, S.red, e, lane, P);
+            dbg_stamp(rdbg, 1);
+            const Fe s = pipe_eval<K>(e, rprev, inv2, P);
+            dbg_stamp(rdbg, 2);
+            if (lane < (uint32_t)NS) {
+                S.fin[lane] = s;
+                fe_store(out_rp, (uint64_t)round * NS + lane, s);
+            }
+            Mul29 ch29;
+            const Fe ch = transcript_step(sp, L, S.fin, NS, P, ch29);
+            if (lane == 0) {
+                fe_store(out_ch, round, ch);
+                S.r29[round & 1] = ch29;
+            }
+            if (m == 2) publish_challenge(chal_last, nullptr, ch, ch29, (int)lane);
+            dbg_stamp(rdbg, 3);
+        } else if (m >= 3 && worker) {
+            if (my_work_wave == 0) dbg_stamp(rdbg, 8);
+            const uint32_t q = 1u << (m - 3);
+            if (src_global) fin_work<K, D, EXTRA, true, false>(gsrc, ltab, q, rprev, P, S.stage, S.ew[par ^ 1], S.pw, wl, n_work_waves);
+            else fin_work<K, D, EXTRA, true, false>(ltab, ltab, q, rprev, P, S.stage, S.ew[par ^ 1], S.pw, wl, n_work_waves);
+            if (my_work_wave == 0) dbg_stamp(rdbg, 9);
+        }
+        __syncthreads();
+        if (wave0) dbg_stamp(rdbg, 4);
+        if (m >= 3) nact = fin_active_waves<K, D, EXTRA, false>(1u << (m - 3), n_work_waves);
+        if (m > 2 || out_final) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) rprev.l[i] = __builtin_amdgcn_readfirstlane(S.r29[round & 1].l[i]);
+        }
+        par ^= 1;
+        src_global = false;
+        ++round;
+        --m;
+    }
+    if (wave0) lane_sponge_store(gsponge, sp, L);
+    // out_final: the factors at the whole challenge point.  LDS holds the 4-element tables of the second-to-last round; they
+    // are folded at the last two challenges (rprev = the last one; the one before sits in the other slot)
+    if (out_final && tid < (uint32_t)NF) {
+        Mul29 r2;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r2.l[i] = S.r29[round & 1].l[i];   // round - 2 has the parity of round
+        const uint64_t *T = S.tab[0];
+#pragma unroll
+        for (int f = 1; f < NF; ++f)
+            if (tid == (uint32_t)f) T = S.tab[f];
+        const Fe x0 = fe_load(T, 0), x1 = fe_load(T, 1), x2 = fe_load(T, 2), x3 = fe_load(T, 3);
+        const Fe lo = fe_sub(x0, fe_mul29(fe_sub(x0, x2, P), r2, P), P), hi = fe_sub(x1, fe_mul29(fe_sub(x1, x3, P), r2, P), P);
+        fe_store(out_final, tid, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), rprev, P), P));
     }
 }
 
