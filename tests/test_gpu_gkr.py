@@ -251,3 +251,38 @@ def test_gkr_heavy_fanout_width_2p18():
     dt = time.perf_counter() - t0
     assert gkr.gkr_verify(circ, x, out, bytes(32), proof)
     assert dt < 0.05, f"heavy fan-out proof took {dt * 1e3:.1f} ms"
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_gkr_statement_is_bound_before_the_output_point(field):
+    """the output point used to depend on the caller's seed alone, so outputs + delta with delta~(g) = 0 verified
+    with the honest proof.  Circuit, inputs and outputs are now digested into the transcript first: the forged outputs, a
+    flipped gate and a rewired gate must all be rejected by zk_gkr_verify (and the digests match the model's: the proofs of
+    test_gkr_vs_model are bit-exact against gkr_ref, whose transcript starts with them)."""
+    c = ctx_for(field)
+    p = zk_amd.modulus(field)
+    rng = random.Random(99 + field)
+    logs = [2, 3, 2]
+    layers = rand_circuit(rng, logs)
+    inputs = [rng.randrange(p) for _ in range(1 << logs[-1])]
+    seed = bytes(32)
+    circ = upload_circuit(c, layers)
+    x = MLE.new(c, logs[-1], F(field, inputs))
+    out, proof = gkr.gkr_prove(circ, x, seed)
+    assert gkr.gkr_verify(circ, x, out, seed, proof)
+    # delta orthogonal to eq(g_old, .), g_old = the point the seed alone would have given
+    from oracle import pyref
+    tr = pyref.Transcript()
+    tr.append(seed)
+    g_old = [tr.sample_field_element(field) for _ in range(logs[0])]
+    eq = gkr_ref.eq_table(field, g_old)
+    delta = [eq[1], (-eq[0]) % p, 0, 0]
+    forged = [(o + d) % p for o, d in zip(I(field, out.evaluation_slice()), delta)]
+    assert not gkr.gkr_verify(circ, x, MLE.new(c, logs[0], F(field, forged)), seed, proof)
+    lo, li, op, left, right = layers[1]
+    flipped = list(layers)
+    flipped[1] = (lo, li, [1 - op[0]] + list(op[1:]), left, right)
+    assert not gkr.gkr_verify(upload_circuit(c, flipped), x, out, seed, proof)
+    rewired = list(layers)
+    rewired[1] = (lo, li, op, [(left[0] + 1) % (1 << li)] + list(left[1:]), right)
+    assert not gkr.gkr_verify(upload_circuit(c, rewired), x, out, seed, proof)

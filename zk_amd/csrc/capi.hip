@@ -1468,7 +1468,7 @@ static bool has_duplicate_handles(zk_mle *const *f, uint64_t k) {
 // factor values, for a caller that chains further device work on them without a host round trip (the GKR driver).
 static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpec &ts, uint32_t D, const uint64_t sum[4],
                           int32_t absorb_table, int32_t consume, uint64_t *out_rp, uint64_t *out_ch, uint64_t *out_final,
-                          uint64_t *d_keep_ch = nullptr, uint64_t *d_keep_final = nullptr) {
+                          uint64_t *d_keep_ch = nullptr, uint64_t *d_keep_final = nullptr, const Sponge *init = nullptr) {
     if (!sum) return ZK_ERR_BAD_ARG;
     ZKCHK(product_args(c, (const zk_mle *const *)f, k));
     if (f[0]->n_vars && (!out_rp || !out_ch)) return ZK_ERR_BAD_ARG;
@@ -1476,7 +1476,8 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
     const FieldParams &P = c->fi->P;
     const uint64_t n = f[0]->n_vars;
     Sponge sp;
-    sp.init();                                                           // Transcript::new (prover.rs:16,28)
+    if (init) sp = *init;                                                // a driver chaining its sumchecks onto its own transcript (GKR)
+    else sp.init();                                                      // Transcript::new (prover.rs:16,28)
     if (absorb_table) ZKCHK(absorb_tables(c, sp, f, k));                 // prover.rs:17
     absorb_elements(sp, sum, 1, P);                                      // prover.rs:42
     if (n == 0) {                                                        // no rounds (prover.rs:44)

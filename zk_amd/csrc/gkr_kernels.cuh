@@ -287,4 +287,77 @@ __global__ __launch_bounds__(kBlock) void k_dft_across(const uint64_t *__restric
     }
 }
 
+// ---- statement digest: Keccak-256 tree hash (the driver binds circuit, inputs and outputs before the output point is drawn) ----
+// digest(data) = 128-byte leaves hashed one per thread, then 4-ary nodes Keccak256(child digests) level by level
+// (oracle/gkr_ref.py: tree_digest).  One sponge over 2^20 elements would be serial and cost more than the whole proof; a
+// message of <= 128 bytes is ONE permutation (rate 136), so a level is one permutation per thread.
+ZK_D void tree_keccak_finish(uint64_t (&s)[25], uint32_t len_bytes, uint64_t *__restrict__ out) {
+    s[len_bytes >> 3] ^= 0x01ull << (8 * (len_bytes & 7));   // pad10*1 with Keccak's 0x01 domain byte
+    s[16] ^= 0x8000000000000000ull;
+    keccak_f1600(s);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = s[i];
+}
+// leaf i = the to_bytes image (32-byte big-endian canonical integers, evaluation_form.rs:97-103) of elements [4i, 4i+4)
+__global__ __launch_bounds__(kBlock) void k_tree_leaves_table(const uint64_t *__restrict__ table, uint64_t n_elems, uint64_t n_leaves,
+                                                              uint64_t *__restrict__ out, FieldParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_leaves; i += stride) {
+        uint64_t s[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) s[k] = 0;
+        uint32_t len = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (4 * i + e < n_elems) {
+                const Fe c = fe_to_canonical(fe_load(table, 4 * i + e), P);
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    s[4 * e + w] = WordSponge::bswap64((uint64_t)c.v[2 * (3 - w)] | ((uint64_t)c.v[2 * (3 - w) + 1] << 32));
+                len += 32;
+            }
+        }
+        tree_keccak_finish(s, len, out + 4 * i);
+    }
+}
+// leaf i = bytes [128 i, min(128 i + 128, nbytes)) of a raw device array (gate lists)
+__global__ __launch_bounds__(kBlock) void k_tree_leaves_bytes(const uint8_t *__restrict__ data, uint64_t nbytes, uint64_t n_leaves,
+                                                              uint64_t *__restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_leaves; i += stride) {
+        uint64_t s[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) s[k] = 0;
+        const uint64_t base = 128 * i;
+        const uint32_t len = (uint32_t)(nbytes - base < 128 ? nbytes - base : 128);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            uint64_t x = 0;
+            for (int b = 0; b < 8; ++b)
+                if ((uint32_t)(8 * w + b) < len) x |= (uint64_t)data[base + 8 * w + b] << (8 * b);
+            s[w] = x;
+        }
+        tree_keccak_finish(s, len, out + 4 * i);
+    }
+}
+// node j = Keccak256(digests [4j, min(4j + 4, n_in)) concatenated)
+__global__ __launch_bounds__(kBlock) void k_tree_level(const uint64_t *__restrict__ in, uint64_t n_in, uint64_t n_out, uint64_t *__restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n_out; j += stride) {
+        uint64_t s[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) s[k] = 0;
+        uint32_t len = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (4 * j + c < n_in) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) s[4 * c + w] = in[4 * (4 * j + c) + w];
+                len += 32;
+            }
+        }
+        tree_keccak_finish(s, len, out + 4 * j);
+    }
+}
+
 }  // namespace zk

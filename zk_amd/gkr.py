@@ -95,7 +95,7 @@ class Circuit:
         return MultiLinearPolynomial(self.ctx, h)
 
     def free(self):
-        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None) and lib is not None:   # (lib is None at interpreter exit)
             lib.zk_circuit_free(self._h)
         self._h = None
 
