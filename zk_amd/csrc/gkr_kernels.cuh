@@ -13,6 +13,7 @@
 // entries carry the gate's output index, other input and op: no atomics on 256-bit values, one thread per row.
 #pragma once
 #include "common.cuh"
+#include "transcript.cuh"
 
 namespace zk {
 
@@ -358,6 +359,20 @@ __global__ __launch_bounds__(kBlock) void k_tree_level(const uint64_t *__restric
         }
         tree_keccak_finish(s, len, out + 4 * j);
     }
+}
+// The same node function with ONE WAVE per node (lane-parallel Keccak-f[1600], transcript.cuh): a permutation takes ~3 us on a
+// wave against ~17 us for a single lane's 64-bit state, so the small upper levels of the tree -- pure latency -- go this way.
+__global__ __launch_bounds__(64) void k_tree_level_wave(const uint64_t *__restrict__ in, uint64_t n_in, uint64_t *__restrict__ out) {
+    const uint64_t j = blockIdx.x;
+    const LaneKeccak L = lane_keccak_init();
+    const uint64_t rem = n_in - 4 * j;
+    const uint32_t nwords = 4 * (uint32_t)(rem < 4 ? rem : 4);   // message words (8 bytes each)
+    uint64_t a = 0;
+    if (L.index >= 0 && (uint32_t)L.index < nwords) a = in[16 * j + (uint32_t)L.index];
+    if ((uint32_t)L.index == nwords) a ^= 0x01ull;                 // pad10*1, Keccak domain byte
+    if (L.index == 16) a ^= 0x8000000000000000ull;
+    a = lane_keccak_f1600(a, L);
+    if (L.index >= 0 && L.index < 4) out[4 * j + (uint32_t)L.index] = a;
 }
 
 }  // namespace zk
