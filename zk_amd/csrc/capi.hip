@@ -2128,7 +2128,9 @@ extern "C" int32_t zk_bench_fold_samples(zk_ctx *c, const zk_mle *t, const uint6
 }
 extern "C" int32_t zk_bench_ntt(zk_ctx *c, const zk_mle *in, int32_t inverse, zk_mle *out, int32_t reps, double *out_ms) {
     if (!c || !in || !out || !out_ms || reps <= 0) return ZK_ERR_BAD_ARG;
-    ZKCHK(zk_ntt(c, in, inverse, out));   // builds the twiddle tables / warms up
+    // builds the twiddle tables, then as many untimed transforms as timed ones: the passes are ALU-bound and follow the shader
+    // clock, which keeps climbing for ~20 ms after idle (r02 kernel trace: 986 -> 720 us for the same kernel over 12 transforms)
+    for (int i = 0; i <= reps; ++i) ZKCHK(zk_ntt(c, in, inverse, out));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     for (int i = 0; i < reps; ++i) ZKCHK(zk_ntt(c, in, inverse, out));
     HIPCHK(hipEventRecord(c->ev1, c->stream));

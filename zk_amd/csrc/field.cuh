@@ -367,7 +367,10 @@ ZK_HD Mul29 mul29_prepare(const Fe &c, const FieldParams &P) {
     split29(t.v, m.l);
     return m;
 }
-ZK_HD Fe fe_mul29(const Fe &a, const Mul29 &c, const FieldParams &P) {
+// LAZY = true leaves out the final conditional subtraction: the result is in [0, 2p) for ANY 256-bit a (a*c*2^-261 + p < 2p
+// since c < p < 2^255 makes the first term < 2^250) -- the NTT keeps its values in [0, 2p) inside a transform and reduces once.
+template <bool LAZY = false>
+ZK_HD Fe fe_mul29_t(const Fe &a, const Mul29 &c, const FieldParams &P) {
     constexpr uint32_t M = (1u << 29) - 1;
     uint32_t x[9], m[9], r[9];
     split29(a.v, x);
@@ -402,12 +405,14 @@ ZK_HD Fe fe_mul29(const Fe &a, const Mul29 &c, const FieldParams &P) {
         if (29 - sh + 29 < 32 && i + 2 < 9) v |= r[i + 2] << (58 - sh);
         s.v[w] = v;
     }
+    if constexpr (LAZY) return s;
     Fe d, o;
     const uint32_t borrow = sub8(d.v, s.v, P.p);
 #pragma unroll
     for (int i = 0; i < 8; ++i) o.v[i] = borrow ? s.v[i] : d.v[i];
     return o;
 }
+ZK_HD Fe fe_mul29(const Fe &a, const Mul29 &c, const FieldParams &P) { return fe_mul29_t<false>(a, c, P); }
 
 // ---- 32-byte element I/O (two 16-byte accesses: global_load_dwordx4 / global_store_dwordx4) ---------------
 #if defined(__HIPCC__)

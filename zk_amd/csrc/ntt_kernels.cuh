@@ -84,6 +84,49 @@ ZK_D void lds_put(unsigned char *lo_plane, unsigned char *hi_plane, uint32_t row
     *reinterpret_cast<uint4 *>(hi_plane + lds_off(row, col)) = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
 }
 
+// ---- lazy arithmetic inside a transform ------------------------------------------------------------------------------------
+// Values stay in [0, 2p) from the load of the first pass to the store of the last one (2p < 2^256 for every supported field):
+// add / sub reduce modulo 2p (same instruction count as modulo p), the multiplier skips its final conditional subtraction
+// (fe_mul29_t<true>: 16 instructions per butterfly), and the last pass subtracts p once.  Same values modulo p, so the canonical
+// outputs are bit-identical.
+struct Mod2p {
+    uint32_t p[8];
+};
+ZK_D Mod2p mod2p_of(const FieldParams &P) {
+    Mod2p m;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        m.p[i] = (P.p[i] << 1) | c;
+        c = P.p[i] >> 31;
+    }
+    return m;
+}
+ZK_D Fe fe_add2(const Fe &a, const Fe &b, const Mod2p &M) {
+    Fe s, d, r;
+    const uint32_t carry = add8(s.v, a.v, b.v);
+    const uint32_t borrow = sub8(d.v, s.v, M.p);
+    const bool use_d = carry | (borrow ^ 1u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = use_d ? d.v[i] : s.v[i];
+    return r;
+}
+ZK_D Fe fe_sub2(const Fe &a, const Fe &b, const Mod2p &M) {
+    Fe d, e, r;
+    const uint32_t borrow = sub8(d.v, a.v, b.v);
+    add8(e.v, d.v, M.p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = borrow ? e.v[i] : d.v[i];
+    return r;
+}
+ZK_D Fe fe_canon2(const Fe &a, const FieldParams &P) {   // [0, 2p) -> [0, p)
+    Fe d, r;
+    const uint32_t borrow = sub8(d.v, a.v, P.p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = borrow ? a.v[i] : d.v[i];
+    return r;
+}
+
 // ---- stage groups -----------------------------------------------------------------------------------------------------
 // The l radix-2 DIF stages of a tile are run in groups of up to 3 stages: a thread holds the 2^g rows (one column) that
 // interact inside the group in REGISTERS and does the g stages there; tiles cross LDS only between groups (l = 8: groups
@@ -100,26 +143,26 @@ struct NttGroups {   // group sizes from the top stage down
 // compile-time recursion over (stage within the group SU, butterfly B): every x[] index is a constant, so the group
 // stays in registers (a runtime-indexed array would go to scratch)
 template <int L, int S_LO, int G, int SU, int B>
-ZK_D void ntt_bfly(Fe (&x)[1 << G], uint32_t post, const uint32_t *tws, const FieldParams &P) {
+ZK_D void ntt_bfly(Fe (&x)[1 << G], uint32_t post, const uint32_t *tws, const FieldParams &P, const Mod2p &M2) {
     constexpr uint32_t hu = 1u << SU;
     constexpr uint32_t ua = (uint32_t)((B >> SU) << (SU + 1)) | (B & (hu - 1)), ub = ua + hu;
     constexpr int s = S_LO + SU;             // global stage
     const Fe a0 = x[ua], a1 = x[ub];
-    Fe d = fe_sub(a0, a1, P);
+    Fe d = fe_sub2(a0, a1, M2);
     // unit twiddles are skipped when known at compile time: the s = 0 stage, and j = 0 butterflies of the last group
     if constexpr (s > 0 && !(S_LO == 0 && (ua & (hu - 1)) == 0)) {
         const uint32_t j = ((ua & (hu - 1)) << S_LO) | post;              // r mod 2^s
-        d = fe_mul29(d, load_mul29(tws + ((size_t)j << (L - 1 - s)) * kTw29Words), P);
+        d = fe_mul29_t<true>(d, load_mul29(tws + ((size_t)j << (L - 1 - s)) * kTw29Words), P);
     }
-    x[ua] = fe_add(a0, a1, P);
+    x[ua] = fe_add2(a0, a1, M2);
     x[ub] = d;
-    if constexpr (B + 1 < (1 << (G - 1))) ntt_bfly<L, S_LO, G, SU, B + 1>(x, post, tws, P);
-    else if constexpr (SU > 0) ntt_bfly<L, S_LO, G, SU - 1, 0>(x, post, tws, P);
+    if constexpr (B + 1 < (1 << (G - 1))) ntt_bfly<L, S_LO, G, SU, B + 1>(x, post, tws, P, M2);
+    else if constexpr (SU > 0) ntt_bfly<L, S_LO, G, SU - 1, 0>(x, post, tws, P, M2);
 }
 template <int L, int S_HI, int S_LO>
-ZK_D void ntt_group_stages(Fe (&x)[1 << (S_HI - S_LO + 1)], uint32_t post, const uint32_t *tws, const FieldParams &P) {
+ZK_D void ntt_group_stages(Fe (&x)[1 << (S_HI - S_LO + 1)], uint32_t post, const uint32_t *tws, const FieldParams &P, const Mod2p &M2) {
     constexpr int G = S_HI - S_LO + 1;
-    ntt_bfly<L, S_LO, G, G - 1, 0>(x, post, tws, P);
+    ntt_bfly<L, S_LO, G, G - 1, 0>(x, post, tws, P, M2);
 }
 
 // One pass over one tile.  LAST = false: pass p < P (strided axis, inter-pass twiddle, same addresses in and out);
@@ -172,6 +215,7 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
         out_stride_a = 1ull << lo_sum;
     }
     const uint64_t *w_full = LAST ? nullptr : pl.w_full[pass];
+    const Mod2p M2 = mod2p_of(P);
     __syncthreads();   // tws ready
 
     // ---- group 0: stages l-1 .. l-G0, rows (u << (l-G0)) | post, straight from HBM ----
@@ -194,7 +238,7 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
                 const uint32_t a = ((uint32_t)u << S_LO) | post;
                 x[u] = LAST ? fe_load(in, base_in + ((uint64_t)t << t_shift) + a) : fe_load(in, base_in + ((uint64_t)a << log_inner) + t);
             }
-            ntt_group_stages<L, L - 1, S_LO>(x, post, tws, P);
+            ntt_group_stages<L, L - 1, S_LO>(x, post, tws, P, M2);
 #pragma unroll
             for (int u = 0; u < (1 << G0); ++u) lds_put(lo_plane, hi_plane, ((uint32_t)u << S_LO) | post, t, x[u]);
         }
@@ -212,11 +256,12 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
                 } else {
                     tw = ntt_twiddle(pl, ((tw_i0 + t) * k) << lo_sum, P);
                 }
-                v = fe_mul29(v, tw, P);
+                v = fe_mul29_t<true>(v, tw, P);   // stays in [0, 2p): the next pass is lazy too
             }
             fe_store(out, base_out + ((uint64_t)k << log_inner) + t, v);
         } else {
-            if (do_scale) v = fe_mul29(v, scale, P);
+            if (do_scale) v = fe_mul29(v, scale, P);   // (reduces fully)
+            else v = fe_canon2(v, P);                  // the one reduction [0, 2p) -> [0, p) of the transform
             fe_store(out, base_out + t + (uint64_t)k * out_stride_a, v);
         }
     };
@@ -230,7 +275,7 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
             Fe x[1 << G1];
 #pragma unroll
             for (int u = 0; u < (1 << G1); ++u) x[u] = lds_get(lo_plane, hi_plane, (pre << G1) | u, t);
-            ntt_group_stages<L, S_HI, 0>(x, 0, tws, P);
+            ntt_group_stages<L, S_HI, 0>(x, 0, tws, P, M2);
 #pragma unroll
             for (int u = 0; u < (1 << G1); ++u) store_out((pre << G1) | u, t, x[u]);
         }
@@ -243,7 +288,7 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
             Fe x[1 << G1];
 #pragma unroll
             for (int u = 0; u < (1 << G1); ++u) x[u] = lds_get(lo_plane, hi_plane, (pre << (S_HI1 + 1)) | ((uint32_t)u << S_LO1) | post, t);
-            ntt_group_stages<L, S_HI1, S_LO1>(x, post, tws, P);
+            ntt_group_stages<L, S_HI1, S_LO1>(x, post, tws, P, M2);
 #pragma unroll
             for (int u = 0; u < (1 << G1); ++u) lds_put(lo_plane, hi_plane, (pre << (S_HI1 + 1)) | ((uint32_t)u << S_LO1) | post, t, x[u]);
         }
@@ -254,7 +299,7 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
             Fe x[1 << G2];
 #pragma unroll
             for (int u = 0; u < (1 << G2); ++u) x[u] = lds_get(lo_plane, hi_plane, (pre << G2) | u, t);
-            ntt_group_stages<L, G2 - 1, 0>(x, 0, tws, P);
+            ntt_group_stages<L, G2 - 1, 0>(x, 0, tws, P, M2);
 #pragma unroll
             for (int u = 0; u < (1 << G2); ++u) store_out((pre << G2) | u, t, x[u]);
         }
