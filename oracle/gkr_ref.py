@@ -66,7 +66,7 @@ def circuit_digest(layers) -> bytes:
 def prove_partial_terms(field, terms, D, claimed_sum, tr=None):
     """prove_partial (prover.rs:24-30, :33-73) on sum_i prod_{f in terms[i]} table_f.  terms: list of lists of tables
     (lists of ints).  Returns (round_polys, challenges, finals) with finals = every factor at the challenge point.
-    tr: transcript to continue (the GKR driver chains its sumchecks onto its own transcript); None = a fresh one, which is
+    tr: transcript to continue (the GKR driver runs ONE transcript through all its sumchecks); None = a fresh one, which is
     exactly the reference's prove_partial."""
     p = pyref.modulus(field)
     tr = pyref.Transcript() if tr is None else tr
@@ -155,7 +155,7 @@ def _absorb(tr, elems):
 
 
 def _next_claim(field, tr, layer_proof, u, v):
-    """the layer's messages have been absorbed as they were produced ([rp1 | W(u)] then [rp2 | W(v)]): draw alpha, beta"""
+    """the layer's messages have been absorbed as they were produced (sumcheck #1, W(u), sumcheck #2, W(v)): draw alpha, beta"""
     p = pyref.modulus(field)
     alpha = tr.sample_field_element(field)
     beta = tr.sample_field_element(field)
@@ -181,9 +181,9 @@ def gkr_prove(field, layers, inputs, seed):
             else:
                 H[x] = (H[x] + E[z]) % p
                 B1[x] = (B1[x] + E[z] * W[y]) % p
-        rp1, u, fin1 = prove_partial_terms(field, [[W, H], [B1]], 2, claim["c"], fork(tr))   # chained onto the driver transcript
+        rp1, u, fin1 = prove_partial_terms(field, [[W, H], [B1]], 2, claim["c"], tr)   # continues the ONE driver transcript
         wu = fin1[0]
-        _absorb(tr, [x for rp in rp1 for x in rp] + [wu])
+        _absorb(tr, [wu])
         sub1 = (fin1[0] * fin1[1] + fin1[2]) % p
         equ = eq_table(field, u)
         A2, M2 = [0] * n_in, [0] * n_in
@@ -195,9 +195,9 @@ def gkr_prove(field, layers, inputs, seed):
                 A2[y] = (A2[y] + t) % p
         H2 = [(a + wu * m) % p for a, m in zip(A2, M2)]
         C2 = [wu * a % p for a in A2]
-        rp2, v, fin2 = prove_partial_terms(field, [[W, H2], [C2]], 2, sub1, fork(tr))      # W(u) is bound before v is drawn
+        rp2, v, fin2 = prove_partial_terms(field, [[W, H2], [C2]], 2, sub1, tr)        # W(u) is bound before v is drawn
         wv = fin2[0]
-        _absorb(tr, [x for rp in rp2 for x in rp] + [wv])
+        _absorb(tr, [wv])
         layer_proof = [x for rp in rp1 for x in rp] + [x for rp in rp2 for x in rp] + [wu, wv]
         proof += layer_proof
         claim = _next_claim(field, tr, layer_proof, u, v)
@@ -220,10 +220,10 @@ def gkr_verify(field, layers, inputs, outputs, seed, proof):
         rp2 = [layer_proof[3 * s + 3 * r:3 * s + 3 * r + 3] for r in range(s)]
         wu, wv = layer_proof[-2], layer_proof[-1]
         try:
-            sub1, u = _verify_partial_from(fork(tr), field, claim["c"], rp1)
-            _absorb(tr, [x for rp in rp1 for x in rp] + [wu])
-            sub2, v = _verify_partial_from(fork(tr), field, sub1, rp2)
-            _absorb(tr, [x for rp in rp2 for x in rp] + [wv])
+            sub1, u = _verify_partial_from(tr, field, claim["c"], rp1)
+            _absorb(tr, [wu])
+            sub2, v = _verify_partial_from(tr, field, sub1, rp2)
+            _absorb(tr, [wv])
         except ValueError:
             return False
         E = _E(field, claim, log_out)

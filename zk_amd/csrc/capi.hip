@@ -744,13 +744,32 @@ struct ProverScratch {
     uint64_t *d_ch;          // rounds elements
     uint64_t *d_final;       // kMaxFactors elements (same block as d_rp, d_ch)
     size_t rp_bytes, ch_bytes;
+    bool external;           // sponge and the three outputs belong to a DeviceChain (not allocated / freed here)
+};
+// A caller that keeps ONE transcript on the device across several sumchecks (the GKR driver): the sponge already holds
+// everything absorbed so far INCLUDING this sumcheck's claimed sum; round polynomials, challenges and the factor values at
+// the point are written straight to the caller's device buffers; nothing is copied to the host and nothing waits.
+struct DeviceChain {
+    WordSponge *d_sponge;
+    uint64_t *d_rp, *d_ch, *d_final;
 };
 // The proof being assembled is ONE device block [round polys | challenges | factor values at the point] so that it comes
 // back in one copy (through pinned memory: a device-to-pageable copy blocks the host once per call).
-static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint32_t D) {
+static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint32_t D, const DeviceChain *chain = nullptr) {
     ps = {};
     ps.rp_bytes = (size_t)(rounds ? rounds : 1) * (D + 1) * 32;
     ps.ch_bytes = (size_t)(rounds ? rounds : 1) * 32;
+    if (chain) {
+        ps.external = true;
+        ps.d_sponge = chain->d_sponge;
+        ps.d_rp = chain->d_rp;
+        ps.d_ch = chain->d_ch;
+        ps.d_final = chain->d_final;
+        ZKCHK(pool_alloc(c, 2 * kChallengeBytes, (void **)&ps.d_challenge));
+        ZKCHK(pool_alloc(c, 2 * kEpartBytes, (void **)&ps.d_epart));
+        HIPCHK(hipMemsetAsync(ps.d_epart, 0, 2 * kEpartBytes, c->stream));
+        return ZK_OK;
+    }
     ZKCHK(pool_alloc(c, sizeof(WordSponge), (void **)&ps.d_sponge));
     ZKCHK(pool_alloc(c, 2 * kChallengeBytes, (void **)&ps.d_challenge));
     ZKCHK(pool_alloc(c, 2 * kEpartBytes, (void **)&ps.d_epart));
@@ -761,6 +780,12 @@ static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint
     return ZK_OK;
 }
 static void scratch_free(zk_ctx *c, ProverScratch &ps) {
+    if (ps.external) {
+        pool_free(c, ps.d_challenge, 2 * kChallengeBytes);
+        pool_free(c, ps.d_epart, 2 * kEpartBytes);
+        ps = {};
+        return;
+    }
     pool_free(c, ps.d_sponge, sizeof(WordSponge));
     pool_free(c, ps.d_challenge, 2 * kChallengeBytes);
     pool_free(c, ps.d_epart, 2 * kEpartBytes);
@@ -1055,7 +1080,7 @@ static void round_state_release(RoundState &st) {
     scratch_free(st.c, st.ps);
 }
 static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uint64_t k, uint32_t D, bool consume,
-                                uint64_t total_rounds) {
+                                uint64_t total_rounds, const DeviceChain *chain = nullptr) {
     st.c = c;
     st.k = k;
     st.vars_left = f[0]->n_vars;
@@ -1074,7 +1099,7 @@ static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uin
         st.scratch[i] = nullptr;
         st.scratch_bytes[i] = 0;
     }
-    int32_t rc = scratch_alloc(c, st.ps, total_rounds, D);
+    int32_t rc = scratch_alloc(c, st.ps, total_rounds, D, chain);
     if (rc == ZK_OK && D >= 1 && D <= (uint32_t)kMaxSkipDegree) {
         auto it = c->lagrange_w.find(D);
         if (it == c->lagrange_w.end()) {
@@ -1468,9 +1493,30 @@ static bool has_duplicate_handles(zk_mle *const *f, uint64_t k) {
 // factor values, for a caller that chains further device work on them without a host round trip (the GKR driver).
 static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpec &ts, uint32_t D, const uint64_t sum[4],
                           int32_t absorb_table, int32_t consume, uint64_t *out_rp, uint64_t *out_ch, uint64_t *out_final,
-                          uint64_t *d_keep_ch = nullptr, uint64_t *d_keep_final = nullptr, const Sponge *init = nullptr) {
-    if (!sum) return ZK_ERR_BAD_ARG;
+                          uint64_t *d_keep_ch = nullptr, uint64_t *d_keep_final = nullptr, const Sponge *init = nullptr,
+                          const DeviceChain *chain = nullptr) {
+    if (!sum && !chain) return ZK_ERR_BAD_ARG;
     ZKCHK(product_args(c, (const zk_mle *const *)f, k));
+    if (chain) {   // device-resident transcript: enqueue the rounds and return (no host data, no synchronisation)
+        const uint64_t n = f[0]->n_vars;
+        if (n == 0 || D >= kMaxSums) return ZK_ERR_UNSUPPORTED;
+        if (has_duplicate_handles(f, k)) consume = 0;
+        RoundState st;
+        ZKCHK(round_state_init(st, c, f, k, D, consume != 0, n, chain));
+        st.terms = ts;
+        st.d_final = st.ps.d_final;
+        int32_t rc = ZK_OK;
+        bool fin = false;
+        while (st.round < n && rc == ZK_OK) rc = prover_step(st, &fin);
+        if (rc == ZK_OK && !fin) {
+            FactorPtrs fp = {};
+            for (uint64_t i = 0; i < k; ++i) fp.in[i] = st.cur[i];
+            k_final_evals<<<1, 64, 0, c->stream>>>(fp, (uint32_t)k, chal_prev(st), st.d_final, c->fi->P);
+            if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+        }
+        round_state_release(st);   // stream-ordered reuse of the scratch
+        return rc;
+    }
     if (f[0]->n_vars && (!out_rp || !out_ch)) return ZK_ERR_BAD_ARG;
     if (D >= kMaxSums) return ZK_ERR_UNSUPPORTED;
     const FieldParams &P = c->fi->P;

@@ -20,7 +20,8 @@ namespace zk {
 // eq(point, .) over nv variables by direct products (small tables only: nv muls per entry):
 // out[j] = scale * prod_w (bit_{nv-1-w}(j) ? g_w : 1 - g_w)
 __global__ __launch_bounds__(kBlock) void k_eq_direct(const uint64_t *__restrict__ point, uint32_t nv, Fe scale,
-                                                      uint64_t *__restrict__ out, FieldParams P) {
+                                                      uint64_t *__restrict__ out, FieldParams P, const uint64_t *__restrict__ d_scale = nullptr) {
+    if (d_scale) scale = fe_load(d_scale, 0);   // the scale lives on the device (the GKR driver's alpha / beta)
     const uint64_t n = 1ull << nv, stride = (uint64_t)gridDim.x * kBlock;
     Fe one;
 #pragma unroll
@@ -52,8 +53,10 @@ __global__ __launch_bounds__(kBlock) void k_eq_outer(const uint64_t *__restrict_
 // are built by direct products in LDS (<= 8 dependent multiplies), so the whole chain is <= 9 multiplies deep; the point
 // is read from DEVICE memory once.  k_eq_outer then needs ONE multiply per element of the full table.
 __global__ __launch_bounds__(kBlock) void k_eq_halves(const uint64_t *__restrict__ point, uint32_t m, Fe scale,
-                                                      uint64_t *__restrict__ d_hi, uint64_t *__restrict__ d_lo, FieldParams P) {
+                                                      uint64_t *__restrict__ d_hi, uint64_t *__restrict__ d_lo, FieldParams P,
+                                                      const uint64_t *__restrict__ d_scale = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char eq_smem[];
+    if (d_scale) scale = fe_load(d_scale, 0);
     const uint32_t hi_bits = m / 2, lo_bits = m - hi_bits;
     const bool is_hi = blockIdx.x == 0;
     const uint32_t nv = is_hi ? hi_bits : lo_bits, first = is_hi ? 0 : hi_bits;
@@ -286,6 +289,64 @@ __global__ __launch_bounds__(kBlock) void k_dft_across(const uint64_t *__restric
             fe_store(out, (uint64_t)k * L + j, acc);
         }
     }
+}
+
+// ---- the driver's transcript on the device (one wave per step) ------------------------------------------------------------------
+// The GKR driver keeps ONE sponge for the whole proof: every sumcheck continues it, and the few
+// scalar steps between two sumchecks run here, so that a proof needs no host synchronisation between its first and its last
+// kernel.  sc = the proof's scalar block in device memory: [0] current claim, [1] alpha, [2] beta, [3] claim of sumcheck #2.
+constexpr int kGkrScClaim = 0, kGkrScAlpha = 1, kGkrScBeta = 2, kGkrScSum2 = 3, kGkrScalars = 4;
+// absorb the claim of the first sumcheck (prover.rs:42 of that sumcheck)
+__global__ __launch_bounds__(64) void k_gkr_chain_start(WordSponge *__restrict__ gsp, const uint64_t *__restrict__ sc, FieldParams P) {
+    __shared__ Fe buf[2];
+    const LaneKeccak L = lane_keccak_init();
+    LaneSponge sp = lane_sponge_load(gsp, L);
+    if (L.lane == 0) buf[0] = fe_load(sc, kGkrScClaim);
+    lane_absorb_elems(sp, L, buf, 1, P);
+    lane_sponge_store(gsp, sp, L);
+}
+// after sumcheck #1 of a layer: fin = [W(u), H(u), B1(u)].  proof gets W(u); absorb W(u); the claim of #2 is P1(u) = W(u) H(u) +
+// B1(u), absorbed as that sumcheck's first message
+__global__ __launch_bounds__(64) void k_gkr_chain_mid(WordSponge *__restrict__ gsp, const uint64_t *__restrict__ fin, uint64_t *__restrict__ proof_wu,
+                                                       uint64_t *__restrict__ sc, FieldParams P) {
+    __shared__ Fe buf[2];
+    const LaneKeccak L = lane_keccak_init();
+    LaneSponge sp = lane_sponge_load(gsp, L);
+    if (L.lane == 0) {
+        const Fe wu = fe_load(fin, 0), hu = fe_load(fin, 1), bu = fe_load(fin, 2);
+        const Fe s2 = fe_add(fe_mul(wu, hu, P), bu, P);
+        buf[0] = wu;
+        buf[1] = s2;
+        fe_store(proof_wu, 0, wu);
+        fe_store(sc, kGkrScSum2, s2);
+    }
+    lane_absorb_elems(sp, L, buf, 2, P);
+    lane_sponge_store(gsp, sp, L);
+}
+// after sumcheck #2: fin = [W(v), ..].  proof gets W(v); absorb W(v); draw alpha, beta; next claim alpha W(u) + beta W(v), absorbed
+// as the next layer's first message (after the last layer nobody reads the transcript again)
+__global__ __launch_bounds__(64) void k_gkr_chain_end(WordSponge *__restrict__ gsp, const uint64_t *__restrict__ fin, const uint64_t *__restrict__ proof_wu,
+                                                       uint64_t *__restrict__ proof_wv, uint64_t *__restrict__ sc, FieldParams P) {
+    __shared__ Fe buf[2];
+    const LaneKeccak L = lane_keccak_init();
+    LaneSponge sp = lane_sponge_load(gsp, L);
+    const Fe wu = fe_load(proof_wu, 0), wv = fe_load(fin, 0);
+    if (L.lane == 0) {
+        buf[0] = wv;
+        fe_store(proof_wv, 0, wv);
+    }
+    lane_absorb_elems(sp, L, buf, 1, P);
+    Mul29 t29;
+    const Fe alpha = lane_squeeze(sp, L, P, t29), beta = lane_squeeze(sp, L, P, t29);
+    const Fe claim = fe_add(fe_mul(alpha, wu, P), fe_mul(beta, wv, P), P);
+    if (L.lane == 0) {
+        buf[1] = claim;
+        fe_store(sc, kGkrScAlpha, alpha);
+        fe_store(sc, kGkrScBeta, beta);
+        fe_store(sc, kGkrScClaim, claim);
+    }
+    lane_absorb_elems(sp, L, buf + 1, 1, P);
+    lane_sponge_store(gsp, sp, L);
 }
 
 // ---- statement digest: Keccak-256 tree hash (the driver binds circuit, inputs and outputs before the output point is drawn) ----

@@ -200,7 +200,13 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
             continue;
         }
         Fe s = fe_zero();
-        for (uint32_t b = lane; b < nblocks; b += 64) s = fe_add(s, fe_load(partials, (uint64_t)b * ns + t), P);
+        for (uint32_t b = lane; b < nblocks; b += 8 * 64) {   // eight independent loads in flight, then a tree of adds
+            Fe x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = b + u * 64 < nblocks ? fe_load(partials, (uint64_t)(b + u * 64) * ns + t) : fe_zero();
+            const Fe lo = fe_add(fe_add(x[0], x[1], P), fe_add(x[2], x[3], P), P), hi = fe_add(fe_add(x[4], x[5], P), fe_add(x[6], x[7], P), P);
+            s = fe_add(s, fe_add(lo, hi, P), P);
+        }
         s = fe_wave_sum(s, P);
         if (lane == 0) fin[t] = s;
     }

@@ -148,7 +148,8 @@ ZK_D void lane_sponge_store(WordSponge *gsp, const LaneSponge &sp, const LaneKec
     if (L.index >= 0) gsp->s[L.index] = sp.a;
     if (L.lane == 0) gsp->pos = sp.pos;
 }
-ZK_D Fe transcript_step(LaneSponge &sp, const LaneKeccak &L, const Fe *sums, uint32_t ns, const FieldParams &P, Mul29 &ch29) {
+// absorb ns elements (Montgomery form; read by lane, so `sums` may be LDS or global memory) as 32-byte big-endian canonical images
+ZK_D void lane_absorb_elems(LaneSponge &sp, const LaneKeccak &L, const Fe *sums, uint32_t ns, const FieldParams &P) {
     for (uint32_t base = 0; base < ns; base += 64) {
         // lane t converts sum (base + t): Montgomery -> canonical, in parallel across lanes
         const uint32_t mine = base + (uint32_t)L.lane < ns ? base + (uint32_t)L.lane : ns - 1;
@@ -179,6 +180,10 @@ ZK_D Fe transcript_step(LaneSponge &sp, const LaneKeccak &L, const Fe *sums, uin
             }
         }
     }
+}
+// sample_field_element (transcript/src/lib.rs:20-30): squeeze one challenge; returned in Montgomery form (wave-uniform), ch29 =
+// its prepared multiplier form
+ZK_D Fe lane_squeeze(LaneSponge &sp, const LaneKeccak &L, const FieldParams &P, Mul29 &ch29) {
     // squeeze: pad10*1 with Keccak's 0x01 domain byte, permute, digest = words 0..3
     if ((uint32_t)L.index == sp.pos) sp.a ^= 0x01ull;
     if (L.index == 16) sp.a ^= 0x8000000000000000ull;
@@ -208,6 +213,10 @@ ZK_D Fe transcript_step(LaneSponge &sp, const LaneKeccak &L, const Fe *sums, uin
     const Fe chs = fe_mul29(xr, k1, P);
     split29(chs.v, ch29.l);
     return ch;
+}
+ZK_D Fe transcript_step(LaneSponge &sp, const LaneKeccak &L, const Fe *sums, uint32_t ns, const FieldParams &P, Mul29 &ch29) {
+    lane_absorb_elems(sp, L, sums, ns, P);
+    return lane_squeeze(sp, L, P, ch29);
 }
 // publish a challenge for the next round's fused fold: [Fe r][Mul29 of r] (common.cuh, kChallengeBytes)
 ZK_D void publish_challenge(uint64_t *d_challenge, uint64_t *out_ch, const Fe &ch, const Mul29 &ch29, int lane) {
