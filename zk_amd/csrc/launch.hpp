@@ -28,7 +28,7 @@ int launch_round_single_t(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k,
 
 
 // ---- pipelined rounds (pipe_kernels.cuh / pipe.hip): sums of round s as a polynomial in the pending challenge -------------
-constexpr uint32_t kPipeMaxWorkBlocks = 512;
+constexpr uint32_t kPipeMaxWorkBlocks = 256;
 }  // namespace zk
 #include "pipe_args.hpp"
 namespace zk {

@@ -24,8 +24,14 @@ static uint32_t pipe_threads(int k, uint32_t D, int extra) {
 }
 uint32_t pipe_rows_per_block(int k, uint32_t D, int extra) { return pipe_threads(k, D, extra) / 16; }
 uint32_t pipe_work_blocks(int k, uint32_t D, int extra, uint64_t q) {
+    // Four passes per block once there is work for more than 64 blocks: a launch ends when its LAST block has reduced every
+    // block's partials (~1 us per 128 of them), so few blocks with a few passes each (~2 us per pass) beat many with one
     const uint32_t rows = pipe_rows_per_block(k, D, extra);
     uint64_t g = (q + rows - 1) / rows;
+    if (g > 64) {
+        g = (g + 3) / 4;
+        if (g < 64) g = 64;
+    }
     if (g > kPipeMaxWorkBlocks) g = kPipeMaxWorkBlocks;
     return (uint32_t)(g ? g : 1);
 }
