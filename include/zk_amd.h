@@ -259,10 +259,11 @@ int32_t zk_circuit_layer_dims(const zk_circuit *c, uint64_t layer, uint64_t *out
 int32_t zk_circuit_proof_elems(const zk_circuit *c, uint64_t *out);   /* sum over layers of 6*log_in + 2 */
 /* evaluate the circuit on the device: new table of 2^log_out(0) outputs */
 int32_t zk_gkr_evaluate(const zk_circuit *c, const zk_mle *input, zk_mle **out_outputs);
-/* GKR prover: per layer two prove_partial calls (Libra's phase 1 over x, phase 2 over y), chained by their sub-claims;
- * seed = 32 bytes binding the statement (the caller's digest of circuit / inputs / outputs), absorbed first by the
- * driver's transcript (Transcript semantics of transcript/src/lib.rs).  out_proof: zk_circuit_proof_elems elements,
- * per layer [round polys #1 (log_in*3) | round polys #2 (log_in*3) | W(u) | W(v)].  Returns the outputs table. */
+/* GKR prover: per layer two prove_partial-style sumchecks (Libra's phase 1 over x, phase 2 over y), chained by their
+ * sub-claims, on ONE transcript (Transcript semantics of transcript/src/lib.rs) that first absorbs seed (32 bytes: the caller's
+ * domain separator / session id) and the library's own digests of the circuit, the inputs and the outputs (Keccak-256 tree
+ * hash) -- the statement is bound before the output point is drawn.  out_proof: zk_circuit_proof_elems
+ * elements, per layer [round polys #1 (log_in*3) | round polys #2 (log_in*3) | W(u) | W(v)].  Returns the outputs table. */
 int32_t zk_gkr_prove(const zk_circuit *c, const zk_mle *input, const uint8_t seed[32], zk_mle **out_outputs,
                      uint64_t *out_proof);
 /* ZK_OK = accept; ZK_ERR_VERIFY_SUM = a sumcheck round check failed; ZK_ERR_GKR_REJECT = wiring / input check failed */
