@@ -105,6 +105,30 @@ TEST(test_fft) {
     ASSERT_EQ(ifft<Bls12_377Fr>(fft<Bls12_377Fr>(a)), a);
 }
 
+// pairing_index.rs:61-96 (the literal pair lists), evaluation_form.rs:4 (Clone, PartialEq), transcript/src/lib.rs:32-34
+TEST(test_index_pair_clone_eq_sample_n) {
+    using PV = std::vector<std::pair<size_t, size_t>>;
+    ASSERT_EQ(index_pair(3, 0), (PV{{0, 4}, {1, 5}, {2, 6}, {3, 7}}));
+    ASSERT_EQ(index_pair(3, 1), (PV{{0, 2}, {1, 3}, {4, 6}, {5, 7}}));
+    ASSERT_EQ(index_pair(3, 2), (PV{{0, 1}, {2, 3}, {4, 5}, {6, 7}}));
+    ASSERT_EQ(index_pair(1, 0), (PV{{0, 1}}));
+    auto p = MultiLinearPolynomial<F>::new_(2, frs({3, 1, 2, 5})).unwrap();
+    auto q = MultiLinearPolynomial<F>::new_(2, frs({3, 1, 2, 5})).unwrap();
+    auto r = MultiLinearPolynomial<F>::new_(2, frs({3, 1, 2, 6})).unwrap();
+    ASSERT(p == q);
+    ASSERT(!(p == r));
+    Transcript t1, t2;
+    t1.append({1, 2, 3});
+    t2.append({1, 2, 3});
+    auto many = t1.sample_n_field_elements<F>(3);
+    for (int i = 0; i < 3; ++i) ASSERT_EQ(many[i], t2.sample_field_element<F>());
+    // fft_internal with the root fft itself uses reproduces fft (fft/src/lib.rs:4-8)
+    auto a = frs({0, 2, 34, 3434});
+    Fr w;
+    ASSERT(zk_field_root_of_unity(F::id, 2, w.l.data()) == ZK_OK);
+    ASSERT_EQ(fft_internal<F>(a, w), fft<F>(a));
+}
+
 int main() {
     try {
         run_test_new_multilinear_poly();
@@ -118,10 +142,11 @@ int main() {
         run_test_correct_sum_prove_partial();
         run_test_invalid_sum();
         run_test_fft();
+        run_test_index_pair_clone_eq_sample_n();
     } catch (const std::exception &e) {
         std::printf("EXCEPTION: %s\n", e.what());
         return 2;
     }
-    std::printf(failures ? "FAILED (%d)\n" : "ok: 11 reference tests passed%.0d\n", failures);
+    std::printf(failures ? "FAILED (%d)\n" : "ok: 12 reference tests passed%.0d\n", failures);
     return failures ? 1 : 0;
 }

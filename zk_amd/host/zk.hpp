@@ -140,8 +140,10 @@ public:
         zk_mle_to_bytes(context<F>(), h_->h, b.data());
         return b;
     }
-    bool operator==(const MultiLinearPolynomial &o) const {   // #[derive(PartialEq)]
-        return n_vars() == o.n_vars() && evaluation_slice() == o.evaluation_slice();
+    bool operator==(const MultiLinearPolynomial &o) const {   // #[derive(PartialEq)]: compared on the device (zk_mle_equal)
+        int32_t eq = 0;
+        if (zk_mle_equal(context<F>(), h_->h, o.h_->h, &eq) != ZK_OK) return false;
+        return eq != 0;
     }
     zk_mle *raw() const { return h_->h; }
 };
@@ -303,8 +305,8 @@ public:
     }
     template <class F>
     std::vector<Fe<F>> sample_n_field_elements(size_t n) {
-        std::vector<Fe<F>> v;
-        for (size_t i = 0; i < n; ++i) v.push_back(sample_field_element<F>());
+        std::vector<Fe<F>> v(n);   // transcript/src/lib.rs:32-34
+        zk_transcript_sample_n_field_elements(t_, F::id, n, reinterpret_cast<uint64_t *>(v.data()));
         return v;
     }
 };
@@ -316,6 +318,26 @@ inline std::vector<Fe<F>> fft(const std::vector<Fe<F>> &coefficients) {
     const int32_t rc = zk_fft_host(context<F>(), reinterpret_cast<const uint64_t *>(coefficients.data()), coefficients.size(),
                                    reinterpret_cast<uint64_t *>(out.data()));
     if (rc != ZK_OK) throw std::runtime_error(zk_strerror(rc));
+    return out;
+}
+// fft/src/lib.rs:21-46 -- any omega; "values must be a power of 2" as the reference
+template <class F>
+inline std::vector<Fe<F>> fft_internal(const std::vector<Fe<F>> &values, const Fe<F> &omega) {
+    std::vector<Fe<F>> out(values.size());
+    const int32_t rc = zk_fft_internal_host(context<F>(), reinterpret_cast<const uint64_t *>(values.data()), values.size(), omega.l.data(),
+                                            reinterpret_cast<uint64_t *>(out.data()));
+    if (rc != ZK_OK) throw std::runtime_error(zk_strerror(rc));
+    return out;
+}
+// polynomial/src/multilinear/pairing_index.rs:2-9 (host index arithmetic; the kernels compute the same indices inline)
+inline std::vector<std::pair<size_t, size_t>> index_pair(uint8_t n_vars, uint8_t index) {
+    if (n_vars == 0 || index > n_vars - 1) throw std::runtime_error(zk_strerror(ZK_ERR_PANIC_INDEX));
+    const unsigned pos = n_vars - 1 - index;
+    std::vector<std::pair<size_t, size_t>> out;
+    for (size_t j = 0; j < ((size_t)1 << (n_vars - 1)); ++j) {
+        const size_t left = ((j >> pos) << (pos + 1)) | (j & (((size_t)1 << pos) - 1));
+        out.emplace_back(left, left | ((size_t)1 << pos));
+    }
     return out;
 }
 template <class F>
