@@ -32,7 +32,7 @@ while time.time() < t_end:
     elif kind == "terms":
         shape = rng.choice([[2, 1], [2, 1], [3, 1], [1, 1], [2, 2], [2, 1, 1], [3, 2]])
         D = max(shape) + rng.randrange(2)
-        n = rng.choice([1, 3, 6, 9, 10, 11, 12])
+        n = rng.choice([1, 3, 6, 9, 10, 11, 12, 13, 14])
         tabs = [[[rng.randrange(p) for _ in range(1 << n)] for _ in range(kk)] for kk in shape]
         s = rng.randrange(p)
         want = gkr_ref.prove_partial_terms(f, tabs, D, s)
