@@ -48,17 +48,38 @@ __global__ __launch_bounds__(kBlock) void k_eq_outer(const uint64_t *__restrict_
     }
 }
 
+// out[idx] = hi1[..] * lo1[..] + hi2[..] * lo2[..]: E = alpha*eq(g1,.) + beta*eq(g2,.) in ONE pass over the table (the scales are
+// folded into the hi halves) instead of a write pass plus a read-modify-write pass
+__global__ __launch_bounds__(kBlock) void k_eq_outer2(const uint64_t *__restrict__ hi1, const uint64_t *__restrict__ lo1,
+                                                      const uint64_t *__restrict__ hi2, const uint64_t *__restrict__ lo2, uint32_t lo_bits,
+                                                      uint64_t n, uint64_t *__restrict__ out, FieldParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock, mask = (1ull << lo_bits) - 1;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        const Fe a = fe_mul(fe_load(hi1, j >> lo_bits), fe_load(lo1, j & mask), P), b = fe_mul(fe_load(hi2, j >> lo_bits), fe_load(lo2, j & mask), P);
+        fe_store(out, j, fe_add(a, b, P));
+    }
+}
+
 // The two half tables of eq(point, .) for m <= 30 in one launch: workgroup 0 builds hi (the first m/2 variables, scale
 // folded in), workgroup 1 builds lo.  A half of nv <= 15 variables is itself the outer product of two quarter tables that
 // are built by direct products in LDS (<= 8 dependent multiplies), so the whole chain is <= 9 multiplies deep; the point
 // is read from DEVICE memory once.  k_eq_outer then needs ONE multiply per element of the full table.
+// With a second point (point2 != null, grid = 4) workgroups 2, 3 build its halves into d_hi2 / d_lo2 with *d_scale2.
 __global__ __launch_bounds__(kBlock) void k_eq_halves(const uint64_t *__restrict__ point, uint32_t m, Fe scale,
                                                       uint64_t *__restrict__ d_hi, uint64_t *__restrict__ d_lo, FieldParams P,
-                                                      const uint64_t *__restrict__ d_scale = nullptr) {
+                                                      const uint64_t *__restrict__ d_scale = nullptr, const uint64_t *__restrict__ point2 = nullptr,
+                                                      const uint64_t *__restrict__ d_scale2 = nullptr, uint64_t *__restrict__ d_hi2 = nullptr,
+                                                      uint64_t *__restrict__ d_lo2 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char eq_smem[];
+    if (blockIdx.x >= 2) {   // (block-uniform)
+        point = point2;
+        d_scale = d_scale2;
+        d_hi = d_hi2;
+        d_lo = d_lo2;
+    }
     if (d_scale) scale = fe_load(d_scale, 0);
     const uint32_t hi_bits = m / 2, lo_bits = m - hi_bits;
-    const bool is_hi = blockIdx.x == 0;
+    const bool is_hi = (blockIdx.x & 1) == 0;
     const uint32_t nv = is_hi ? hi_bits : lo_bits, first = is_hi ? 0 : hi_bits;
     const uint32_t a = nv / 2, b = nv - a, na = 1u << a, nb = 1u << b;
     uint64_t *qa = reinterpret_cast<uint64_t *>(eq_smem), *qb = qa + (size_t)na * 4, *pt = qb + (size_t)nb * 4;
