@@ -86,6 +86,15 @@ static inline uint32_t grid_for(uint64_t items) {
     if (b > kMaxGrid) b = kMaxGrid;
     return (uint32_t)b;
 }
+// Wait for the stream: poll for a short while (a proof is ~0.3 ms of GPU time and the blocking wait's wake-up costs tens of
+// microseconds), then block.
+static inline hipError_t stream_wait(hipStream_t s) {
+    for (int i = 0; i < 20000; ++i) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+    }
+    return hipStreamSynchronize(s);
+}
 static inline int32_t use_device(const zk_ctx *ctx) {
     HIPCHK(hipSetDevice(ctx->device));
     return ZK_OK;
@@ -753,6 +762,11 @@ struct DeviceChain {
     WordSponge *d_sponge;
     uint64_t *d_rp, *d_ch, *d_final;
 };
+// the two last-block-done counters (8 bytes each, behind the two buffers) -- not the 2 x 130 KiB buffers themselves
+static int32_t epart_counters_zero(zk_ctx *c, uint64_t *d_epart) {
+    HIPCHK(hipMemsetAsync(d_epart + 2 * (kEpartBytes / 8), 0, 16, c->stream));   // both counters sit behind the two buffers
+    return ZK_OK;
+}
 // The proof being assembled is ONE device block [round polys | challenges | factor values at the point] so that it comes
 // back in one copy (through pinned memory: a device-to-pageable copy blocks the host once per call).
 static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint32_t D, const DeviceChain *chain = nullptr) {
@@ -766,14 +780,14 @@ static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint
         ps.d_ch = chain->d_ch;
         ps.d_final = chain->d_final;
         ZKCHK(pool_alloc(c, 2 * kChallengeBytes, (void **)&ps.d_challenge));
-        ZKCHK(pool_alloc(c, 2 * kEpartBytes, (void **)&ps.d_epart));
-        HIPCHK(hipMemsetAsync(ps.d_epart, 0, 2 * kEpartBytes, c->stream));
+        ZKCHK(pool_alloc(c, 2 * kEpartBytes + 16, (void **)&ps.d_epart));
+        ZKCHK(epart_counters_zero(c, ps.d_epart));
         return ZK_OK;
     }
     ZKCHK(pool_alloc(c, sizeof(WordSponge), (void **)&ps.d_sponge));
     ZKCHK(pool_alloc(c, 2 * kChallengeBytes, (void **)&ps.d_challenge));
-    ZKCHK(pool_alloc(c, 2 * kEpartBytes, (void **)&ps.d_epart));
-    HIPCHK(hipMemsetAsync(ps.d_epart, 0, 2 * kEpartBytes, c->stream));   // the last-block-done counters start at zero
+    ZKCHK(pool_alloc(c, 2 * kEpartBytes + 16, (void **)&ps.d_epart));
+    ZKCHK(epart_counters_zero(c, ps.d_epart));   // the last-block-done counters start at zero
     ZKCHK(pool_alloc(c, ps.rp_bytes + ps.ch_bytes + kMaxFactors * 32, (void **)&ps.d_rp));
     ps.d_ch = ps.d_rp + ps.rp_bytes / 8;
     ps.d_final = ps.d_ch + ps.ch_bytes / 8;
@@ -782,13 +796,13 @@ static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint
 static void scratch_free(zk_ctx *c, ProverScratch &ps) {
     if (ps.external) {
         pool_free(c, ps.d_challenge, 2 * kChallengeBytes);
-        pool_free(c, ps.d_epart, 2 * kEpartBytes);
+        pool_free(c, ps.d_epart, 2 * kEpartBytes + 16);
         ps = {};
         return;
     }
     pool_free(c, ps.d_sponge, sizeof(WordSponge));
     pool_free(c, ps.d_challenge, 2 * kChallengeBytes);
-    pool_free(c, ps.d_epart, 2 * kEpartBytes);
+    pool_free(c, ps.d_epart, 2 * kEpartBytes + 16);
     pool_free(c, ps.d_rp, ps.rp_bytes + ps.ch_bytes + kMaxFactors * 32);
     ps = {};
 }
@@ -1068,7 +1082,7 @@ static inline uint64_t *chal_cur(const RoundState &st) { return chal_of_round(st
 static inline uint64_t *chal_prev(const RoundState &st) { return chal_of_round(st, st.round + 1); }   // round - 1 (same parity as round + 1)
 static inline uint64_t *epart_of_round(const RoundState &st, uint64_t round) { return st.ps.d_epart + (round & 1) * (kEpartBytes / 8); }
 static inline uint32_t *epart_counter(const RoundState &st, uint64_t round) {
-    return reinterpret_cast<uint32_t *>(epart_of_round(st, round) + (size_t)(kPipeMaxWorkBlocks + 1) * 16 * 4);
+    return reinterpret_cast<uint32_t *>(st.ps.d_epart + 2 * (kEpartBytes / 8) + (round & 1));
 }
 static void round_state_release(RoundState &st) {
     for (uint64_t i = 0; i < (uint64_t)kMaxFactors; ++i)
@@ -1561,7 +1575,7 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
     const size_t block = st.ps.rp_bytes + st.ps.ch_bytes + kMaxFactors * 32;
     if (rc == ZK_OK) rc = results_staging(c, block, &stage);
     if (rc == ZK_OK && hipMemcpyAsync(stage, st.ps.d_rp, block, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ZK_ERR_HIP;
-    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == ZK_OK) {
+    if (stream_wait(c->stream) != hipSuccess && rc == ZK_OK) {
         g_hip_err = "sumcheck: stream synchronize failed";
         rc = ZK_ERR_HIP;
     }
