@@ -6,6 +6,7 @@
 //   fft/src/lib.rs:4-19.  There is no CPU compute fallback: every table operation is a gfx950 kernel.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <map>
 #include <new>
@@ -1548,6 +1549,8 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
     // the reference takes the polynomial by value and clones per fold, so a table may appear twice (A * A): in-place folds
     // would then fold the shared buffer once per listing -- such a product is proved out of place (own scratch per factor)
     if (has_duplicate_handles(f, k)) consume = 0;
+    static const bool host_dbg = getenv("ZK_HOST_DEBUG") != nullptr;
+    const auto t_enter = std::chrono::steady_clock::now();
     RoundState st;
     ZKCHK(round_state_init(st, c, f, k, D, consume != 0, n));
     st.terms = ts;
@@ -1575,9 +1578,15 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
     const size_t block = st.ps.rp_bytes + st.ps.ch_bytes + kMaxFactors * 32;
     if (rc == ZK_OK) rc = results_staging(c, block, &stage);
     if (rc == ZK_OK && hipMemcpyAsync(stage, st.ps.d_rp, block, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ZK_ERR_HIP;
+    const auto t_enq = std::chrono::steady_clock::now();
     if (stream_wait(c->stream) != hipSuccess && rc == ZK_OK) {
         g_hip_err = "sumcheck: stream synchronize failed";
         rc = ZK_ERR_HIP;
+    }
+    if (host_dbg) {
+        const auto t_done = std::chrono::steady_clock::now();
+        fprintf(stderr, "[host] n=%llu: enqueue %.1f us (everything up to the last launch), wait %.1f us\n", (unsigned long long)n,
+                std::chrono::duration<double, std::micro>(t_enq - t_enter).count(), std::chrono::duration<double, std::micro>(t_done - t_enq).count());
     }
     if (c->d_dbg) pipe_dbg_dump(c);
     if (rc == ZK_OK) {

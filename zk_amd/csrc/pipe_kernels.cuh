@@ -30,7 +30,6 @@
 //   B2 lane (point t, node rho): the product over the factors (1 multiply, unreduced accumulation).
 #pragma once
 #include "common.cuh"
-#include "quad.cuh"
 #include "transcript.cuh"
 #include "pipe_args.hpp"
 
@@ -429,12 +428,11 @@ __global__ __launch_bounds__((pipe_block_threads<K, D, EXTRA>())) void k_round_p
 // Rounds are numbered from 0 at the first round this kernel closes (out_rp / out_ch point at that round's slots).
 enum { kFinEntryFresh = 0, kFinEntryPending = 1, kFinEntryPipe = 2 };
 constexpr int kFinWorkWaves = kFinishPipeThreads / 64 - 1;
-constexpr int kFinRows = kFinWorkWaves * 4;
 constexpr int kFinStageBytes = 24 * 1024;   // exchange buffers of the work rows
-// The finisher takes over when the tables it folds into LDS have at most 2^8 elements: its first prepared round then has
-// 2^6 pair indices = two passes of the work rows, about one transcript step; bigger rounds are faster as k_round_pipe
-// launches spread over many CUs.
-constexpr int finish_pipe_vars(int nf) { return nf <= 4 ? 7 : 7; }
+// The finisher takes over when the tables it folds have at most 2^8 elements (2^7 kept in LDS): its first prepared round then
+// has 2^5 pair indices = three passes of its twelve work rows, about one transcript step; bigger rounds are faster as
+// k_round_pipe launches spread over many CUs.
+constexpr int finish_pipe_vars(int /*n_factors*/) { return 7; }
 
 struct FinLds {   // carved from the dynamic region (32-byte aligned offsets)
     uint64_t *tab[4];
