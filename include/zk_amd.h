@@ -303,8 +303,10 @@ int32_t zk_fft_internal_host(zk_ctx *ctx, const uint64_t *in, uint64_t n, const 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------ */
 /* time `reps` launches of the MSB fold of `t` into `out` with HIP events on the context's stream; average ms/launch */
 int32_t zk_bench_fold(zk_ctx *ctx, const zk_mle *t, const uint64_t r[4], zk_mle *out, int32_t reps, double *out_ms);
-/* the same with one event per launch boundary: out_ms_each[i] = duration of launch i, reps values (reps <= 65536) */
-int32_t zk_bench_fold_samples(zk_ctx *ctx, const zk_mle *t, const uint64_t r[4], zk_mle *out, int32_t reps, double *out_ms_each);
+/* the same with one event every `group` launches: out_ms_each[i] = average launch duration inside group i,
+   ceil(reps / group) values (at most 65536); group = 1 brackets every launch (an event record costs the stream ~4 us) */
+int32_t zk_bench_fold_samples(zk_ctx *ctx, const zk_mle *t, const uint64_t r[4], zk_mle *out, int32_t reps, int32_t group,
+                              double *out_ms_each);
 /* the same for zk_ntt (all passes of one transform), average ms per transform */
 int32_t zk_bench_ntt(zk_ctx *ctx, const zk_mle *in, int32_t inverse, zk_mle *out, int32_t reps, double *out_ms);
 /* register-resident modular-multiply throughput (no memory traffic): variant 0 = fe_mul chain. Returns modmul/s */

@@ -234,11 +234,11 @@ class MultiLinearPolynomial:
         check(lib.zk_bench_fold(self.ctx._h, self._h, _p(r), out._h, reps, c.byref(ms)))
         return ms.value
 
-    def bench_fold_samples(self, r, out, reps):
-        """per-launch durations (ms) of `reps` folds, one HIP event per launch boundary"""
+    def bench_fold_samples(self, r, out, reps, group=1):
+        """launch durations (ms) of `reps` folds: one HIP event every `group` launches, each sample the average inside its group"""
         r = _elems(r, 1)
-        ms = np.zeros(reps, dtype=np.float64)
-        check(lib.zk_bench_fold_samples(self.ctx._h, self._h, _p(r), out._h, reps, ms.ctypes.data_as(c.POINTER(c.c_double))))
+        ms = np.zeros((reps + group - 1) // group, dtype=np.float64)
+        check(lib.zk_bench_fold_samples(self.ctx._h, self._h, _p(r), out._h, reps, group, ms.ctypes.data_as(c.POINTER(c.c_double))))
         return ms
 
     # evaluate (evaluation_form.rs:83-89)
