@@ -471,6 +471,52 @@ def test_config_24var_fold_properties():
         assert np.array_equal(got[j], want)
 
 
+_EVAL_CHILD = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import zk_amd
+from oracle import binding as orc
+for field in (zk_amd.BN254_FR, zk_amd.BLS12_381_FR):
+    c = zk_amd.Context(field, 0)
+    for n in (1, 8, 9, 12, 13, 17, 20):
+        tab = orc.fill_random(field, 4100 + n, 1 << n)
+        pt = orc.fill_random(field, 4200 + n, n)
+        assert np.array_equal(zk_amd.MultiLinearPolynomial.new(c, n, tab).evaluate(pt), orc.mle_evaluate(field, n, tab, pt)), (field, n)
+print("evaluate ok")
+"""
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_evaluate_every_arity(field):
+    """evaluate (evaluation_form.rs:83-89) at every arity 1..21 (BN254: ..23): above 2^20 elements the top 1-4 variables go first
+    (k_fold_eq), then the bulk kernel takes the low 8-12 variables per launch (k_eval_low), the one-workgroup tail the rest; edge
+    points (0, 1, p - 1 coordinates) included.  Bit-exact vs the oracle."""
+    c = ctx_for(field)
+    p = zk_amd.modulus(field)
+    for n in range(1, 24 if field == zk_amd.BN254_FR else 22):
+        tab = orc.fill_random(field, 4000 + n, 1 << n)
+        t = MLE.new(c, n, tab)
+        pts = [orc.fill_random(field, 4300 + n, n)]
+        if n in (9, 10, 13, 20, 22):
+            edge = [0, 1, p - 1, 2]
+            pts.append(F(field, [edge[(i * 7 + n) % 4] for i in range(n)]))
+        for pt in pts:
+            assert np.array_equal(t.evaluate(pt), orc.mle_evaluate(field, n, tab, pt)), n
+        t.free()
+
+
+def test_evaluate_fold_path_still_exact():
+    """ZK_EVAL_FOLDS=1 keeps the variable-by-variable evaluate (k_fold_multi + tail) for A/B runs: same results."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _EVAL_CHILD % root], env=dict(os.environ, ZK_EVAL_FOLDS="1"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "evaluate ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_skip1_rounds_bit_exact():
     """Big fused rounds leave out the t = 1 sums and derive S(1) from the previous round's claim (k_round_kd SKIP1,
     TailDerive).  A child process with the threshold forced to 1 pair proves the (k, D) grid that way and compares every

@@ -543,32 +543,81 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
         return ZK_OK;
     }
     const FieldParams &P = c->fi->P;
-    const uint64_t tail_vars = n < (uint64_t)kEvalTailVars ? n : (uint64_t)kEvalTailVars;
-    const uint64_t big = n - tail_vars;                    // folds done as full launches
-    uint64_t *scratch = nullptr;
-    size_t scratch_bytes = 0;
-    if (big) {
-        scratch_bytes = (size_t)32 << (n - 1);
-        ZKCHK(pool_alloc(c, scratch_bytes, (void **)&scratch));
-    }
+    // bulk: the LOW variables first, 8-12 per launch (k_eval_low, one workgroup per output element).  With 8..12 variables left one
+    // workgroup finishes and writes the result; with more, a launch leaves 8 for that last one when 8..12 low variables get
+    // there, otherwise it takes 12; fewer than 8 left over go to k_evaluate_tail.
+    uint64_t *scratch[2] = {nullptr, nullptr};
+    size_t scratch_bytes[2] = {0, 0};
     int32_t rc = ZK_OK;
     const uint64_t *src = t->d;
+    uint64_t cur = n;   // variables left
+    static const bool bulk_low = getenv("ZK_EVAL_FOLDS") == nullptr;   // ZK_EVAL_FOLDS=1: the variable-by-variable path (A/B, tests)
+    for (int pass = 0; bulk_low && cur >= 8 && rc == ZK_OK; ++pass) {
+        uint64_t L = cur <= (uint64_t)kEvalLowMax ? cur : cur - 8;
+        if (L > (uint64_t)kEvalLowMax) L = kEvalLowMax;
+        if (L < (uint64_t)kEvalLowMin) L = kEvalLowMin;   // cur >= 13 here
+        const uint64_t n_out = 1ull << (cur - L);
+        uint64_t *dst = d_out_elem;
+        if (L != cur) {
+            const int b = pass & 1;
+            if (scratch_bytes[b] < n_out * 32) {
+                if (scratch[b]) pool_free(c, scratch[b], scratch_bytes[b]);
+                scratch[b] = nullptr;
+                scratch_bytes[b] = (size_t)n_out * 32;
+                rc = pool_alloc(c, scratch_bytes[b], (void **)&scratch[b]);
+                if (rc != ZK_OK) {
+                    scratch_bytes[b] = 0;
+                    break;
+                }
+            }
+            dst = scratch[b];
+        }
+        EvalLowPoint pt = {};
+        for (uint64_t p = 0; p < L; ++p) {
+            const Fe r = fe_from_u64limbs(point + 4 * (cur - 1 - p));   // index bit p <-> variable cur-1-p (variable 0 is the MSB)
+            for (int i = 0; i < 8; ++i) pt.r[p][i] = r.v[i];
+        }
+        k_eval_low<<<(uint32_t)n_out, kBlock, 0, c->stream>>>(src, dst, (uint32_t)L, pt, P);
+        if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+        src = dst;
+        cur -= L;
+    }
+    auto release = [&]() {
+        for (int b = 0; b < 2; ++b)
+            if (scratch[b]) pool_free(c, scratch[b], scratch_bytes[b]);
+    };
+    if (rc != ZK_OK || (bulk_low && cur == 0)) {   // failed, or the last k_eval_low has written the result
+        release();
+        return rc;
+    }
+    const uint64_t tail_vars = cur < (uint64_t)kEvalTailVars ? cur : (uint64_t)kEvalTailVars;
+    const uint64_t big = cur - tail_vars;                    // folds done as full launches (ZK_EVAL_FOLDS only)
+    uint64_t *fold_scratch = nullptr;
+    size_t fold_scratch_bytes = 0;
+    if (big) {
+        fold_scratch_bytes = (size_t)32 << (cur - 1);
+        rc = pool_alloc(c, fold_scratch_bytes, (void **)&fold_scratch);
+        if (rc != ZK_OK) {
+            release();
+            return rc;
+        }
+    }
     for (uint64_t i = 0; i < big && rc == ZK_OK;) {
-        const uint64_t left = big - i, m = n - i;
+        const uint64_t left = big - i, m = cur - i;
         if (left >= 2) {   // three (or two) variables per launch
             const int v = left >= 3 ? 3 : 2;
             FoldChallenges ch = {};
             for (int u = 0; u < v; ++u) ch.r[u] = mul29_prepare(fe_from_u64limbs(point + 4 * (i + u)), P);
             const uint64_t n_out = 1ull << (m - v);
-            if (v == 3) k_fold_multi<3><<<grid_for(n_out), kBlock, 0, c->stream>>>(src, scratch, n_out, P, ch);
-            else k_fold_multi<2><<<grid_for(n_out), kBlock, 0, c->stream>>>(src, scratch, n_out, P, ch);
+            if (v == 3) k_fold_multi<3><<<grid_for(n_out), kBlock, 0, c->stream>>>(src, fold_scratch, n_out, P, ch);
+            else k_fold_multi<2><<<grid_for(n_out), kBlock, 0, c->stream>>>(src, fold_scratch, n_out, P, ch);
             if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
             i += v;
         } else {
-            rc = launch_fold(c, src, scratch, m, 0, fe_from_u64limbs(point + 4 * i));
+            rc = launch_fold(c, src, fold_scratch, m, 0, fe_from_u64limbs(point + 4 * (i)));
             i += 1;
         }
-        src = scratch;
+        src = fold_scratch;
     }
     if (rc == ZK_OK) {
         // the remaining assignments travel in the kernel arguments: no staging buffer, no synchronisation
@@ -586,7 +635,8 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
             if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
         }
     }
-    if (scratch) pool_free(c, scratch, scratch_bytes);
+    release();
+    if (fold_scratch) pool_free(c, fold_scratch, fold_scratch_bytes);
     return rc;
 }
 extern "C" int32_t zk_mle_evaluate(zk_ctx *c, const zk_mle *t, const uint64_t *point, uint64_t n_point, uint64_t out[4]) {
@@ -594,9 +644,24 @@ extern "C" int32_t zk_mle_evaluate(zk_ctx *c, const zk_mle *t, const uint64_t *p
     if (t->ctx != c) return ZK_ERR_CONTEXT_MISMATCH;
     if (n_point != t->n_vars) return ZK_ERR_EVAL_ARITY;   // evaluation_form.rs:84-86
     ZKCHK(use_device(c));
-    ZKCHK(evaluate_device(c, t, point, c->d_sums));
-    HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_sums, 32, hipMemcpyDeviceToHost, c->stream));   // through pinned memory: one wait
-    HIPCHK(hipStreamSynchronize(c->stream));
+    static const bool host_dbg = getenv("ZK_HOST_DEBUG") != nullptr;
+    const auto t_enter = std::chrono::steady_clock::now();
+    if (t->n_vars == 0) {
+        ZKCHK(evaluate_device(c, t, point, c->d_sums));
+        HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_sums, 32, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        // the last kernel stores the 32-byte result straight into the pinned host buffer (mapped into the device's address space):
+        // a device-to-host copy of 32 bytes is a blit launch of its own (4-5 us on the stream)
+        ZKCHK(evaluate_device(c, t, point, c->h_pinned));
+    }
+    const auto t_enq = std::chrono::steady_clock::now();
+    HIPCHK(stream_wait(c->stream));
+    if (host_dbg) {
+        const auto t_done = std::chrono::steady_clock::now();
+        fprintf(stderr, "[host] evaluate n=%llu: enqueue %.1f us, wait %.1f us\n", (unsigned long long)t->n_vars,
+                std::chrono::duration<double, std::micro>(t_enq - t_enter).count(),
+                std::chrono::duration<double, std::micro>(t_done - t_enq).count());
+    }
     memcpy(out, c->h_pinned, 32);
     return ZK_OK;
 }

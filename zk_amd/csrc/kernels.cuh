@@ -104,6 +104,77 @@ __global__ __launch_bounds__(kBlock) void k_fold_multi(const uint64_t *in, uint6
     }
 }
 
+// ---- MultiLinearPolynomial::evaluate, bulk (evaluation_form.rs:83-89): the LOW L variables of the table in one pass ---------
+// evaluate() folds variable after variable: n launches (or n/3 three-variable ones), each writing a table the next one reads, and
+// all but the first are launch latency.  Folding variables is restriction of a multilinear polynomial, so the table after the
+// low L variables (index bits 0..L-1) have been assigned is
+//   out[g] = sum_{x < 2^L} in[g * 2^L + x] * eq(point_low, x),   eq(., x) = prod_p (bit p of x ? r_p : 1 - r_p)
+// -- the same field elements whatever the order of the folds (exact arithmetic, canonical representatives), so the result of
+// evaluate() is bit-identical.  One workgroup produces one out[g] from 2^L CONTIGUOUS elements (L = 8..12: 8-128 KiB):
+// thread t owns the elements x = xm * 256 + t, all loaded before any arithmetic; waves 0-2 build three 16-entry eq tables (bits
+// 0-3, 4-7, 8-L-1; chains of <= 3 multiplications, hidden under the loads); then each thread adds its <= 16 products
+// in[.] * eq_m[xm] UNREDUCED (wide_mac), reduces once, multiplies by its own eq_l[t] = eq_47[t >> 4] * eq_03[t & 15] and the
+// workgroup sums.  Per element: one 512-bit product and 32 bytes read; the remaining n - L variables are a 2^L times smaller table.
+constexpr int kEvalLowMax = 12, kEvalLowMin = 8;   // L = 8: one element per thread
+struct EvalLowPoint {   // r for index bit p (Montgomery form), p = 0 the least significant bit = the LAST variable
+    uint32_t r[kEvalLowMax][8];
+};
+__global__ __launch_bounds__(kBlock) void k_eval_low(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t L,
+                                                     EvalLowPoint pt, FieldParams P) {
+    __shared__ Fe eq[3][16];
+    __shared__ uint32_t red[kBlock / 64][8];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t n_m = 1u << (L - 8);   // elements per thread
+    const uint64_t base = ((uint64_t)blockIdx.x << L) + tid;
+    Fe x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if ((uint32_t)i < n_m) x[i] = fe_load(in, base + (uint64_t)i * 256);
+    if (wave < 3) {   // table `wave`: bits 4*wave .. (the third table has L - 8 bits); lane j < 16 builds entry j
+        const uint32_t nb = wave < 2 ? 4u : L - 8;
+        Fe one;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
+        Fe acc = one;
+        for (uint32_t k = 0; k < nb; ++k) {
+            Fe r;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r.v[i] = pt.r[4 * wave + k][i];   // wave-uniform index: scalar loads from the argument segment
+            const Fe sel = (lane >> k) & 1 ? r : fe_sub(one, r, P);
+            acc = k == 0 ? sel : fe_mul(acc, sel, P);
+        }
+        if (lane < 16) eq[wave][lane] = acc;
+    }
+    __syncthreads();
+    WideAcc w;
+    wide_zero(w);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if ((uint32_t)i < n_m) {
+            const Fe m = eq[2][i];
+            wide_mac(w, x[i].v, m.v);
+        }
+    const Fe wl = fe_mul(eq[1][tid >> 4], eq[0][tid & 15], P);
+    Fe s = fe_mul(redc_wide(w, P), wl, P);
+    s = fe_wave_sum(s, P);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[tid >> 6][i] = s.v[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        Fe acc = s;
+        for (int wv = 1; wv < kBlock / 64; ++wv) {
+            Fe o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] = red[wv][i];
+            acc = fe_add(acc, o, P);
+        }
+        fe_store(out, blockIdx.x, acc);
+    }
+}
+
 // ---- MultiLinearPolynomial::evaluate, tail (evaluation_form.rs:83-89) -----------------------------------------------------
 // Once the table is small every further fold is launch latency.  One 1024-thread workgroup finishes the last m <= 12
 // variables: the first of them is folded while the 2^m elements are read from HBM (so 2^(m-1) elements = 64 KiB of LDS at
