@@ -6,7 +6,9 @@
 //   fft/src/lib.rs:4-19.  There is no CPU compute fallback: every table operation is a gfx950 kernel.
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <chrono>
+#include <mutex>
 #include <cstdio>
 #include <map>
 #include <new>
@@ -1915,7 +1917,20 @@ extern "C" int32_t zk_ctx_device_free(zk_ctx *c, void *ptr, uint64_t bytes) {
 // value at x of the unique polynomial of degree <= D through (i, ys[i]), i = 0..D: what
 // UnivariatePolynomial::interpolate(ys).evaluate(x) returns (univariate_poly.rs:43-49, :29-40); exact in F_p.
 // Lagrange basis on the nodes 0..D: w_i = 1 / prod_{j != i} (i - j), computed once per proof (one field inversion each)
+// Barycentric weights of the nodes 0..D: one field inversion per node (~0.1 ms of host time for D = 2), so they are computed
+// once per (modulus, D) and kept (a GKR verification interpolates in 2 x depth sumchecks).
+static std::vector<Fe> interp_weights_compute(uint32_t D, const FieldParams &P);
 static std::vector<Fe> interp_weights(uint32_t D, const FieldParams &P) {
+    static std::mutex mu;
+    static std::map<std::pair<std::array<uint32_t, 8>, uint32_t>, std::vector<Fe>> cache;
+    std::array<uint32_t, 8> key;
+    for (int i = 0; i < 8; ++i) key[i] = P.p[i];
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({key, D});
+    if (it == cache.end()) it = cache.emplace(std::make_pair(key, D), interp_weights_compute(D, P)).first;
+    return it->second;
+}
+static std::vector<Fe> interp_weights_compute(uint32_t D, const FieldParams &P) {
     std::vector<Fe> w(D + 1);
     for (uint32_t i = 0; i <= D; ++i) {
         Fe den = fe_one(P);
