@@ -1079,7 +1079,7 @@ static Fe squeeze_field_element(Sponge &sp, const FieldParams &P) {   // transcr
 }
 // absorb poly.to_bytes() (product_poly.rs:77-83) -- device serialiser, chunked D2H, host sponge.  The Keccak sponge is
 // serial by construction and runs on the host (one GPU wave permutes 136 bytes in ~3 us = 45 MB/s; a host core does
-// several hundred MB/s), so it bounds `prove`; the serialiser kernel and the copy of chunk i+1 run while the host absorbs
+// 0.4-0.75 GB/s with keccak_host::rounds), so it bounds `prove`; the serialiser kernel and the copy of chunk i+1 run while the host absorbs
 // chunk i (two device + two pinned buffers, one event each; the pinned buffers stay with the context).
 static int32_t absorb_tables(zk_ctx *c, Sponge &sp, zk_mle *const *f, uint64_t k) {
     const uint64_t n = 1ull << f[0]->n_vars;
