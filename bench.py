@@ -195,13 +195,22 @@ def main():
     import zk_amd
 
     field = zk_amd.BN254_FR
+    # ZK_BENCH_REHEARSE=1: run the N > 1 code path with every rank on GPU 0 (gloo group, host-staged collectives): RCCL refuses two
+    # ranks on one device, and a one-GPU box is all the development loop has.  The numbers of such a run mean nothing.
+    rehearse = os.environ.get("ZK_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
+    tdev = "cpu" if rehearse else "cuda"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("ZK_BENCH_FORCE_DIST") == "1":
         # launched by torch.distributed.run: one rank per GPU over RCCL (also taken at world == 1 so the path is testable)
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if dist is not None:
@@ -233,7 +242,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     weights = np.full(len(samples), group, dtype=np.float64)
@@ -256,7 +265,7 @@ def main():
         "scaling": "strong",   # total work is fixed (ONE 2^24 table) as N grows
         "vs_baseline": None,
         "dtype": "u256 (8 x u32 Montgomery limbs, integer)",
-        "data": "synthetic",
+        "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU, not a measurement)",
         "config": {"workload": "mle_fold_msb of ONE 2^24-element BN254-Fr table (partial_evaluate(0,[r])), sharded by index mod n_gpus",
                    "n_vars": N_VARS, "field": "bn254_fr", "elements_per_gpu": 1 << local_vars,
                    "shard": "index mod n_gpus (no collective in the fold)"},
@@ -428,10 +437,10 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         try:
-            from zk_amd.distributed import GpuShardBackend, RcclComm, ntt_sharded
+            from zk_amd.distributed import GpuShardBackend, HostComm, RcclComm, ntt_sharded
 
             ex = result.setdefault("extra", {})
-            comm = RcclComm(ctx)
+            comm = HostComm(ctx) if rehearse else RcclComm(ctx)
             ns = local_vars
             A = zk_amd.MultiLinearPolynomial.random(ctx, ns, 0x5EED0100, first_index=rank << ns)
             B = zk_amd.MultiLinearPolynomial.random(ctx, ns, 0x5EED0200, first_index=rank << ns)
@@ -448,15 +457,15 @@ def main():
                 backend.close()
                 for q in pp.polynomials:
                     q.free()
-            tt = torch.tensor([sorted(ts[2:])[len(ts[2:]) // 2]], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([sorted(ts[2:])[len(ts[2:]) // 2]], dtype=torch.float64, device=tdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            chk = torch.from_numpy(ch.view("int64").copy()).cuda()
+            chk = torch.from_numpy(ch.view("int64").copy()).to(tdev)
             ref = chk.clone()
             dist.broadcast(ref, 0)
-            same = torch.tensor([int((chk == ref).all().item())], device="cuda")
+            same = torch.tensor([int((chk == ref).all().item())], device=tdev)
             dist.all_reduce(same, op=dist.ReduceOp.MIN)
             # latency of the round's one collective: (D+1)*8 uint64 lanes, back to back on the stream
-            lanes = torch.zeros(24, dtype=torch.int64, device="cuda")
+            lanes = torch.zeros(24, dtype=torch.int64, device=tdev)
             for _ in range(20):
                 dist.all_reduce(lanes)
             torch.cuda.synchronize()
@@ -487,7 +496,7 @@ def main():
                     ctx.synchronize()
                     tn.append(time.perf_counter() - t1)
                     y.free()
-                tt = torch.tensor([sorted(tn)[2]], dtype=torch.float64, device="cuda")
+                tt = torch.tensor([sorted(tn)[2]], dtype=torch.float64, device=tdev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 if rank == 0:
                     ex[f"sharded_ntt_ms_2p24_world{world}"] = float(tt.item()) * 1e3
