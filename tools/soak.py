@@ -14,7 +14,11 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctxs = {f: zk_amd.Context(f, 0) for f in (0, 1, 2)}
 t_end = time.time() + budget
 n_cases = 0
+t_beat = time.time() + 60
 while time.time() < t_end:
+    if time.time() > t_beat:
+        print(f"  ... {n_cases} cases", flush=True)
+        t_beat += 60
     f = rng.randrange(3)
     c = ctxs[f]
     p = zk_amd.modulus(f)
