@@ -829,12 +829,12 @@ struct ProverScratch {
 struct DeviceChain {
     WordSponge *d_sponge;
     uint64_t *d_rp, *d_ch, *d_final;
+    uint64_t *d_epart;   // E-partial buffers + counters shared by the chain's sumchecks (counters zero between launches)
 };
-// the two last-block-done counters (8 bytes each, behind the two buffers) -- not the 2 x 130 KiB buffers themselves
-static int32_t epart_counters_zero(zk_ctx *c, uint64_t *d_epart) {
-    HIPCHK(hipMemsetAsync(d_epart + 2 * (kEpartBytes / 8), 0, 16, c->stream));   // both counters sit behind the two buffers
-    return ZK_OK;
-}
+// The two last-block-done counters (8 bytes each) sit behind the two E-partial buffers.  A pipelined launch leaves its counter
+// at zero, so they are cleared once per proof -- by the launch that stores the initial sponge (sponge_to_device), not by a
+// memset of their own.
+static inline uint64_t *epart_counters(uint64_t *d_epart) { return d_epart + 2 * (kEpartBytes / 8); }
 // The proof being assembled is ONE device block [round polys | challenges | factor values at the point] so that it comes
 // back in one copy (through pinned memory: a device-to-pageable copy blocks the host once per call).
 static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint32_t D, const DeviceChain *chain = nullptr) {
@@ -847,15 +847,13 @@ static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint
         ps.d_rp = chain->d_rp;
         ps.d_ch = chain->d_ch;
         ps.d_final = chain->d_final;
+        ps.d_epart = chain->d_epart;
         ZKCHK(pool_alloc(c, 2 * kChallengeBytes, (void **)&ps.d_challenge));
-        ZKCHK(pool_alloc(c, 2 * kEpartBytes + 16, (void **)&ps.d_epart));
-        ZKCHK(epart_counters_zero(c, ps.d_epart));
         return ZK_OK;
     }
     ZKCHK(pool_alloc(c, sizeof(WordSponge), (void **)&ps.d_sponge));
     ZKCHK(pool_alloc(c, 2 * kChallengeBytes, (void **)&ps.d_challenge));
-    ZKCHK(pool_alloc(c, 2 * kEpartBytes + 16, (void **)&ps.d_epart));
-    ZKCHK(epart_counters_zero(c, ps.d_epart));   // the last-block-done counters start at zero
+    ZKCHK(pool_alloc(c, 2 * kEpartBytes + 16, (void **)&ps.d_epart));   // counters: cleared by sponge_to_device
     ZKCHK(pool_alloc(c, ps.rp_bytes + ps.ch_bytes + kMaxFactors * 32, (void **)&ps.d_rp));
     ps.d_ch = ps.d_rp + ps.rp_bytes / 8;
     ps.d_final = ps.d_ch + ps.ch_bytes / 8;
@@ -864,7 +862,6 @@ static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint
 static void scratch_free(zk_ctx *c, ProverScratch &ps) {
     if (ps.external) {
         pool_free(c, ps.d_challenge, 2 * kChallengeBytes);
-        pool_free(c, ps.d_epart, 2 * kEpartBytes + 16);
         ps = {};
         return;
     }
@@ -1555,10 +1552,11 @@ static int32_t prover_step(RoundState &st, bool *finished_in_kernel) {
 
 // host byte sponge (table + claimed sum absorbed) -> device word sponge.  The 208-byte state travels as a kernel argument:
 // no staging buffer, no copy engine, no host synchronisation in front of the first round.
-static int32_t sponge_to_device(zk_ctx *c, const Sponge &host, WordSponge *d_sponge) {
+// d_epart: the E-partial block whose two counters the same launch clears (every proof starts with this launch)
+static int32_t sponge_to_device(zk_ctx *c, const Sponge &host, WordSponge *d_sponge, uint64_t *d_epart) {
     WordSponge w;
     if (!w.from_byte_sponge(host)) return ZK_ERR_BAD_ARG;
-    k_store_sponge<<<1, 64, 0, c->stream>>>(w, d_sponge);
+    k_store_sponge<<<1, 64, 0, c->stream>>>(w, d_sponge, d_epart ? epart_counters(d_epart) : nullptr);
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
@@ -1623,7 +1621,7 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
     st.terms = ts;
     int32_t rc = ZK_OK;
     if (out_final) st.d_final = st.ps.d_final;
-    if (rc == ZK_OK) rc = sponge_to_device(c, sp, st.ps.d_sponge);
+    if (rc == ZK_OK) rc = sponge_to_device(c, sp, st.ps.d_sponge, st.ps.d_epart);
     bool finished_in_kernel = false;
     while (st.round < n && rc == ZK_OK) rc = prover_step(st, &finished_in_kernel);   // prover.rs:44-68, all on device
     // prover.rs:64 after the LAST round folds to a 0-variable polynomial the reference drops: computed only on request.
@@ -1750,7 +1748,7 @@ extern "C" int32_t zk_shard_prover_create(zk_ctx *c, zk_mle *const *f, uint64_t 
         Sponge host;
         host.init();
         absorb_elements(host, sum, 1, c->fi->P);   // prover.rs:42 -- the GLOBAL claimed sum, identical on every rank
-        rc = sponge_to_device(c, host, sp->st.ps.d_sponge);
+        rc = sponge_to_device(c, host, sp->st.ps.d_sponge, sp->st.ps.d_epart);
     }
     if (rc != ZK_OK) {
         (void)zk_shard_prover_destroy(sp);

@@ -629,12 +629,15 @@ __global__ __launch_bounds__(kBlock) void k_finish_terms(FactorPtrs fp, TermSpec
 }
 
 // the prover's initial sponge state, passed by value in the kernel arguments
-__global__ void k_store_sponge(WordSponge w, WordSponge *__restrict__ dst) {
+// zero2 (optional): two uint64 words cleared by the same launch (the pipelined rounds' last-block-done counters: a 16-byte
+// hipMemsetAsync is a launch of its own on the stream)
+__global__ void k_store_sponge(WordSponge w, WordSponge *__restrict__ dst, uint64_t *__restrict__ zero2) {
     if (threadIdx.x < 25) dst->s[threadIdx.x] = w.s[threadIdx.x];
     if (threadIdx.x == 0) {
         dst->pos = w.pos;
         dst->pad_ = 0;
     }
+    if (zero2 && threadIdx.x >= 32 && threadIdx.x < 34) zero2[threadIdx.x - 32] = 0;
 }
 
 // Sharded prover, after the all-reduce: lanes hold sums over ranks of 32-bit digits.  Carry-propagate, reduce mod p
