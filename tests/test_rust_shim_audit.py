@@ -186,3 +186,39 @@ def test_index_pair_formula_matches_the_reference_kats():
     assert "let pos = n_vars - 1 - index;" in src
     assert "let left = ((j >> pos) << (pos + 1)) | (j & ((1usize << pos) - 1));" in src
     assert "(left, left | (1usize << pos))" in src
+
+
+def test_delimiters_balance():
+    """No rustc here: at least every (), [] and {} of the shim closes in order (strings, chars, comments and lifetimes skipped)."""
+    src = open(SHIM).read()
+    stack, i, n = [], 0, len(src)
+    pairs = {")": "(", "]": "[", "}": "{"}
+    while i < n:
+        c = src[i]
+        if src.startswith("//", i):
+            i = src.index("\n", i) if "\n" in src[i:] else n
+            continue
+        if src.startswith("/*", i):
+            i = src.index("*/", i) + 2
+            continue
+        if c == '"':
+            i += 1
+            while src[i] != '"':
+                i += 2 if src[i] == "\\" else 1
+            i += 1
+            continue
+        if c == "'":
+            # a char literal ('x', '\n') or a lifetime ('static, 'a): a literal closes within four characters
+            close = src.find("'", i + 1, i + 5)
+            if close != -1 and (close == i + 2 or src[i + 1] == "\\"):
+                i = close + 1
+            else:
+                i += 1
+            continue
+        if c in "([{":
+            stack.append((c, src.count("\n", 0, i) + 1))
+        elif c in ")]}":
+            assert stack and stack[-1][0] == pairs[c], f"unbalanced {c!r} at line {src.count(chr(10), 0, i) + 1}"
+            stack.pop()
+        i += 1
+    assert not stack, f"unclosed {stack[-1][0]!r} opened at line {stack[-1][1]}"
