@@ -63,6 +63,113 @@ ZK_HD void mac(Acc &acc, uint32_t a, uint32_t b) {
     acc.lh = s;
 #endif
 }
+// acc += sum_{i<N} a[i] * b[-i]  (b points at the FIRST product's second operand and is walked downwards: one column of a
+// product-scanning multiplication).  ONE asm statement for the whole column: between separate asm statements the compiler
+// pads with s_nop (it cannot see that the next statement does not read the vcc this one wrote) -- 64 of them per 256 x 256-bit
+// product, 30 % of the instructions of the sums-only round kernel's loop.
+template <int N>
+ZK_HD void mac_col(Acc &acc, const uint32_t *a, const uint32_t *b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM)
+#define ZK_MAC_PAIR(A, B) "v_mad_u64_u32 %0, vcc, " A ", " B ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+    if constexpr (N == 1) {
+        asm(ZK_MAC_PAIR("%2", "%3")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(b[0])
+            : "vcc");
+    } else if constexpr (N == 2) {
+        asm(ZK_MAC_PAIR("%2", "%4") ZK_MAC_PAIR("%3", "%5")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[-1])
+            : "vcc");
+    } else if constexpr (N == 3) {
+        asm(ZK_MAC_PAIR("%2", "%5") ZK_MAC_PAIR("%3", "%6") ZK_MAC_PAIR("%4", "%7")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[-1]), "v"(b[-2])
+            : "vcc");
+    } else if constexpr (N == 4) {
+        asm(ZK_MAC_PAIR("%2", "%6") ZK_MAC_PAIR("%3", "%7") ZK_MAC_PAIR("%4", "%8") ZK_MAC_PAIR("%5", "%9")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[-1]), "v"(b[-2]), "v"(b[-3])
+            : "vcc");
+    } else if constexpr (N == 5) {
+        asm(ZK_MAC_PAIR("%2", "%7") ZK_MAC_PAIR("%3", "%8") ZK_MAC_PAIR("%4", "%9") ZK_MAC_PAIR("%5", "%10") ZK_MAC_PAIR("%6", "%11")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(b[0]), "v"(b[-1]), "v"(b[-2]), "v"(b[-3]), "v"(b[-4])
+            : "vcc");
+    } else if constexpr (N == 6) {
+        asm(ZK_MAC_PAIR("%2", "%8") ZK_MAC_PAIR("%3", "%9") ZK_MAC_PAIR("%4", "%10") ZK_MAC_PAIR("%5", "%11") ZK_MAC_PAIR("%6", "%12") ZK_MAC_PAIR("%7", "%13")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(b[0]), "v"(b[-1]), "v"(b[-2]), "v"(b[-3]), "v"(b[-4]), "v"(b[-5])
+            : "vcc");
+    } else if constexpr (N == 7) {
+        asm(ZK_MAC_PAIR("%2", "%9") ZK_MAC_PAIR("%3", "%10") ZK_MAC_PAIR("%4", "%11") ZK_MAC_PAIR("%5", "%12") ZK_MAC_PAIR("%6", "%13") ZK_MAC_PAIR("%7", "%14") ZK_MAC_PAIR("%8", "%15")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(b[0]), "v"(b[-1]), "v"(b[-2]), "v"(b[-3]), "v"(b[-4]), "v"(b[-5]), "v"(b[-6])
+            : "vcc");
+    } else {
+        static_assert(N == 8, "a column of an 8 x 8 limb product has at most 8 terms");
+        asm(ZK_MAC_PAIR("%2", "%10") ZK_MAC_PAIR("%3", "%11") ZK_MAC_PAIR("%4", "%12") ZK_MAC_PAIR("%5", "%13") ZK_MAC_PAIR("%6", "%14") ZK_MAC_PAIR("%7", "%15") ZK_MAC_PAIR("%8", "%16") ZK_MAC_PAIR("%9", "%17")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b[0]), "v"(b[-1]), "v"(b[-2]), "v"(b[-3]), "v"(b[-4]), "v"(b[-5]), "v"(b[-6]), "v"(b[-7])
+            : "vcc");
+    }
+#undef ZK_MAC_PAIR
+#else
+    for (int i = 0; i < N; ++i) mac(acc, a[i], b[-i]);
+#endif
+}
+// the same with the b operands wave-uniform (modulus limbs): they stay in SGPRs (one scalar source per instruction)
+template <int N>
+ZK_HD void mac_col_s(Acc &acc, const uint32_t *a, const uint32_t *b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM)
+#define ZK_MAC_PAIR(A, B) "v_mad_u64_u32 %0, vcc, " A ", " B ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+    if constexpr (N == 1) {
+        asm(ZK_MAC_PAIR("%2", "%3")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "s"(b[0])
+            : "vcc");
+    } else if constexpr (N == 2) {
+        asm(ZK_MAC_PAIR("%2", "%4") ZK_MAC_PAIR("%3", "%5")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(a[1]), "s"(b[0]), "s"(b[-1])
+            : "vcc");
+    } else if constexpr (N == 3) {
+        asm(ZK_MAC_PAIR("%2", "%5") ZK_MAC_PAIR("%3", "%6") ZK_MAC_PAIR("%4", "%7")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "s"(b[0]), "s"(b[-1]), "s"(b[-2])
+            : "vcc");
+    } else if constexpr (N == 4) {
+        asm(ZK_MAC_PAIR("%2", "%6") ZK_MAC_PAIR("%3", "%7") ZK_MAC_PAIR("%4", "%8") ZK_MAC_PAIR("%5", "%9")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "s"(b[0]), "s"(b[-1]), "s"(b[-2]), "s"(b[-3])
+            : "vcc");
+    } else if constexpr (N == 5) {
+        asm(ZK_MAC_PAIR("%2", "%7") ZK_MAC_PAIR("%3", "%8") ZK_MAC_PAIR("%4", "%9") ZK_MAC_PAIR("%5", "%10") ZK_MAC_PAIR("%6", "%11")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "s"(b[0]), "s"(b[-1]), "s"(b[-2]), "s"(b[-3]), "s"(b[-4])
+            : "vcc");
+    } else if constexpr (N == 6) {
+        asm(ZK_MAC_PAIR("%2", "%8") ZK_MAC_PAIR("%3", "%9") ZK_MAC_PAIR("%4", "%10") ZK_MAC_PAIR("%5", "%11") ZK_MAC_PAIR("%6", "%12") ZK_MAC_PAIR("%7", "%13")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "s"(b[0]), "s"(b[-1]), "s"(b[-2]), "s"(b[-3]), "s"(b[-4]), "s"(b[-5])
+            : "vcc");
+    } else if constexpr (N == 7) {
+        asm(ZK_MAC_PAIR("%2", "%9") ZK_MAC_PAIR("%3", "%10") ZK_MAC_PAIR("%4", "%11") ZK_MAC_PAIR("%5", "%12") ZK_MAC_PAIR("%6", "%13") ZK_MAC_PAIR("%7", "%14") ZK_MAC_PAIR("%8", "%15")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "s"(b[0]), "s"(b[-1]), "s"(b[-2]), "s"(b[-3]), "s"(b[-4]), "s"(b[-5]), "s"(b[-6])
+            : "vcc");
+    } else {
+        static_assert(N == 8, "a column of an 8 x 8 limb product has at most 8 terms");
+        asm(ZK_MAC_PAIR("%2", "%10") ZK_MAC_PAIR("%3", "%11") ZK_MAC_PAIR("%4", "%12") ZK_MAC_PAIR("%5", "%13") ZK_MAC_PAIR("%6", "%14") ZK_MAC_PAIR("%7", "%15") ZK_MAC_PAIR("%8", "%16") ZK_MAC_PAIR("%9", "%17")
+            : "+v"(acc.lh), "+v"(acc.ex)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "s"(b[0]), "s"(b[-1]), "s"(b[-2]), "s"(b[-3]), "s"(b[-4]), "s"(b[-5]), "s"(b[-6]), "s"(b[-7])
+            : "vcc");
+    }
+#undef ZK_MAC_PAIR
+#else
+    for (int i = 0; i < N; ++i) mac(acc, a[i], b[-i]);
+#endif
+}
 // acc += a*b with b wave-uniform (modulus limbs, the fold challenge): b stays in an SGPR
 ZK_HD void mac_s(Acc &acc, uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM)
@@ -77,6 +184,16 @@ ZK_HD void mac_s(Acc &acc, uint32_t a, uint32_t b) {
 }
 // acc += x (32-bit)
 ZK_HD void acc_add32(Acc &acc, uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM)
+    // x * 1 through the same mad + addc pair as a product: 12 cycles where the add_co / addc / addc chain the compiler emits is
+    // 12 cycles plus two s_nop 1 (gfx950 pads every VALU-written carry before the VALU that reads it)
+    asm("v_mad_u64_u32 %0, vcc, %2, 1, %0\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc.lh), "+v"(acc.ex)
+        : "v"(x)
+        : "vcc");
+    return;
+#endif
     uint32_t c0, c1;
     uint32_t lo = __builtin_addc((uint32_t)acc.lh, x, 0u, &c0);
     uint32_t hi = __builtin_addc((uint32_t)(acc.lh >> 32), 0u, c0, &c1);
@@ -161,41 +278,41 @@ ZK_HD Fe fe_one(const FieldParams &P) {
 
 // ---- multiplication -------------------------------------------------------------------------------------
 // t[0..16) = a * b   (full 512-bit product, product scanning)
+template <int C>
+ZK_HD void mul_wide_col(uint32_t t[16], Acc &acc, const uint32_t a[8], const uint32_t b[8]) {
+    constexpr int lo = C < 8 ? 0 : C - 7, hi = C < 8 ? C : 7;
+    mac_col<hi - lo + 1>(acc, a + lo, b + (C - lo));
+    t[C] = acc_shift(acc);
+    if constexpr (C + 1 < 15) mul_wide_col<C + 1>(t, acc, a, b);
+}
 ZK_HD void mul_wide(uint32_t t[16], const uint32_t a[8], const uint32_t b[8]) {
     Acc acc = {0, 0};
-#pragma unroll
-    for (int c = 0; c < 15; ++c) {
-        const int lo = c < 8 ? 0 : c - 7;
-        const int hi = c < 8 ? c : 7;
-#pragma unroll
-        for (int i = lo; i <= hi; ++i) mac(acc, a[i], b[c - i]);
-        t[c] = acc_shift(acc);
-    }
+    mul_wide_col<0>(t, acc, a, b);
     t[15] = (uint32_t)acc.lh;
 }
 
+// the 16 columns of a word-serial Montgomery reduction: columns 0..7 fix the multipliers m[c], columns 8..15 give the result
+template <int C>
+ZK_HD void redc_cols(const uint32_t *t, uint32_t (&m)[8], uint32_t *out8, Acc &acc, const FieldParams &P) {
+    acc_add32(acc, t[C]);
+    if constexpr (C < 8) {
+        if constexpr (C > 0) mac_col_s<C>(acc, m, P.p + C);   // sum_{i<C} m[i] * p[C-i]
+        m[C] = (uint32_t)acc.lh * P.inv;
+        mac_s(acc, m[C], P.p[0]);
+        (void)acc_shift(acc);   // low word is zero by construction
+    } else {
+        if constexpr (C < 15) mac_col_s<15 - C>(acc, m + (C - 7), P.p + 7);   // sum_{i=C-7..7} m[i] * p[C-i]
+        out8[C - 8] = acc_shift(acc);
+    }
+    if constexpr (C + 1 < 16) redc_cols<C + 1>(t, m, out8, acc, P);
+}
 // Montgomery reduction of a 512-bit value t < p*R (+ slack, see `extra`): returns t * R^-1 mod p, fully reduced.
 // `top` is an optional 17th limb of weight 2^512 already folded by the caller (see redc_wide).
 ZK_HD Fe redc(const uint32_t t[16], const FieldParams &P) {
     uint32_t m[8];
     Acc acc = {0, 0};
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        acc_add32(acc, t[c]);
-#pragma unroll
-        for (int i = 0; i < c; ++i) mac_s(acc, m[i], P.p[c - i]);
-        m[c] = (uint32_t)acc.lh * P.inv;
-        mac_s(acc, m[c], P.p[0]);
-        (void)acc_shift(acc);   // low word is zero by construction
-    }
     Fe s;
-#pragma unroll
-    for (int c = 8; c < 16; ++c) {
-        acc_add32(acc, t[c]);
-#pragma unroll
-        for (int i = c - 7; i < 8; ++i) mac_s(acc, m[i], P.p[c - i]);
-        s.v[c - 8] = acc_shift(acc);
-    }
+    redc_cols<0>(t, m, s.v, acc, P);
     // result = s + carry*2^256 < 2p when t < p*R
     uint32_t carry = (uint32_t)acc.lh;
     Fe d, r;
@@ -265,17 +382,17 @@ ZK_HD void wide_zero(WideAcc &w) {
     for (int i = 0; i < 17; ++i) w.v[i] = 0;
 }
 // w += a*b  (unreduced; product scanning straight into the running sum)
+template <int C>
+ZK_HD void wide_mac_col(WideAcc &w, Acc &acc, const uint32_t a[8], const uint32_t b[8]) {
+    constexpr int lo = C < 8 ? 0 : C - 7, hi = C < 8 ? C : 7;
+    acc_add32(acc, w.v[C]);
+    mac_col<hi - lo + 1>(acc, a + lo, b + (C - lo));
+    w.v[C] = acc_shift(acc);
+    if constexpr (C + 1 < 15) wide_mac_col<C + 1>(w, acc, a, b);
+}
 ZK_HD void wide_mac(WideAcc &w, const uint32_t a[8], const uint32_t b[8]) {
     Acc acc = {0, 0};
-#pragma unroll
-    for (int c = 0; c < 15; ++c) {
-        const int lo = c < 8 ? 0 : c - 7;
-        const int hi = c < 8 ? c : 7;
-        acc_add32(acc, w.v[c]);
-#pragma unroll
-        for (int i = lo; i <= hi; ++i) mac(acc, a[i], b[c - i]);
-        w.v[c] = acc_shift(acc);
-    }
+    wide_mac_col<0>(w, acc, a, b);
     acc_add32(acc, w.v[15]);
     w.v[15] = acc_shift(acc);
     w.v[16] += (uint32_t)acc.lh;
@@ -287,23 +404,8 @@ ZK_HD void wide_mac(WideAcc &w, const uint32_t a[8], const uint32_t b[8]) {
 ZK_HD Fe redc_wide(const WideAcc &w, const FieldParams &P) {
     uint32_t m[8];
     Acc acc = {0, 0};
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        acc_add32(acc, w.v[c]);
-#pragma unroll
-        for (int i = 0; i < c; ++i) mac_s(acc, m[i], P.p[c - i]);
-        m[c] = (uint32_t)acc.lh * P.inv;
-        mac_s(acc, m[c], P.p[0]);
-        (void)acc_shift(acc);
-    }
     uint32_t s[9];
-#pragma unroll
-    for (int c = 8; c < 16; ++c) {
-        acc_add32(acc, w.v[c]);
-#pragma unroll
-        for (int i = c - 7; i < 8; ++i) mac_s(acc, m[i], P.p[c - i]);
-        s[c - 8] = acc_shift(acc);
-    }
+    redc_cols<0>(w.v, m, s, acc, P);
     s[8] = (uint32_t)acc.lh;
     // s += top * (R mod p)
     {
