@@ -1,8 +1,11 @@
 #!/bin/bash
-# A/B of two builds on the same box: alternate, 3 rounds
+# Same-box A/B of library builds: put the variants at ab_tmp/libzk_<name>.so (ab_tmp/ travels with gpurun), then on the GPU box:
+#   bash tools/ab_libs.sh old new        -> three alternating rounds of the n = 24 / n = 20 / k = 3 provers and the GKR driver
+# (box-to-box spread is ~3 %, so variants are only comparable inside one call).  Restores nothing: rebuild afterwards.
+set -u
 for r in 1 2 3; do
-  for v in new2 new3; do
-    cp ab_tmp/libzk_$v.so zk_amd/libzk_amd.so
+  for v in "$@"; do
+    cp ab_tmp/libzk_$v.so zk_amd/libzk_amd.so || exit 1
     echo "== $v: $(python3 tools/prof_sumcheck.py 24 8 | tail -1)"
     echo "== $v: $(python3 tools/prof_sumcheck.py 20 8 | tail -1)"
     echo "== $v: $(python3 tools/prof_k3.py 20 | tail -1)"
