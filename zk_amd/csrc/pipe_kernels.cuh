@@ -275,12 +275,18 @@ ZK_D void pipe_tail_block(const PipeTailArgs &ta, const FieldParams &P) {
     LaneSponge sp = {0, 0};
     if (wave0) dbg_stamp(ta.dbg, 0);
     if (wave0) sp = lane_sponge_load(ta.sponge, L);   // in flight while the partials are reduced
-    if (ta.nblocks == 1) {   // already reduced (the last work block of the launch before did it): no barrier, no other wave
-        if (!wave0) return;
-        if (lane < 16 && lane < ta.n_in) red[lane] = fe_load(ta.partials, lane);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (ta.nblocks == 1) {   // already reduced (the last work block of the launch before did it)
+        if (wave >= 2) return;
+        if (wave0 && lane < 16 && lane < ta.n_in) red[lane] = fe_load(ta.partials, lane);
     } else {
         pipe_reduce_partials(ta.partials, ta.nblocks, ta.n_in, red, stage, P);
+        if (wave >= 2) return;
     }
+    // wave 0: the transcript step.  wave 1: waits for the digest and converts it to the Montgomery form the proof records,
+    // while wave 0 goes on with the multiplier form the next launch needs (one carry-free multiplication each)
+    __shared__ Fe digest_x;
+    Fe x = fe_zero();
     if (wave0) {
         __builtin_amdgcn_s_setprio(3);
         dbg_stamp(ta.dbg, 1);
@@ -321,12 +327,18 @@ ZK_D void pipe_tail_block(const PipeTailArgs &ta, const FieldParams &P) {
             fe_store(ta.out_rp, lane, s);
         }
         dbg_stamp(ta.dbg, 2);
-        Mul29 ch29;
-        const Fe ch = transcript_step(sp, L, fin, NS, P, ch29);
+        lane_absorb_elems(sp, L, fin, NS, P);
+        x = lane_squeeze_x(sp, L);
+        if (lane == 0) digest_x = x;
         dbg_stamp(ta.dbg, 3);
-        publish_challenge(ta.chal_out, ta.out_ch, ch, ch29, L.lane);
+    }
+    __syncthreads();   // waves 0 and 1 (the others have left)
+    if (wave0) {
+        publish_challenge29(ta.chal_out, challenge29_of(x, P), L.lane);
         lane_sponge_store(ta.sponge, sp, L);
         dbg_stamp(ta.dbg, 4);
+    } else {
+        publish_challenge_fe(ta.chal_out, ta.out_ch, challenge_fe_of(digest_x, P), (int)lane);
     }
 }
 
@@ -442,10 +454,11 @@ struct FinLds {   // carved from the dynamic region (32-byte aligned offsets)
     Fe (*st16)[16];                  // [16 waves][16]
     Fe *red;                         // [16]
     Fe *fin;                         // [4]
+    Fe *xr;                          // [2] by round parity: the raw digest of the round's squeeze (for the Montgomery conversion)
     Mul29 *r29;                      // [2] by round parity
     ZK_D uint32_t *red_u32() const { return reinterpret_cast<uint32_t *>(red); }
 };
-constexpr size_t kFinMiscBytes = kFinStageBytes + sizeof(Fe) * (2 * kFinWorkWaves * 16 + kFinWorkWaves * 16 + 16 * 16 + 16 + 4) + 2 * sizeof(Mul29) + 64;
+constexpr size_t kFinMiscBytes = kFinStageBytes + sizeof(Fe) * (2 * kFinWorkWaves * 16 + kFinWorkWaves * 16 + 16 * 16 + 16 + 4 + 2) + 2 * sizeof(Mul29) + 64;
 
 // One pass set of the work rows over the pair indices j < q of the NEXT round.  src: tables with 8q (FOLD: folded at r into
 // the 4q-element tables dst first) or 4q elements per factor.
@@ -528,6 +541,8 @@ __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs f
     carve += sizeof(Fe) * 16;
     S.fin = reinterpret_cast<Fe *>(carve);
     carve += sizeof(Fe) * 4;
+    S.xr = reinterpret_cast<Fe *>(carve);
+    carve += sizeof(Fe) * 2;
     S.r29 = reinterpret_cast<Mul29 *>(carve);
 
     const LaneKeccak L = lane_keccak_init();
@@ -637,6 +652,10 @@ __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs f
     // ---- uniform loop: close round `round` (its table has m - 1 variables) while the next one is prepared ----
     // rprev = challenge of round - 1 (folds the m-variable table into this round's)
     if (wave0) __builtin_amdgcn_s_setprio(3);   // the transcript wave is the critical path: first pick of issue slots / LDS
+    // the wave that turns digests into Montgomery-form challenges: the LAST work wave (the rows of a small round fill the work
+    // waves from the first one up, so it is the one most often idle); with no work wave at all, the transcript wave itself
+    const bool converter = n_work_waves ? (worker && my_work_wave == n_work_waves - 1) : wave0;
+    bool conv_pending = false;   // a round of this loop has squeezed a digest that is not converted yet
     while (m >= 2) {
         uint64_t *rdbg = dbg ? dbg + 16 * round : nullptr;
         if (wave0) {
@@ -650,21 +669,27 @@ __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs f
                 S.fin[lane] = s;
                 fe_store(out_rp, (uint64_t)round * NS + lane, s);
             }
-            Mul29 ch29;
-            const Fe ch = transcript_step(sp, L, S.fin, NS, P, ch29);
-            if (lane == 0) {
-                fe_store(out_ch, round, ch);
-                S.r29[round & 1] = ch29;
-            }
-            if (m == 2) publish_challenge(chal_last, nullptr, ch, ch29, (int)lane);
+            // the transcript wave keeps only what the next round needs: the multiplier form of the challenge.  The Montgomery form
+            // (the proof's record) is converted from the raw digest by the last work wave, one round later (below)
+            lane_absorb_elems(sp, L, S.fin, NS, P);
+            const Fe x = lane_squeeze_x(sp, L);
+            if (lane == 0) S.xr[round & 1] = x;
+            if (converter) publish_challenge_fe(nullptr, out_ch + 4 * (uint64_t)round, challenge_fe_of(x, P), (int)lane);   // no work wave exists
+            const Mul29 ch29 = challenge29_of(x, P);
+            if (lane == 0) S.r29[round & 1] = ch29;
+            if (m == 2) publish_challenge29(chal_last, ch29, (int)lane);
             dbg_stamp(rdbg, 3);
-        } else if (m >= 3 && worker) {
+        } else if (worker) {
+            if (converter && conv_pending) publish_challenge_fe(nullptr, out_ch + 4 * (uint64_t)(round - 1), challenge_fe_of(S.xr[(round - 1) & 1], P), (int)lane);
+            if (m >= 3) {
             if (my_work_wave == 0) dbg_stamp(rdbg, 8);
             const uint32_t q = 1u << (m - 3);
             if (src_global) fin_work<K, D, EXTRA, true, false>(gsrc, ltab, q, rprev, P, S.stage, S.ew[par ^ 1], S.pw, wl, n_work_waves);
             else fin_work<K, D, EXTRA, true, false>(ltab, ltab, q, rprev, P, S.stage, S.ew[par ^ 1], S.pw, wl, n_work_waves);
             if (my_work_wave == 0) dbg_stamp(rdbg, 9);
+            }
         }
+        conv_pending = true;
         __syncthreads();
         if (wave0) dbg_stamp(rdbg, 4);
         if (m >= 3) nact = fin_active_waves<K, D, EXTRA, false>(1u << (m - 3), n_work_waves);
@@ -678,6 +703,10 @@ __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs f
         --m;
     }
     if (wave0) lane_sponge_store(gsponge, sp, L);
+    if (converter && conv_pending) {   // the last round's challenge (the barrier that ended the loop has published its digest)
+        const Fe ch = challenge_fe_of(S.xr[(round - 1) & 1], P);
+        publish_challenge_fe(chal_last, out_ch + 4 * (uint64_t)(round - 1), ch, (int)lane);
+    }
     // out_final: the factors at the whole challenge point.  LDS holds the 4-element tables of the second-to-last round; they
     // are folded at the last two challenges (rprev = the last one; the one before sits in the other slot)
     if (out_final && tid < (uint32_t)NF) {

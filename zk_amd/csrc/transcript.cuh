@@ -181,9 +181,16 @@ ZK_D void lane_absorb_elems(LaneSponge &sp, const LaneKeccak &L, const Fe *sums,
         }
     }
 }
-// sample_field_element (transcript/src/lib.rs:20-30): squeeze one challenge; returned in Montgomery form (wave-uniform), ch29 =
-// its prepared multiplier form
-ZK_D Fe lane_squeeze(LaneSponge &sp, const LaneKeccak &L, const FieldParams &P, Mul29 &ch29) {
+// sample_field_element (transcript/src/lib.rs:20-30) in three pieces, so that a kernel can keep only what the NEXT round needs on
+// the transcript wave (a lone wave issues one instruction per ~10 cycles: every instruction there is on the critical path):
+//   lane_squeeze_x   : pad, permute, reset to the digest (transcript/src/lib.rs:22-23); returns int(digest, big endian) as a raw
+//                      256-bit integer x (wave-uniform), NOT reduced mod p
+//   challenge29_of(x): the prepared multiplier form of the challenge (what folds and the next evaluation read)
+//   challenge_fe_of(x): the challenge in Montgomery form (what the proof records) -- any wave may compute it later
+// No reduction of x first: the carry-free multiplier takes any 256-bit integer (nine 29-bit limbs hold 261 bits; a * c / 2^261
+// < 2^250 for a < 2^256, c < p, so the value is < 2p before its final conditional subtraction) and returns the canonical
+// representative of x * c * 2^-261 mod p either way; fe_reduce_u256's five conditional 9-limb subtractions are not needed.
+ZK_D Fe lane_squeeze_x(LaneSponge &sp, const LaneKeccak &L) {
     // squeeze: pad10*1 with Keccak's 0x01 domain byte, permute, digest = words 0..3
     if ((uint32_t)L.index == sp.pos) sp.a ^= 0x01ull;
     if (L.index == 16) sp.a ^= 0x8000000000000000ull;
@@ -193,40 +200,58 @@ ZK_D Fe lane_squeeze(LaneSponge &sp, const LaneKeccak &L, const FieldParams &P, 
     // finalize_reset + update(digest) (transcript/src/lib.rs:22-23): state = digest words, cursor 4
     sp.a = (L.index >= 0 && L.index < 4) ? sp.a : 0ull;
     sp.pos = 4;
-    // int(digest, big endian) mod p (transcript/src/lib.rs:29), then two independent carry-free multiplies by prepared
-    // constants give the challenge in Montgomery form (x * R) and its multiplier form (x * R * 2^5, split into 29-bit limbs)
+    // int(digest, big endian) (transcript/src/lib.rs:29)
     const uint64_t h[4] = {WordSponge::bswap64(d3), WordSponge::bswap64(d2), WordSponge::bswap64(d1), WordSponge::bswap64(d0)};
-    uint32_t x[8];
+    Fe x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        x[2 * i] = (uint32_t)h[i];
-        x[2 * i + 1] = (uint32_t)(h[i] >> 32);
+        x.v[2 * i] = (uint32_t)h[i];
+        x.v[2 * i + 1] = (uint32_t)(h[i] >> 32);
     }
-    const Fe xr = fe_reduce_u256(x, P);
-    Mul29 k0, k1;
+    return x;
+}
+ZK_D Mul29 challenge29_of(const Fe &x, const FieldParams &P) {
+    Mul29 k1, ch29;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        k0.l[i] = P.r2_29[i];       // prepare(R^2):        fe_mul29(x, k0) = x * R^2 * 2^-256       = x * R
-        k1.l[i] = P.r2s_29[i];      // prepare(R^2 * 2^5):  fe_mul29(x, k1) = x * R^2 * 2^5 * 2^-256 = (x * R) * 2^5
-    }
-    const Fe ch = fe_mul29(xr, k0, P);
-    const Fe chs = fe_mul29(xr, k1, P);
+    for (int i = 0; i < 9; ++i) k1.l[i] = P.r2s_29[i];   // prepare(R^2 * 2^5): fe_mul29(x, k1) = x * R^2 * 2^5 * 2^-256 = (x * R) * 2^5
+    const Fe chs = fe_mul29(x, k1, P);
     split29(chs.v, ch29.l);
-    return ch;
+    return ch29;
+}
+ZK_D Fe challenge_fe_of(const Fe &x, const FieldParams &P) {
+    Mul29 k0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k0.l[i] = P.r2_29[i];    // prepare(R^2): fe_mul29(x, k0) = x * R^2 * 2^-256 = x * R
+    return fe_mul29(x, k0, P);
+}
+// the three together: challenge in Montgomery form (wave-uniform), ch29 = its prepared multiplier form
+ZK_D Fe lane_squeeze(LaneSponge &sp, const LaneKeccak &L, const FieldParams &P, Mul29 &ch29) {
+    const Fe x = lane_squeeze_x(sp, L);
+    ch29 = challenge29_of(x, P);
+    return challenge_fe_of(x, P);
 }
 ZK_D Fe transcript_step(LaneSponge &sp, const LaneKeccak &L, const Fe *sums, uint32_t ns, const FieldParams &P, Mul29 &ch29) {
     lane_absorb_elems(sp, L, sums, ns, P);
     return lane_squeeze(sp, L, P, ch29);
 }
-// publish a challenge for the next round's fused fold: [Fe r][Mul29 of r] (common.cuh, kChallengeBytes)
-ZK_D void publish_challenge(uint64_t *d_challenge, uint64_t *out_ch, const Fe &ch, const Mul29 &ch29, int lane) {
+// publish a challenge for the next round's fused fold: [Fe r][Mul29 of r] (common.cuh, kChallengeBytes); the two halves may
+// come from different waves (publish_challenge29 from the transcript wave, publish_challenge_fe from whoever converts)
+ZK_D void publish_challenge29(uint64_t *d_challenge, const Mul29 &ch29, int lane) {
     if (lane == 0) {
-        fe_store(d_challenge, 0, ch);
         uint32_t *rec = reinterpret_cast<uint32_t *>(d_challenge) + 8;
 #pragma unroll
         for (int i = 0; i < 9; ++i) rec[i] = ch29.l[i];
+    }
+}
+ZK_D void publish_challenge_fe(uint64_t *d_challenge, uint64_t *out_ch, const Fe &ch, int lane) {
+    if (lane == 0) {
+        if (d_challenge) fe_store(d_challenge, 0, ch);
         if (out_ch) fe_store(out_ch, 0, ch);
     }
+}
+ZK_D void publish_challenge(uint64_t *d_challenge, uint64_t *out_ch, const Fe &ch, const Mul29 &ch29, int lane) {
+    publish_challenge_fe(d_challenge, out_ch, ch, lane);
+    publish_challenge29(d_challenge, ch29, lane);
 }
 ZK_D void transcript_round(WordSponge *gsp, const Fe *sums, uint32_t ns, uint64_t *d_challenge, uint64_t *out_ch,
                            const FieldParams &P) {
