@@ -44,13 +44,73 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(field):
-    """CPU restatement (oracle) of the same path on bounded samples, rank 0 at N = 1 only.  Faithful rows are single
-    threaded (the reference is); the "optimised" rows use every core of the box's share."""
+PROVER_SEED = 0x5EED0000   # + n: factor f of the n-variable prover is the generator stream [f << n, (f + 1) << n)
+
+
+def oracle_prover_rows(field, ns, tabs, claimed, cache):
+    """the CPU restatement's prove_partial (k = 2, D = 2) on `tabs`: faithful, single thread (prover.rs:33-73 as written)
+    and -- from 2^20 -- the fused OpenMP form, bit-compared with it.  Fills cache[ns] = {faithful_ms, fused_ms, threads, proof}."""
     import numpy as np
 
     from oracle import binding as orc
 
+    t1 = time.perf_counter()
+    want = orc.sumcheck_prove(field, ns, tabs, 2, claimed, False)
+    row = {"faithful_ms": (time.perf_counter() - t1) * 1e3, "proof": want}
+    if ns >= 20:
+        t1 = time.perf_counter()
+        rp, ch, used_p = orc.sumcheck_prove_fused_parallel(field, ns, tabs, 2, claimed, host_cores())
+        row["fused_ms"] = (time.perf_counter() - t1) * 1e3
+        row["threads"] = used_p
+        assert np.array_equal(rp, want[0]) and np.array_equal(ch, want[1]), "fused CPU prover differs from the faithful one"
+    cache[ns] = row
+    return row
+
+
+def parity_gate(ctx, field, table, out, r):
+    """BASELINE.md 3 / SURVEY 8d: "GPU output == CPU restatement output, limb for limb, on the timed inputs ... bit-compare
+    outputs before timing".  (a) the timed fold: all 2^23 outputs of partial_evaluate(0, [r]) on the timed 2^24 table against
+    the oracle's faithful fold (evaluation_form.rs:40-80); (b) the n = 20 and n = 24 proofs of the timed prover inputs (every
+    round polynomial and challenge) against the oracle's faithful prover (prover.rs:33-73).  The oracle runs of (b) are the
+    cpu_baseline's prover rows: same tables, one run.  Returns (gate dict, cache for cpu_baseline)."""
+    import numpy as np
+
+    import zk_amd
+    from oracle import binding as orc
+
+    gate, cache = {}, {}
+    table.fold_into(r, out)
+    tab = table.evaluation_slice()
+    t1 = time.perf_counter()
+    want = orc.mle_partial_evaluate(field, N_VARS, tab, 0, np.asarray(r).reshape(1, 4))
+    cache["fold_2p24_faithful_ms"] = (time.perf_counter() - t1) * 1e3
+    gate["fold_2p24"] = bool(np.array_equal(out.evaluation_slice(), want))
+    gate["generator_matches_oracle"] = bool(np.array_equal(tab[:1 << 16], orc.fill_random(field, 0x5EED0000 + 24, 1 << 16)))
+    del want, tab
+    for n in (20, 24):
+        polys = [zk_amd.MultiLinearPolynomial.random(ctx, n, PROVER_SEED + n, f << n) for f in range(2)]
+        tabs = [q.evaluation_slice() for q in polys]
+        pp = zk_amd.ProductPoly.new(polys)
+        s = pp.round_sums(1)
+        claimed = zk_amd.fe_from_int(field, zk_amd.fe_to_int(field, s[0]) + zk_amd.fe_to_int(field, s[1]))
+        proof, ch = zk_amd.SumcheckProver(2).prove_partial(pp, claimed)
+        row = oracle_prover_rows(field, n, tabs, claimed, cache)
+        gate[f"prove_n{n}"] = bool(np.array_equal(proof.round_polys, row["proof"][0]) and np.array_equal(ch, row["proof"][1]))
+        for q in polys:
+            q.free()
+        del tabs
+    return gate, cache
+
+
+def cpu_baseline(field, cache=None):
+    """CPU restatement (oracle) of the same path on bounded samples, rank 0 at N = 1 only.  Faithful rows are single
+    threaded (the reference is); the "optimised" rows use every core of the box's share.  The prover rows at n = 20 / 24 are
+    the parity gate's oracle runs when the gate ran (same tables as the GPU leg, bit-compared with it)."""
+    import numpy as np
+
+    from oracle import binding as orc
+
+    cache = dict(cache or {})
     ncores = host_cores()
     n = 21   # 2^21 elements = 64 MiB: same streaming pattern, bounded run time
     tab = orc.fill_random(field, 0x5EED0000 + 24, 1 << n)
@@ -75,19 +135,19 @@ def cpu_baseline(field):
     assert np.array_equal(out_par, out), "parallel CPU fold differs from the faithful fold"
     # the other half of the metric on the CPU: reference-faithful prover ((D+2)*k folds + (D+1) prod_reduce per round),
     # configs[0] (n = 12), configs[1] (n = 20) and configs[2]'s problem size (n = 24) of BASELINE.json
-    cpu_prove, cpu_fused = {}, {}
+    cpu_prove, cpu_fused, used_p = {}, {}, ncores
     for ns in (12, 16, 20, 24):
-        tabs = [orc.fill_random(field, 0x5EED0000 + ns + f, 1 << ns) for f in range(2)]
-        s = orc.fill_random(field, 5, 1)[0]
-        t1 = time.perf_counter()
-        want = orc.sumcheck_prove(field, ns, tabs, 2, s, False)
-        cpu_prove[ns] = (time.perf_counter() - t1) * 1e3
-        if ns >= 20:   # the optimised CPU prover row: fused rounds, OpenMP, bit-compared with the faithful one
-            t1 = time.perf_counter()
-            rp, ch, used_p = orc.sumcheck_prove_fused_parallel(field, ns, tabs, 2, s, ncores)
-            cpu_fused[ns] = (time.perf_counter() - t1) * 1e3
-            assert np.array_equal(rp, want[0]) and np.array_equal(ch, want[1]), "fused CPU prover differs from the faithful one"
-        del tabs
+        if ns not in cache:   # the same tables the GPU leg proves (bench.py: PROVER_SEED), claimed sum = the true sum
+            tabs = [orc.fill_random(field, PROVER_SEED + ns, 1 << ns, first_index=f << ns) for f in range(2)]
+            s = np.zeros(4, dtype=np.uint64)
+            for e in orc.prod_reduce(field, ns, tabs) if ns <= 16 else []:
+                s = orc.add(field, s, e)
+            oracle_prover_rows(field, ns, tabs, s, cache)
+            del tabs
+        cpu_prove[ns] = cache[ns]["faithful_ms"]
+        if "fused_ms" in cache[ns]:
+            cpu_fused[ns] = cache[ns]["fused_ms"]
+            used_p = cache[ns]["threads"]
     # the reference's own criterion bench on the CPU restatement: evaluate at 20 variables (n clone + fold + copy steps)
     t20 = orc.fill_random(field, 0x5EED0E00 + 20, 1 << 20)
     pt20 = orc.fill_random(field, 0xE7A1, 20)
@@ -115,6 +175,8 @@ def cpu_baseline(field):
         "sumcheck_prove_partial_ms_n16_k2_d2": cpu_prove[16],
         "sumcheck_prove_partial_ms_n20_k2_d2": cpu_prove[20],
         "sumcheck_prove_partial_ms_n24_k2_d2": cpu_prove[24],
+        "prover_rows_source": ("the parity gate's oracle runs: the SAME tables and claimed sums the GPU leg proves, proofs "
+                               "bit-compared" if cache.get("from_gate") else "same generator tables as the GPU leg (gate not run)"),
         "fft_faithful_recursive_ms": {f"2p{lg}": v for lg, v in fft_ms.items()},
         "fft_faithful_recursive_ms_2p24_extrapolated": fft_2p24_est,
         "fft_extrapolation": "T(2^24) = T(2^20) * 16 * (24/20)^2: n*log2(n)/2 butterflies, each two pow() of ~log2(n) multiplies",
@@ -166,6 +228,181 @@ def pmc_traffic():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def _field_sum(zk_amd, field, elems):
+    p = zk_amd.modulus(field)
+    return zk_amd.fe_from_int(field, sum(zk_amd.fe_to_int(field, e) for e in elems) % p)
+
+
+def sharded_leg(args, ctx, field, dist, torch, rank, world, ns, tdev, rehearse, result):
+    """N > 1 (and torchrun at N = 1): the n = 24, k = 2, D = 2 prover on tables sharded by index mod world
+    (zk_shard_prover_run: prover.rs:44-68 with one all-reduce per round).  The timing is only published when the proof is
+    RIGHT: (a) the claimed sum is the true sum (all ranks' local sums added), (b) the proof passes verify_partial and its
+    subclaim equals the product of the factors evaluated at the challenges (verifier.rs:15-33's final check, evaluated on the
+    shards), (c) on rank 0 it equals, bit for bit, the proof of the UNSHARDED 2^24 tables made on rank 0's own GPU."""
+    import numpy as np
+
+    import zk_amd
+    from zk_amd.distributed import GpuShardBackend, HostComm, RcclComm, ntt_sharded
+
+    ex = result.setdefault("extra", {})
+    lw = world.bit_length() - 1
+    n = ns + lw
+    comm = HostComm(ctx) if rehearse else RcclComm(ctx)
+    seeds = (0x5EED0100, 0x5EED0200)
+    shards = [zk_amd.MultiLinearPolynomial.random(ctx, ns, sd, first_index=rank << ns) for sd in seeds]
+
+    def gather_elems(local):   # (m, 4) uint64 per rank -> (world, m, 4) on every rank
+        t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.uint64).view(np.int64).copy()).to(tdev)
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return np.stack([o.cpu().numpy().view(np.uint64) for o in outs])
+
+    # (a) the true claimed sum: sum over ranks of the local S(0) + S(1)
+    s_loc = zk_amd.ProductPoly.new(shards).round_sums(1)
+    claimed = _field_sum(zk_amd, field, gather_elems(s_loc).reshape(-1, 4))
+
+    def run_once(gb, phases=False):
+        pp = zk_amd.ProductPoly.new([q.clone() for q in shards])
+        backend = GpuShardBackend(pp, 2, claimed, world, torch_stream=False)
+        ctx.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        res = backend.run_phases(comm, gb) if phases else backend.run(comm, gb)   # whole loop inside the library; synchronises
+        dt = time.perf_counter() - t1
+        backend.close()
+        for q in pp.polynomials:
+            q.free()
+        return res, dt
+
+    # gather_below g: rounds run sharded (one all-reduce each) while the local tables have more than 2^g elements, then one
+    # all-gather and the remaining rounds replicated.  Where the two meet depends on the fabric's small-message latency (a
+    # collective round costs two small launches + the all-reduce, a replicated one a round kernel on N x the data), so the
+    # line reports a few settings and names the best.
+    per_gb, proofs, phases_by_gb = {}, {}, {}
+    for gb in (10, 13, 16):
+        if gb >= ns:
+            continue
+        ts = []
+        for it in range(7):
+            (rp, ch), dt = run_once(gb)
+            ts.append(dt)
+        tt = torch.tensor([sorted(ts[2:])[len(ts[2:]) // 2]], dtype=torch.float64, device=tdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        per_gb[gb] = float(tt.item()) * 1e3
+        proofs[gb] = (rp, ch)
+        (_, _, ph), _ = run_once(gb, phases=True)
+        pt = torch.tensor([ph["local_kernels_ms"], ph["allreduce_ms"], ph["gather_ms"], ph["tail_rounds_ms"]], dtype=torch.float64,
+                          device=tdev)
+        dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+        phases_by_gb[gb] = dict(zip(("local_kernels_ms", "allreduce_ms", "gather_ms", "tail_rounds_ms"), [float(v) for v in pt.cpu()]))
+
+    # (b) every rank holds the same proof; it verifies; the subclaim is the product at the challenges (evaluated on the shards:
+    # the last lw variables select the rank -- index = local * world + rank -- so f(ch) = sum_r eq(ch[ns:], r) * f_r(ch[:ns]))
+    verified, same_all = bool(per_gb), True
+    p = zk_amd.modulus(field)
+    for gb, (rp, ch) in proofs.items():
+        all_ch = gather_elems(ch)
+        all_rp = gather_elems(rp.reshape(-1, 4))
+        same_all = same_all and all(np.array_equal(all_ch[q], all_ch[0]) and np.array_equal(all_rp[q], all_rp[0]) for q in range(world))
+        sub = zk_amd.SumcheckVerifier.verify_partial(field, zk_amd.SumcheckProof(claimed, rp))   # raises when a round check fails
+        vals = gather_elems(np.stack([q.evaluate(ch[:ns]) for q in shards]))                     # (world, k, 4)
+        cs = [zk_amd.fe_to_int(field, e) for e in ch[ns:]]
+        prod = 1
+        for f in range(len(shards)):
+            acc = 0
+            for q in range(world):
+                w = 1
+                for i, c_i in enumerate(cs):   # variable ns + i is bit (lw - 1 - i) of the rank
+                    w = w * (c_i if (q >> (lw - 1 - i)) & 1 else (1 - c_i)) % p
+                acc = (acc + w * zk_amd.fe_to_int(field, vals[q][f])) % p
+            prod = prod * acc % p
+        verified = verified and np.array_equal(sub.challenges, ch) and zk_amd.fe_to_int(field, sub.sum) == prod
+    vt = torch.tensor([int(verified and same_all)], device=tdev)
+    dist.all_reduce(vt, op=dist.ReduceOp.MIN)
+    verified_all = bool(vt.item())
+
+    # (c) rank 0: the unsharded tables (global index = local * world + rank) proved on one GPU give the same proof
+    equals_unsharded = None
+    if rank == 0 and per_gb:
+        full = []
+        for sd in seeds:
+            host = np.empty((1 << n, 4), dtype=np.uint64)
+            for q in range(world):
+                t = zk_amd.MultiLinearPolynomial.random(ctx, ns, sd, first_index=q << ns)
+                host[q::world] = t.evaluation_slice()
+                t.free()
+            full.append(zk_amd.MultiLinearPolynomial.new(ctx, n, host))
+            del host
+        proof_u, ch_u = zk_amd.SumcheckProver(2).prove_partial(zk_amd.ProductPoly.new(full), claimed)
+        equals_unsharded = all(np.array_equal(proof_u.round_polys, rp) and np.array_equal(ch_u, ch) for rp, ch in proofs.values())
+        for q in full:
+            q.free()
+
+    # latency of the round's one collective: (D+1)*8 uint64 lanes, back to back on the stream
+    lanes = torch.zeros(24, dtype=torch.int64, device=tdev)
+    for _ in range(20):
+        dist.all_reduce(lanes)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(200):
+        dist.all_reduce(lanes)
+    torch.cuda.synchronize()
+    coll_us = (time.perf_counter() - t1) / 200 * 1e6
+    ok = verified_all and (equals_unsharded is not False)
+    if rank == 0 and per_gb:
+        key = f"n24_k2_d2_world{world}"
+        best = min(per_gb, key=per_gb.get)
+        ex["sharded_proof_verified"] = verified_all
+        ex["sharded_proof_identical_on_all_ranks"] = same_all
+        ex["sharded_proof_equals_unsharded_proof"] = equals_unsharded
+        ex["parity_gate_sharded"] = {"proof_verified": verified_all, "equals_unsharded": equals_unsharded}
+        if ok:   # a wrong proof has no timing worth publishing
+            for gb, ms in per_gb.items():
+                ex[f"sharded_sumcheck_ms_{key}_gather_below{gb}"] = ms
+                ex[f"sharded_sumcheck_phases_ms_{key}_gather_below{gb}"] = phases_by_gb[gb]
+            ex[f"sharded_sumcheck_ms_{key}"] = per_gb[best]
+            ex["sharded_sumcheck_gather_below"] = best
+            ex["sharded_sumcheck_phases_note"] = ("HIP-event breakdown of a separate run (each event record stalls the stream a few "
+                                                  "us, so the phases add up to more than the timed run): max over ranks")
+            result.setdefault("sumcheck_prover_wall_clock_ms", {})[key] = per_gb[best]
+        else:
+            ex["sharded_error"] = "sharded proof wrong (not verified / differs from the unsharded proof): timing withheld"
+        ex["sharded_sumcheck_local_vars"] = ns
+        ex["sharded_sumcheck_collective_rounds"] = {gb: max(ns - gb, 0) for gb in per_gb}
+        ex["allreduce_24_lanes_latency_us"] = coll_us
+    # four-step NTT across the ranks (one all-to-all): the 2^24-point transform, 2^(24 - log2 N) points per rank; forward then
+    # inverse must give the input back on every rank
+    try:
+        xs = zk_amd.MultiLinearPolynomial.random(ctx, ns, 0x5EED0300, first_index=rank << ns)
+        y = ntt_sharded(comm, xs, False)
+        back = ntt_sharded(comm, y, True)
+        rt = torch.tensor([int(bool(back == xs))], device=tdev)
+        dist.all_reduce(rt, op=dist.ReduceOp.MIN)
+        y.free(); back.free()
+        ctx.synchronize()
+        tn = []
+        for it in range(5):
+            dist.barrier()
+            t1 = time.perf_counter()
+            y = ntt_sharded(comm, xs, False)
+            ctx.synchronize()
+            tn.append(time.perf_counter() - t1)
+            y.free()
+        tt = torch.tensor([sorted(tn)[2]], dtype=torch.float64, device=tdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            ex[f"sharded_ntt_ms_2p24_world{world}"] = float(tt.item()) * 1e3
+            ex["sharded_ntt_roundtrip_exact"] = bool(rt.item())
+    except Exception as e:
+        if rank == 0:
+            ex["sharded_ntt_error"] = repr(e)
+    for q in shards:
+        q.free()
+    ctx.synchronize()
+    comm.close()
+    return 0 if ok else 5
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +414,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-pmc", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true",
+                    help="skip the bit-compare of the timed fold and the timed prover inputs with the CPU oracle (profiler runs)")
+    ap.add_argument("--prewarm-ms", type=float, default=250.0,
+                    help="untimed folds before the W warm-up steps so that the shader clock has ramped (the parity gate leaves the "
+                         "GPU idle for seconds); reported in the line")
     args = ap.parse_args()
 
     import numpy as np
@@ -228,6 +470,25 @@ def main():
     r = tr.sample_field_element(field)       # a uniform challenge (not 0/1: generic path)
     ctx.synchronize()
 
+    # ---- parity gate: BEFORE anything is timed (rank 0, N = 1: the oracle is test infrastructure, the checker only)
+    gate, cpu_cache = None, {}
+    if rank == 0 and world == 1 and not args.no_parity_gate:
+        gate, cpu_cache = parity_gate(ctx, field, table, out, r)
+        cpu_cache["from_gate"] = True
+        if not all(gate.values()):
+            print(json.dumps({"metric": "field-ops/sec (MLE fold, 2^24 evals, BN254 Fr) + sumcheck prover wall-clock", "value": None,
+                              "error": "parity gate failed: the GPU path differs from the CPU oracle on the timed inputs; nothing timed",
+                              "parity_gate": gate}))
+            sys.exit(1)
+
+    # the gate (seconds of host work) leaves the GPU at idle clocks: ramp them before the W warm-up steps
+    prewarm_launches = 0
+    t_pw = time.perf_counter()
+    while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
+        for _ in range(64):
+            table.fold_into(r, out)
+        ctx.synchronize()
+        prewarm_launches += 64
     for _ in range(args.warmup):
         table.fold_into(r, out)
     ctx.synchronize()
@@ -270,6 +531,8 @@ def main():
                    "n_vars": N_VARS, "field": "bn254_fr", "elements_per_gpu": 1 << local_vars,
                    "shard": "index mod n_gpus (no collective in the fold)"},
         "timed_region_s": dt,
+        "parity_gate": gate if gate is not None else "not run (--no-parity-gate or N > 1: see sharded_proof_* there)",
+        "clock_prewarm": {"ms": args.prewarm_ms, "untimed_launches": prewarm_launches},
         "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
                      "kernel": "zk::k_fold_msb", "kernel_ms": kernel_ms, "kernel_ms_median": kernel_ms_median,
@@ -287,8 +550,9 @@ def main():
             # second half of the metric: sumcheck prover wall-clock, k=2, D=2: prove_partial (prover.rs:24-30) and prove
             # (prover.rs:15-20: the tables are serialised and absorbed first -- a serial host Keccak the reference mandates)
             for n in (20, 24):
-                A = zk_amd.MultiLinearPolynomial.random(ctx, n, 0x5EED0000 + n, 0)
-                B = zk_amd.MultiLinearPolynomial.random(ctx, n, 0x5EED0000 + n, 1 << n)
+                # the tables (and claimed sum) the parity gate proved with the oracle above: PROVER_SEED + n, factor f at f << n
+                A = zk_amd.MultiLinearPolynomial.random(ctx, n, PROVER_SEED + n, 0)
+                B = zk_amd.MultiLinearPolynomial.random(ctx, n, PROVER_SEED + n, 1 << n)
                 pp = zk_amd.ProductPoly.new([A, B])
                 s = pp.round_sums(1)
                 claimed = zk_amd.fe_from_int(field, zk_amd.fe_to_int(field, s[0]) + zk_amd.fe_to_int(field, s[1]))
@@ -420,107 +684,27 @@ def main():
         result["sumcheck_prover_wall_clock_ms"] = {k.replace("sumcheck_prove_partial_ms_", ""): v for k, v in extra.items()
                                                    if k.startswith("sumcheck_prove_partial_ms_")}
 
+    exit_code = 0
     if dist is not None and not args.no_extra:
         # BASELINE config 3: the n = 24 prover over the table sharded by index mod world: every rank holds 2^(24 - log2 N)
         # elements per factor; one RCCL all-reduce of (D+1)*8 lanes per round and one all-gather for the tail, all enqueued by
-        # zk_shard_prover_run on one stream.  This secondary measurement must never cost the headline line: if it stalls (a
-        # collective waiting on a rank that failed), a watchdog prints the line without it and ends every rank.
+        # zk_shard_prover_run on one stream.  A stalled collective (a rank that died) must not hang the job nor pass for a
+        # success: the watchdog prints the headline line with the error and ends EVERY rank with a non-zero code.
         import threading
 
         def _bail():
             if rank == 0:
-                result.setdefault("extra", {})["sharded_error"] = "sharded-prover extra timed out (watchdog)"
+                result.setdefault("extra", {})["sharded_error"] = "sharded-prover leg timed out (watchdog): a collective stalled"
                 print(json.dumps(result), flush=True)
-            os._exit(0)
+            os._exit(3)
 
-        watchdog = threading.Timer(180.0, _bail)
+        watchdog = threading.Timer(240.0, _bail)
         watchdog.daemon = True
         watchdog.start()
         try:
-            from zk_amd.distributed import GpuShardBackend, HostComm, RcclComm, ntt_sharded
-
-            ex = result.setdefault("extra", {})
-            comm = HostComm(ctx) if rehearse else RcclComm(ctx)
-            ns = local_vars
-            A = zk_amd.MultiLinearPolynomial.random(ctx, ns, 0x5EED0100, first_index=rank << ns)
-            B = zk_amd.MultiLinearPolynomial.random(ctx, ns, 0x5EED0200, first_index=rank << ns)
-            claimed = zk_amd.fe_from_int(field, 12345)   # timing only: the proof need not verify
-            # gather_below g: rounds run sharded (one all-reduce each) while the local tables have more than 2^g elements, then one
-            # all-gather and the remaining rounds replicated.  Where the two meet depends on the fabric's small-message latency
-            # (a collective round costs two small launches + the all-reduce, a replicated one a round kernel on N x the data),
-            # so the line reports a few settings and names the best.
-            per_gb = {}
-            same_all = True
-            for gb in (10, 13, 16):
-                if gb >= ns:
-                    continue
-                ts = []
-                for it in range(7):
-                    pp = zk_amd.ProductPoly.new([A.clone(), B.clone()])
-                    backend = GpuShardBackend(pp, 2, claimed, world, torch_stream=False)
-                    ctx.synchronize()
-                    dist.barrier()
-                    t1 = time.perf_counter()
-                    rp, ch = backend.run(comm, gb)       # whole loop inside the library; results() synchronises
-                    ts.append(time.perf_counter() - t1)
-                    backend.close()
-                    for q in pp.polynomials:
-                        q.free()
-                tt = torch.tensor([sorted(ts[2:])[len(ts[2:]) // 2]], dtype=torch.float64, device=tdev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                chk = torch.from_numpy(ch.view("int64").copy()).to(tdev)
-                ref = chk.clone()
-                dist.broadcast(ref, 0)
-                same = torch.tensor([int((chk == ref).all().item())], device=tdev)
-                dist.all_reduce(same, op=dist.ReduceOp.MIN)
-                same_all = same_all and bool(same.item())
-                per_gb[gb] = float(tt.item()) * 1e3
-            # latency of the round's one collective: (D+1)*8 uint64 lanes, back to back on the stream
-            lanes = torch.zeros(24, dtype=torch.int64, device=tdev)
-            for _ in range(20):
-                dist.all_reduce(lanes)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(200):
-                dist.all_reduce(lanes)
-            torch.cuda.synchronize()
-            coll_us = (time.perf_counter() - t1) / 200 * 1e6
-            if rank == 0 and per_gb:
-                key = f"n24_k2_d2_world{world}"
-                best = min(per_gb, key=per_gb.get)
-                for gb, ms in per_gb.items():
-                    ex[f"sharded_sumcheck_ms_{key}_gather_below{gb}"] = ms
-                ex[f"sharded_sumcheck_ms_{key}"] = per_gb[best]
-                ex["sharded_sumcheck_gather_below"] = best
-                ex["sharded_sumcheck_local_vars"] = ns
-                ex["sharded_sumcheck_collective_rounds"] = max(ns - best, 0)
-                ex["sharded_challenges_identical_on_all_ranks"] = same_all
-                ex["allreduce_24_lanes_latency_us"] = coll_us
-                result.setdefault("sumcheck_prover_wall_clock_ms", {})[key] = per_gb[best]
-            A.free(); B.free()
-            # four-step NTT across the ranks (one all-to-all): the 2^24-point transform, 2^(24 - log2 N) points per rank
-            try:
-                xs = zk_amd.MultiLinearPolynomial.random(ctx, ns, 0x5EED0300, first_index=rank << ns)
-                ntt_sharded(comm, xs, False).free()
-                ctx.synchronize()
-                tn = []
-                for it in range(5):
-                    dist.barrier()
-                    t1 = time.perf_counter()
-                    y = ntt_sharded(comm, xs, False)
-                    ctx.synchronize()
-                    tn.append(time.perf_counter() - t1)
-                    y.free()
-                tt = torch.tensor([sorted(tn)[2]], dtype=torch.float64, device=tdev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                if rank == 0:
-                    ex[f"sharded_ntt_ms_2p24_world{world}"] = float(tt.item()) * 1e3
-            except Exception as e:
-                if rank == 0:
-                    ex["sharded_ntt_error"] = repr(e)
-            ctx.synchronize()
-            comm.close()
+            exit_code = sharded_leg(args, ctx, field, dist, torch, rank, world, local_vars, tdev, rehearse, result)
         except Exception as e:
+            exit_code = 4
             if rank == 0:
                 result.setdefault("extra", {})["sharded_error"] = repr(e)
         finally:
@@ -534,13 +718,18 @@ def main():
             result["roofline"]["traffic_over_algorithmic"] = traffic / ALG_BYTES_PER_FOLD
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(field)
+        result["cpu_baseline"] = cpu_baseline(field, cpu_cache)
+        if "fold_2p24_faithful_ms" in cpu_cache:
+            result["cpu_baseline"]["fold_2p24_faithful_ms"] = cpu_cache["fold_2p24_faithful_ms"]
 
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        if exit_code == 0:
+            dist.barrier()
+            dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+    if exit_code:
+        os._exit(exit_code)   # a failed sharded leg: every rank ends non-zero (no barrier: a peer may be gone)
 
 
 if __name__ == "__main__":

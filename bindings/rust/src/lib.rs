@@ -54,7 +54,11 @@ const ZK_ERR_FFT_NO_ROOT: i32 = -7;
 const ZK_ERR_VERIFY_SUM: i32 = -9;
 const ZK_ERR_GKR_REJECT: i32 = -27;
 
+/// The ABI revision this file was written against (`ZK_AMD_ABI_VERSION` in include/zk_amd.h); checked once per context.
+const ZK_AMD_ABI_VERSION: i32 = 4;
+
 extern "C" {
+    fn zk_abi_version() -> i32;
     fn zk_strerror(status: i32) -> *const c_char;
     fn zk_ctx_create(field: i32, device: i32, out_ctx: *mut *mut zk_ctx) -> i32;
     fn zk_ctx_destroy(ctx: *mut zk_ctx) -> i32;
@@ -83,6 +87,10 @@ extern "C" {
                                   out_subclaim_sum: *mut u64, out_challenges: *mut u64) -> i32;
     fn zk_sumcheck_verify(ctx: *mut zk_ctx, factors: *const *const zk_mle, k: u64, n_round_polys: u64, max_var_degree: u32,
                           sum: *const u64, round_polys: *const u64, out_ok: *mut i32) -> i32;
+    fn zk_sumcheck_verify_partial_lengths(field: i32, n_rounds: u64, evals_per_round: *const u32, sum: *const u64,
+                                          round_polys: *const u64, out_subclaim_sum: *mut u64, out_challenges: *mut u64) -> i32;
+    fn zk_sumcheck_verify_lengths(ctx: *mut zk_ctx, factors: *const *const zk_mle, k: u64, n_round_polys: u64,
+                                  evals_per_round: *const u32, sum: *const u64, round_polys: *const u64, out_ok: *mut i32) -> i32;
     fn zk_fft_host(ctx: *mut zk_ctx, input: *const u64, n: u64, out: *mut u64) -> i32;
     fn zk_ifft_host(ctx: *mut zk_ctx, input: *const u64, n: u64, out: *mut u64) -> i32;
     fn zk_fft_internal_host(ctx: *mut zk_ctx, input: *const u64, n: u64, omega: *const u64, out: *mut u64) -> i32;
@@ -108,6 +116,11 @@ pub trait GpuField: PrimeField {
 impl GpuField for ark_bn254::Fr { const ZK_FIELD: i32 = 0; }
 impl GpuField for ark_bls12_381::Fr { const ZK_FIELD: i32 = 1; }
 impl GpuField for ark_bls12_377::Fr { const ZK_FIELD: i32 = 2; }
+// `limbs()` below hands `&[F]` to C as `*const u64`: that is only sound while an element IS four u64 limbs.  Checked at
+// compile time for every field the library is bound to (polynomial/src/multilinear/evaluation_form.rs:7-10 stores Vec<F>).
+const _: () = assert!(std::mem::size_of::<ark_bn254::Fr>() == 32 && std::mem::align_of::<ark_bn254::Fr>() == 8);
+const _: () = assert!(std::mem::size_of::<ark_bls12_381::Fr>() == 32 && std::mem::align_of::<ark_bls12_381::Fr>() == 8);
+const _: () = assert!(std::mem::size_of::<ark_bls12_377::Fr>() == 32 && std::mem::align_of::<ark_bls12_377::Fr>() == 8);
 
 fn err(status: i32) -> &'static str {
     // zk_strerror returns pointers to static strings that reproduce the reference's own messages
@@ -129,6 +142,8 @@ fn ctx<F: GpuField>() -> Result<Rc<Ctx>, &'static str> {
         let mut slots = cell.borrow_mut();
         let slot = &mut slots[F::ZK_FIELD as usize];
         if let Some(c) = slot { return Ok(Rc::clone(c)); }
+        // a libzk_amd.so of another ABI revision must not be driven through these declarations
+        if unsafe { zk_abi_version() } != ZK_AMD_ABI_VERSION { return Err("zk_amd: libzk_amd.so ABI version mismatch"); }
         let device = std::env::var("ZK_AMD_DEVICE").ok().and_then(|s| s.parse::<i32>().ok()).unwrap_or(0);
         let mut raw: *mut zk_ctx = std::ptr::null_mut();
         let rc = unsafe { zk_ctx_create(F::ZK_FIELD, device, &mut raw) };
@@ -355,35 +370,37 @@ impl<const MAX_VAR_DEGREE: u8, F: GpuField> SumcheckProver<MAX_VAR_DEGREE, F> {
 pub struct SumcheckVerifier<F: GpuField> { _marker: PhantomData<F> }
 
 impl<F: GpuField> SumcheckVerifier<F> {
-    /// Round polynomials as one row-major array.  The C ABI takes one degree for the whole proof, which is what
-    /// SumcheckProver emits (MAX_VAR_DEGREE + 1 evaluations per round); a hand-made proof with rounds of different lengths
-    /// (the reference would interpolate each at its own degree, verifier.rs:58) is rejected as a failed round check.
-    fn flatten(proof: &SumcheckProof<F>) -> Result<(Vec<F>, u32), &'static str> {
-        let ns = proof.round_polys.first().map_or(1, |r| r.len());
-        if ns == 0 || proof.round_polys.iter().any(|r| r.len() != ns) { return Err(err(ZK_ERR_VERIFY_SUM)); }
-        Ok((proof.round_polys.iter().flatten().copied().collect(), (ns - 1) as u32))
+    /// `round_polys` is a `Vec<Vec<F>>` and the reference interpolates every round at its own length (verifier.rs:55-58):
+    /// the evaluations go to the library back to back with one length per round.
+    fn flatten(proof: &SumcheckProof<F>) -> (Vec<F>, Vec<u32>) {
+        let mut lens: Vec<u32> = proof.round_polys.iter().map(|r| r.len() as u32).collect();
+        lens.push(0);
+        let mut rps: Vec<F> = proof.round_polys.iter().flatten().copied().collect();
+        rps.push(F::zero());
+        (rps, lens)
     }
     /// verifier.rs:15-33
     pub fn verify(poly: ProductPoly<F>, proof: SumcheckProof<F>) -> Result<bool, &'static str> {
-        let (rps, degree) = Self::flatten(&proof)?;
+        let (rps, lens) = Self::flatten(&proof);
         let h = poly.handles();
         let s = [proof.sum];
         let mut ok = 0i32;
-        let rc = unsafe { zk_sumcheck_verify(poly.ctx_raw(), h.as_ptr(), h.len() as u64, proof.round_polys.len() as u64, degree,
-                                             limbs(&s), limbs(&rps), &mut ok) };
+        let rc = unsafe { zk_sumcheck_verify_lengths(poly.ctx_raw(), h.as_ptr(), h.len() as u64, proof.round_polys.len() as u64,
+                                                     lens.as_ptr(), limbs(&s), limbs(&rps), &mut ok) };
         if rc != 0 { return Err(err(rc)); } // "invalid proof: require 1 round poly ..." / "verifier check failed: ..."
         Ok(ok != 0)
     }
     /// verifier.rs:38-41
     pub fn verify_partial(proof: SumcheckProof<F>) -> Result<SubClaim<F>, &'static str> {
-        let (rps, degree) = Self::flatten(&proof)?;
+        let (rps, lens) = Self::flatten(&proof);
         let n = proof.round_polys.len();
         let s = [proof.sum];
         let mut sum = [F::zero()];
-        let mut challenges = vec![F::zero(); n];
-        let rc = unsafe { zk_sumcheck_verify_partial(F::ZK_FIELD, n as u64, degree, limbs(&s), limbs(&rps), limbs_mut(&mut sum),
-                                                     limbs_mut(&mut challenges)) };
+        let mut challenges = vec![F::zero(); n.max(1)];
+        let rc = unsafe { zk_sumcheck_verify_partial_lengths(F::ZK_FIELD, n as u64, lens.as_ptr(), limbs(&s), limbs(&rps),
+                                                             limbs_mut(&mut sum), limbs_mut(&mut challenges)) };
         if rc != 0 { return Err(err(rc)); }
+        challenges.truncate(n);
         Ok(SubClaim { sum: sum[0], challenges })
     }
 }

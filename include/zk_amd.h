@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define ZK_AMD_ABI_VERSION 3   /* 3: + zk_comm (RCCL / host), zk_shard_prover_run, zk_ntt_sharded, sample_n, zk_ctx_trim, zk_mle_equal */
+#define ZK_AMD_ABI_VERSION 4   /* 3: + zk_comm (RCCL / host), zk_shard_prover_run, zk_ntt_sharded, sample_n, zk_ctx_trim, zk_mle_equal
+                                  4: + zk_sumcheck_verify_lengths / _verify_partial_lengths (per-round degrees, verifier.rs:55-58) */
 
 typedef enum zk_field {
     ZK_FIELD_BN254_FR = 0,     /* north-star field (not a dependency of the reference: SURVEY D2) */
@@ -219,6 +220,14 @@ int32_t zk_comm_destroy(zk_comm *comm);
  * stream with ZERO host synchronisations (the all-reduce is the round's one collective); fetch the proof with
  * zk_shard_prover_results.  Every rank calls it with the same arguments. */
 int32_t zk_shard_prover_run(zk_shard_prover *sp, zk_comm *comm, uint32_t gather_below);
+/* The same run with a breakdown by HIP events on the stream (each record stalls the stream a few microseconds: a breakdown,
+ * not a timing): out_ms[0] local kernels of the exchanging rounds, [1] the per-round all-reduces, [2] the all-gather of the
+ * shard tails (with the pending fold), [3] the replicated tail rounds.  Synchronises. */
+int32_t zk_shard_prover_run_phases(zk_shard_prover *sp, zk_comm *comm, uint32_t gather_below, double out_ms[4]);
+/* Failure rule of the two collective entry points (zk_shard_prover_run*, zk_ntt_sharded): a rank whose local step fails
+ * between collectives aborts a communicator it created (ncclCommAbort, so its peers' pending collectives return an error
+ * instead of hanging) and returns the error; the zk_comm is dead afterwards -- every later call on it returns ZK_ERR_COMM --
+ * and must be destroyed.  A wrapped communicator (zk_comm_wrap_rccl) is only marked dead: aborting it is its owner's call. */
 /* fft / ifft (fft/src/lib.rs:4-19) of an N = world * 2^m point vector held as index-mod-world shards ("strided": rank r
  * holds x[r + world*j]); ONE all-to-all.  forward: strided in -> "sliced" out (rank s holds X[k], k mod M in its slice of
  * M / world, as world rows of M / world); inverse: sliced in -> strided out, scaled 1/N.  shard is not modified;
@@ -288,6 +297,18 @@ int32_t zk_sumcheck_verify_partial(int32_t field, uint64_t n_rounds, uint32_t ma
 int32_t zk_sumcheck_verify(zk_ctx *ctx, const zk_mle *const *factors, uint64_t k, uint64_t n_round_polys,
                            uint32_t max_var_degree, const uint64_t sum[4], const uint64_t *round_polys,
                            int32_t *out_ok);
+
+/* The same two with every round polynomial at ITS OWN length: SumcheckProof.round_polys is a Vec<Vec<F>> and
+ * verify_internal hands each round to UnivariatePolynomial::interpolate as it comes (verifier.rs:55-58,
+ * univariate_poly.rs:43-49), so a proof whose rounds carry different numbers of evaluations is legal input.
+ * evals_per_round[r] (<= 256; 0 = the zero polynomial, 1 = a constant) evaluations for round r, stored back to back in
+ * round_polys (sum of evals_per_round elements). */
+int32_t zk_sumcheck_verify_partial_lengths(int32_t field, uint64_t n_rounds, const uint32_t *evals_per_round,
+                                           const uint64_t sum[4], const uint64_t *round_polys,
+                                           uint64_t out_subclaim_sum[4], uint64_t *out_challenges);
+int32_t zk_sumcheck_verify_lengths(zk_ctx *ctx, const zk_mle *const *factors, uint64_t k, uint64_t n_round_polys,
+                                   const uint32_t *evals_per_round, const uint64_t sum[4], const uint64_t *round_polys,
+                                   int32_t *out_ok);
 
 /* ---- fft crate  (fft/src/lib.rs) ------------------------------------------------------------------------------ */
 /* fft :4-8 / ifft :11-19 on a device vector of 2^log_n elements (zk_mle doubles as the vector handle);

@@ -344,6 +344,39 @@ def sumcheck_verify(field, n_vars, tables, D, claimed_sum, round_polys):
     return bool(_check(rc))
 
 
+def _ragged(round_polys):
+    """list of per-round (len_r, 4) arrays -> (lens uint32, concatenated (sum len, 4) array)"""
+    rounds = [_arr(r).reshape(-1, 4) for r in round_polys]
+    lens = np.array([r.shape[0] for r in rounds], dtype=np.uint32)
+    flat = np.concatenate(rounds, axis=0) if rounds and int(lens.sum()) else np.zeros((1, 4), dtype=np.uint64)
+    return lens, np.ascontiguousarray(flat)
+
+
+def sumcheck_verify_partial_lengths(field, claimed_sum, round_polys, table_bytes=None):
+    """verify_partial on a proof whose rounds carry different numbers of evaluations (verifier.rs:55-58)"""
+    lens, flat = _ragged(round_polys)
+    n = len(lens)
+    s = _arr(claimed_sum, 1)
+    sub_ = np.zeros(4, dtype=np.uint64)
+    ch = np.zeros((max(n, 1), 4), dtype=np.uint64)
+    tb = bytes(table_bytes) if table_bytes is not None else None
+    fn = _lib.orc_sumcheck_verify_partial_lengths
+    fn.argtypes = [_c.c_int, _c.c_uint64, _c.c_void_p, _u64p, _u64p, _c.c_char_p, _c.c_size_t, _u64p, _u64p]
+    lens_buf = np.ascontiguousarray(np.append(lens, np.uint32(0)))
+    _check(fn(field, n, lens_buf.ctypes.data, _p(s), _p(flat), tb, len(tb) if tb else 0, _p(sub_), _p(ch)))
+    return sub_, ch[:n]
+
+
+def sumcheck_verify_lengths(field, n_vars, tables, claimed_sum, round_polys):
+    tabs, ptrs = _table_ptrs(tables, n_vars)
+    lens, flat = _ragged(round_polys)
+    s = _arr(claimed_sum, 1)
+    fn = _lib.orc_sumcheck_verify_lengths
+    fn.argtypes = [_c.c_int, _c.c_uint64, _c.c_uint64, type(ptrs), _c.c_uint64, _c.c_void_p, _u64p, _u64p]
+    lens_buf = np.ascontiguousarray(np.append(lens, np.uint32(0)))
+    return bool(_check(fn(field, len(tabs), n_vars, ptrs, len(lens), lens_buf.ctypes.data, _p(s), _p(flat))))
+
+
 # ---------------- fft ----------------
 def _fft_call(fn, field, values, *extra):
     v = _arr(values).reshape(-1, 4)
@@ -363,3 +396,13 @@ def ifft(field, values):
 
 def ntt_fast(field, values, inverse=False):
     return _fft_call(_lib.orc_ntt_fast, field, values, _c.c_int(int(inverse)))
+
+
+def dft_point(field, values, k, inverse=False):
+    """one output of fft / ifft from the definition sum_j values[j] * omega^(j*k) (fft/src/lib.rs:39-45)"""
+    v = _arr(values).reshape(-1, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    fn = _lib.orc_dft_point
+    fn.argtypes = [_c.c_int, _u64p, _c.c_uint64, _c.c_uint64, _c.c_int, _u64p]
+    _check(fn(field, _p(v), v.shape[0], int(k), int(bool(inverse)), _p(out)))
+    return out

@@ -731,26 +731,31 @@ static void uni_evaluate(const fparams *F, const u64 *coef, unsigned n, const u6
 /* ------------------------------------------------------------------------------------------
  * sumcheck/src/verifier.rs
  * ---------------------------------------------------------------------------------------- */
-int orc_sumcheck_verify_partial(int field, u64 n_rounds, unsigned D, const u64 sum[4],
-                                const u64 *round_polys, const uint8_t *table_bytes, size_t table_bytes_len,
-                                u64 subclaim_sum[4], u64 *challenges_out) {         /* :44-78 */
+/* verify_internal with each round polynomial at ITS OWN length (proof.round_polys is a Vec<Vec<F>>; :55-58 interpolates
+ * whatever length the round carries: 0 evaluations -> the zero polynomial, 1 -> a constant).  round_polys = the rounds'
+ * evaluations back to back. */
+int orc_sumcheck_verify_partial_lengths(int field, u64 n_rounds, const uint32_t *lens, const u64 sum[4],
+                                        const u64 *round_polys, const uint8_t *table_bytes, size_t table_bytes_len,
+                                        u64 subclaim_sum[4], u64 *challenges_out) {  /* :44-78 */
     const fparams *F = field_get(field);
     if (!F) return ORC_ERR_BAD_FIELD;
-    if (D + 1 > ORC_MAX_DEG) return ORC_ERR_ALLOC;
+    for (u64 r = 0; r < n_rounds; ++r)
+        if (lens[r] > ORC_MAX_DEG) return ORC_ERR_ALLOC;
     orc_transcript *tr = orc_transcript_new();
     if (table_bytes) orc_transcript_append(tr, table_bytes, table_bytes_len);        /* :22 */
     append_elems(tr, field, sum, 1);                                                 /* :50 */
     u64 claimed[4], zero[4] = {0, 0, 0, 0};
     memcpy(claimed, sum, 32);
     int rc = ORC_OK;
-    u64 *coef = (u64 *)malloc((size_t)(D + 1) * 32);
+    u64 *coef = (u64 *)malloc((size_t)(ORC_MAX_DEG + 1) * 32);
+    const u64 *rp = round_polys;
     for (u64 r = 0; r < n_rounds; ++r) {
-        const u64 *rp = round_polys + r * (D + 1) * 4;
-        append_elems(tr, field, rp, D + 1);                                          /* :56 */
-        uni_interpolate(F, field, rp, D + 1, coef);                                  /* :58 */
+        const unsigned len = lens[r];
+        append_elems(tr, field, rp, len);                                            /* :56 */
+        uni_interpolate(F, field, rp, len, coef);                                    /* :58 */
         u64 p0[4], p1[4], s[4];
-        uni_evaluate(F, coef, D + 1, zero, p0);                                      /* :61 */
-        uni_evaluate(F, coef, D + 1, F->r1, p1);                                     /* :62 */
+        uni_evaluate(F, coef, len, zero, p0);                                        /* :61 */
+        uni_evaluate(F, coef, len, F->r1, p1);                                       /* :62 */
         f_add(F, p0, p1, s);
         if (!eq4(claimed, s)) {                                                      /* :64 */
             rc = ORC_ERR_VERIFY_SUM;
@@ -758,11 +763,43 @@ int orc_sumcheck_verify_partial(int field, u64 n_rounds, unsigned D, const u64 s
         }
         u64 *ch = challenges_out + 4 * r;
         orc_transcript_sample_field_element(tr, field, ch);                          /* :69 */
-        uni_evaluate(F, coef, D + 1, ch, claimed);                                   /* :70 */
+        uni_evaluate(F, coef, len, ch, claimed);                                     /* :70 */
+        rp += (size_t)len * 4;
     }
     free(coef);
     orc_transcript_free(tr);
     if (rc == ORC_OK) memcpy(subclaim_sum, claimed, 32);
+    return rc;
+}
+int orc_sumcheck_verify_partial(int field, u64 n_rounds, unsigned D, const u64 sum[4],
+                                const u64 *round_polys, const uint8_t *table_bytes, size_t table_bytes_len,
+                                u64 subclaim_sum[4], u64 *challenges_out) {         /* every round D + 1 evaluations */
+    if (D + 1 > ORC_MAX_DEG) return ORC_ERR_ALLOC;
+    uint32_t *lens = (uint32_t *)malloc((size_t)(n_rounds + 1) * sizeof(uint32_t));
+    if (!lens) return ORC_ERR_ALLOC;
+    for (u64 r = 0; r < n_rounds; ++r) lens[r] = D + 1;
+    int rc = orc_sumcheck_verify_partial_lengths(field, n_rounds, lens, sum, round_polys, table_bytes, table_bytes_len,
+                                                 subclaim_sum, challenges_out);
+    free(lens);
+    return rc;
+}
+
+int orc_sumcheck_verify_lengths(int field, u64 k, u64 n_vars, const u64 *const *tables, u64 n_round_polys,
+                                const uint32_t *lens, const u64 sum[4], const u64 *round_polys) { /* :15-33 */
+    if (n_round_polys != n_vars) return ORC_ERR_VERIFY_ROUNDS;                       /* :17-19 */
+    u64 len = 1ULL << n_vars;
+    uint8_t *bytes = (uint8_t *)malloc(k * len * 32);
+    u64 *ch = (u64 *)malloc((n_vars + 1) * 32);
+    if (!bytes || !ch) return ORC_ERR_ALLOC;
+    for (u64 f = 0; f < k; ++f) orc_mle_to_bytes(field, n_vars, tables[f], bytes + f * len * 32);
+    u64 sub[4], ev[4];
+    int rc = orc_sumcheck_verify_partial_lengths(field, n_vars, lens, sum, round_polys, bytes, k * len * 32, sub, ch);
+    if (rc == ORC_OK) {
+        rc = orc_product_evaluate(field, k, n_vars, tables, ch, n_vars, ev);         /* :27-29 */
+        if (rc == ORC_OK) rc = eq4(ev, sub) ? 1 : 0;                                 /* :31 */
+    }
+    free(bytes);
+    free(ch);
     return rc;
 }
 
@@ -878,5 +915,45 @@ int orc_ntt_fast(int field, const u64 *in, u64 n, int inverse, u64 *out) {
         orc_inverse(field, nm, ninv);
         for (u64 i = 0; i < n; ++i) f_mul(F, out + 4 * i, ninv, out + 4 * i);
     }
+    return ORC_OK;
+}
+
+/* One output of the transform by its definition (fft/src/lib.rs:39-45 computes out[k] = sum_j in[j] * omega^(j*k)):
+ * checks single outputs of transforms too large for the recursion above.  OpenMP over chunks of j; exact field sums, so
+ * the association does not matter. */
+int orc_dft_point(int field, const u64 *in, u64 n, u64 k, int inverse, u64 out[4]) {
+    const fparams *F = field_get(field);
+    if (!F) return ORC_ERR_BAD_FIELD;
+    u64 w[4], wk[4];
+    int rc = orc_root_of_unity(field, n, w);
+    if (rc) return rc;
+    if (inverse) orc_inverse(field, w, w);
+    f_pow(F, w, k % n, wk);
+    const u64 chunk = 1ULL << 12;
+    const u64 n_chunks = (n + chunk - 1) / chunk;
+    u64 *part = (u64 *)calloc(n_chunks, 32);
+    if (!part) return ORC_ERR_ALLOC;
+#pragma omp parallel for schedule(static)
+    for (u64 c = 0; c < n_chunks; ++c) {
+        u64 pw[4], acc[4] = {0, 0, 0, 0}, t[4];
+        f_pow(F, wk, c * chunk, pw);
+        const u64 end = (c + 1) * chunk < n ? (c + 1) * chunk : n;
+        for (u64 j = c * chunk; j < end; ++j) {
+            f_mul(F, in + 4 * j, pw, t);
+            f_add(F, acc, t, acc);
+            f_mul(F, pw, wk, pw);
+        }
+        memcpy(part + 4 * c, acc, 32);
+    }
+    u64 acc[4] = {0, 0, 0, 0};
+    for (u64 c = 0; c < n_chunks; ++c) f_add(F, acc, part + 4 * c, acc);
+    free(part);
+    if (inverse) {
+        u64 nm[4], ninv[4];
+        orc_from_u64(field, n, nm);
+        orc_inverse(field, nm, ninv);
+        f_mul(F, acc, ninv, acc);
+    }
+    memcpy(out, acc, 32);
     return ORC_OK;
 }

@@ -123,6 +123,14 @@ int orc_sumcheck_verify_partial(int field, uint64_t n_rounds, unsigned max_var_d
                                 const uint64_t sum[4], const uint64_t *round_polys,
                                 const uint8_t *table_bytes, size_t table_bytes_len, /* NULL,0 for verify_partial */
                                 uint64_t subclaim_sum[4], uint64_t *challenges_out);
+/* the same with every round polynomial at its own length (proof.round_polys: Vec<Vec<F>>, verifier.rs:55-58): lens[r]
+ * evaluations for round r, stored back to back in round_polys */
+int orc_sumcheck_verify_partial_lengths(int field, uint64_t n_rounds, const uint32_t *lens, const uint64_t sum[4],
+                                        const uint64_t *round_polys, const uint8_t *table_bytes, size_t table_bytes_len,
+                                        uint64_t subclaim_sum[4], uint64_t *challenges_out);
+int orc_sumcheck_verify_lengths(int field, uint64_t k, uint64_t n_vars, const uint64_t *const *tables,
+                                uint64_t n_round_polys, const uint32_t *lens, const uint64_t sum[4],
+                                const uint64_t *round_polys);
 /* verify (verifier.rs:15-33): 1 = Ok(true), 0 = Ok(false), negative = Err */
 int orc_sumcheck_verify(int field, uint64_t k, uint64_t n_vars, const uint64_t *const *tables,
                         uint64_t n_round_polys, unsigned max_var_degree, const uint64_t sum[4],
@@ -135,6 +143,9 @@ int orc_fft_internal(int field, const uint64_t *in, uint64_t n, const uint64_t o
 /* same DFT (same omega) by an iterative table-driven algorithm: used only to check larger sizes in
  * reasonable time; validated against orc_fft at small n by tests/test_oracle_kats.py */
 int orc_ntt_fast(int field, const uint64_t *in, uint64_t n, int inverse, uint64_t *out);
+/* ONE output of fft (inverse = 0) / ifft (inverse != 0) straight from the definition out[k] = sum_j in[j] * omega^(j*k)
+ * (fft/src/lib.rs:39-45): pins single outputs of transforms too large for the recursion */
+int orc_dft_point(int field, const uint64_t *in, uint64_t n, uint64_t k, int inverse, uint64_t out[4]);
 
 #ifdef __cplusplus
 }

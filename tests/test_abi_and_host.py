@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 50
     missing = [n for n in names if not hasattr(_lib.lib, n)]
     assert missing == []
-    assert _lib.lib.zk_abi_version() == 3
+    assert _lib.lib.zk_abi_version() == 4
 
 
 def test_every_declared_symbol_has_a_python_signature():
@@ -106,6 +106,62 @@ def test_verify_partial_matches_oracle(field, k, D, n_vars):
     rp2, _ = orc.sumcheck_prove(field, n_vars, tabs, D, bad, absorb_table=False)
     with pytest.raises(zk_amd.ZkError, match="claimed_sum != p\\(0\\) \\+ p\\(1\\)"):
         zk_amd.SumcheckVerifier.verify_partial(field, zk_amd.SumcheckProof(bad, rp2))
+
+
+def _consistent_ragged_proof(field, lens, seed):
+    """a proof whose round r carries lens[r] evaluations and passes every p(0) + p(1) check: random evaluations with ys[1]
+    (or, for a constant, ys[0]) fixed by the running claim, the claim after each round taken from the oracle's verifier"""
+    rng = random.Random(seed)
+    p = orc.modulus(field)
+    claimed = orc.from_int(field, rng.randrange(p))
+    inv2 = orc.inverse(field, orc.from_int(field, 2))
+    rounds, cur = [], claimed
+    for ln in lens:
+        ys = orc.from_ints(field, [rng.randrange(p) for _ in range(ln)]).reshape(ln, 4)
+        if ln >= 2:
+            ys[1] = orc.sub(field, cur, ys[0])
+        elif ln == 1:
+            ys[0] = orc.mul(field, cur, inv2)
+        rounds.append(ys)
+        try:
+            cur, _ = orc.sumcheck_verify_partial_lengths(field, claimed, rounds)
+        except orc.OracleError:
+            break   # a zero-length round with a non-zero claim: the remaining rounds are never looked at
+    while len(rounds) < len(lens):
+        rounds.append(orc.from_ints(field, [rng.randrange(p) for _ in range(lens[len(rounds)])]).reshape(-1, 4))
+    return claimed, rounds
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_verify_partial_interpolates_each_round_at_its_own_length(field):
+    """verifier.rs:55-58 + univariate_poly.rs:43-49: round_polys is a Vec<Vec<F>> and every round is interpolated at the
+    length it carries.  Library (zk_sumcheck_verify_partial_lengths) against the oracle on proofs with mixed lengths,
+    including constants (1 evaluation) and the zero polynomial (0 evaluations)."""
+    cases = [[3, 2, 4, 1, 3], [1, 1, 1], [2, 5, 2, 7, 3, 3], [4], [3, 0, 3], [9, 2, 6], []]
+    for i, lens in enumerate(cases):
+        claimed, rounds = _consistent_ragged_proof(field, lens, 40 + i)
+        proof = zk_amd.SumcheckProof(claimed, rounds)
+        try:
+            want = orc.sumcheck_verify_partial_lengths(field, claimed, rounds)
+        except orc.OracleError as e:
+            assert 0 in lens and e.code == -9
+            with pytest.raises(zk_amd.ZkError, match="claimed_sum != p\\(0\\) \\+ p\\(1\\)"):
+                zk_amd.SumcheckVerifier.verify_partial(field, proof)
+            continue
+        sub = zk_amd.SumcheckVerifier.verify_partial(field, proof)
+        assert np.array_equal(sub.sum, want[0]) and np.array_equal(sub.challenges, want[1])
+        if lens:   # one evaluation off by one in the last round: both reject
+            rounds[-1][0] = orc.add(field, rounds[-1][0], orc.from_int(field, 1))
+            with pytest.raises(orc.OracleError):
+                orc.sumcheck_verify_partial_lengths(field, claimed, rounds)
+            with pytest.raises(zk_amd.ZkError, match="claimed_sum"):
+                zk_amd.SumcheckVerifier.verify_partial(field, zk_amd.SumcheckProof(claimed, rounds))
+    # a zero claim with an empty first round passes that round in both (zero polynomial: p(0) + p(1) = 0)
+    zero = np.zeros(4, dtype=np.uint64)
+    rounds = [np.zeros((0, 4), dtype=np.uint64), np.zeros((0, 4), dtype=np.uint64)]
+    want = orc.sumcheck_verify_partial_lengths(field, zero, rounds)
+    sub = zk_amd.SumcheckVerifier.verify_partial(field, zk_amd.SumcheckProof(zero, rounds))
+    assert np.array_equal(sub.sum, want[0]) and np.array_equal(sub.challenges, want[1]) and not sub.sum.any()
 
 
 def test_argument_validation_without_gpu():

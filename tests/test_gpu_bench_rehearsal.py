@@ -1,9 +1,12 @@
 """bench.py's N > 1 branch (strong-scaling fold of the 2^24 table sharded by index mod N, the sharded n = 24 prover through
 zk_shard_prover_run, the four-step NTT) only runs when the driver launches several ranks.  ZK_BENCH_REHEARSE=1 runs the same
-code with two ranks on ONE GPU (gloo group, host-staged collectives instead of RCCL): this checks that the line comes out, is
-well-formed and that every rank derived the same challenges -- not its numbers."""
+code with every rank on ONE GPU (gloo group, host-staged collectives instead of RCCL): the line must come out well-formed and
+the sharded proof must be RIGHT -- verified against the true claimed sum, identical on every rank and bit-identical with the
+proof of the unsharded 2^24 tables -- not its numbers.  Four ranks: the GPU box admits at most six processes on its card, so
+the next power of two (eight, the node the driver uses) cannot be rehearsed on it; world 2 and 4 cover log2 W = 1 and > 1."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -12,21 +15,57 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.gpu
-def test_bench_two_ranks_one_gpu():
-    env = dict(os.environ, ZK_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, extra_env=None):
+    env = dict(os.environ, ZK_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "40", "--warmup", "5",
+           "--prewarm-ms", "20"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, lines
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_ranks_on_one_gpu(world):
+    r, lines = _run(world)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 40
-    assert d["config"]["elements_per_gpu"] == 1 << 23
-    assert d["value"] > 0 and d["roofline"]["algorithmic_bytes"] == 48 << 23
+    lv = 24 - (world.bit_length() - 1)
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["steps"] == 40
+    assert d["config"]["elements_per_gpu"] == 1 << lv
+    assert d["value"] > 0 and d["roofline"]["algorithmic_bytes"] == 48 << lv
     ex = d["extra"]
     assert "sharded_error" not in ex and "sharded_ntt_error" not in ex, ex
-    assert ex["sharded_challenges_identical_on_all_ranks"] is True
-    assert ex["sharded_sumcheck_local_vars"] == 23 and ex["sharded_sumcheck_ms_n24_k2_d2_world2"] > 0
-    assert ex["sharded_ntt_ms_2p24_world2"] > 0
+    assert ex["sharded_proof_verified"] is True
+    assert ex["sharded_proof_identical_on_all_ranks"] is True
+    assert ex["sharded_proof_equals_unsharded_proof"] is True
+    assert ex["sharded_sumcheck_local_vars"] == lv and ex[f"sharded_sumcheck_ms_n24_k2_d2_world{world}"] > 0
+    ph = ex[f"sharded_sumcheck_phases_ms_n24_k2_d2_world{world}_gather_below10"]
+    assert set(ph) == {"local_kernels_ms", "allreduce_ms", "gather_ms", "tail_rounds_ms"} and all(v > 0 for v in ph.values())
+    assert ex[f"sharded_ntt_ms_2p24_world{world}"] > 0 and ex["sharded_ntt_roundtrip_exact"] is True
+
+
+@pytest.mark.gpu
+def test_bench_world1_under_torchrun_matches_the_plain_line_shape():
+    """the driver's N = 1 line is the plain `python bench.py`; a world-1 torchrun run takes the distributed branch (RCCL at one
+    rank) and must produce the same headline fields plus a verified sharded proof"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "5",
+           "--no-cpu-baseline", "--no-pmc", "--no-parity-gate"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["elements_per_gpu"] == 1 << 24
+    ex = d["extra"]
+    assert "sharded_error" not in ex, ex
+    assert ex["sharded_proof_verified"] is True and ex["sharded_proof_equals_unsharded_proof"] is True
+    assert 0.3 < d["roofline"]["frac"] < 1.0

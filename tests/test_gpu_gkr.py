@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import zk_amd
+from oracle import binding as orc
 from oracle import gkr_ref, pyref
 from zk_amd import MultiLinearPolynomial as MLE
 from zk_amd import ZkError, gkr
@@ -286,3 +287,34 @@ def test_gkr_statement_is_bound_before_the_output_point(field):
     rewired = list(layers)
     rewired[1] = (lo, li, op, [(left[0] + 1) % (1 << li)] + list(left[1:]), right)
     assert not gkr.gkr_verify(upload_circuit(c, rewired), x, out, seed, proof)
+
+
+def test_config4_gkr_depth8_width_2p20_prove_verify_tamper():
+    """BASELINE config[3] at its own size: depth 8, width 2^20, random add/mul gates with random wiring.  The proof must
+    verify; one tampered proof element (first, middle, last), a tampered output and a tampered input must each be rejected."""
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    rng = np.random.default_rng(0x6B72)
+    w = 20
+    circ = gkr.Circuit(c)
+    for _ in range(8):
+        circ.add_layer(w, w, rng.integers(0, 2, 1 << w, dtype=np.uint8), rng.integers(0, 1 << w, 1 << w, dtype=np.uint32),
+                       rng.integers(0, 1 << w, 1 << w, dtype=np.uint32))
+    x = MLE.random(c, w, 0x6B72, 0)
+    seed = bytes(range(32))
+    out, proof = gkr.gkr_prove(circ, x, seed)
+    assert gkr.gkr_verify(circ, x, out, seed, proof)
+    one = zk_amd.fe_from_int(field, 1)
+    flat = proof.reshape(-1, 4)
+    for idx in (0, flat.shape[0] // 2, flat.shape[0] - 1):
+        bad = proof.copy()
+        bad.reshape(-1, 4)[idx] = orc.add(field, flat[idx], one)
+        assert not gkr.gkr_verify(circ, x, out, seed, bad), f"tampered proof element {idx} accepted"
+    outs = out.evaluation_slice().copy()
+    outs[12345] = orc.add(field, outs[12345], one)
+    assert not gkr.gkr_verify(circ, x, MLE.new(c, w, outs), seed, proof)
+    xs = x.evaluation_slice().copy()
+    xs[54321] = orc.add(field, xs[54321], one)
+    assert not gkr.gkr_verify(circ, MLE.new(c, w, xs), out, seed, proof)
+    assert not gkr.gkr_verify(circ, x, out, bytes(32), proof)   # another seed: another transcript
+    circ.free()

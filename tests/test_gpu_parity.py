@@ -648,3 +648,127 @@ def test_sample_n_and_trim():
     b.free()
     c.trim()                                                         # zk_ctx_trim: the freed block goes back to the device
     assert np.array_equal(a.evaluation_slice(), want)
+
+
+# ------------------------------------------------------------------ BASELINE configs at their OWN sizes, bit-exact vs the oracle
+def _prove_vs_oracle(field, n, k, D, seed):
+    c = ctx_for(field)
+    polys = [MLE.random(c, n, seed, f << n) for f in range(k)]
+    tabs = [q.evaluation_slice() for q in polys]
+    for f, t in enumerate(tabs):   # the device generator is the oracle's generator: pin it on a slice
+        assert np.array_equal(t[:4096], orc.fill_random(field, seed, 4096, first_index=f << n))
+    pp = ProductPoly.new(polys)
+    s = pp.round_sums(1)
+    claimed = orc.add(field, s[0], s[1])
+    want_rp, want_ch = orc.sumcheck_prove(field, n, tabs, D, claimed, False)   # the faithful restatement (prover.rs:33-73)
+    proof, ch = SumcheckProver(D).prove_partial(pp, claimed)                    # default kernel thresholds
+    assert np.array_equal(proof.round_polys, want_rp), "round polynomials differ from the oracle"
+    assert np.array_equal(ch, want_ch), "challenges differ from the oracle"
+    sub = SumcheckVerifier.verify_partial(field, proof)                        # and the claimed sum was the true one
+    assert np.array_equal(sub.challenges, ch)
+    assert np.array_equal(pp.evaluate(ch), sub.sum)
+    for q in polys:
+        q.free()
+
+
+@pytest.mark.parametrize("k,D", [(2, 2), (3, 3)])
+def test_config2_n20_prover_bit_exact_at_default_thresholds(k, D):
+    """BASELINE config[1] ("20-var MLE fold + full sumcheck on 1xMI355X, bit-exact vs CPU"): the whole proof -- every round
+    polynomial and challenge -- equal to the faithful oracle's, with the kernel thresholds the product ships (SKIP1 rounds from
+    2^17 pairs, quad rounds, pipelined rounds, finisher: every path at its real size).  prover.rs:44-68."""
+    _prove_vs_oracle(zk_amd.BN254_FR, 20, k, D, 0x5EED0000 + 20)
+
+
+def test_config3_n24_prover_and_fold_bit_exact():
+    """The metric's own size: n = 24, k = 2, D = 2 proof equal to the faithful oracle's (round 0 on 2 x 512 MiB, SKIP1 fused
+    rounds at 2^22..2^17 pairs), and the timed fold (partial_evaluate(0, [r]) of the 2^24 table, evaluation_form.rs:40-80)
+    equal to the oracle's on ALL 2^23 outputs."""
+    field = zk_amd.BN254_FR
+    _prove_vs_oracle(field, 24, 2, 2, 0x5EED0000 + 24)
+    c = ctx_for(field)
+    T = MLE.random(c, 24, 0x5EED0000 + 24, 0)
+    out = MLE.alloc(c, 23)
+    r = orc.fill_random(field, 0xC4A11, 1)
+    T.fold_into(r[0], out)
+    want = orc.mle_partial_evaluate(field, 24, T.evaluation_slice(), 0, r)
+    assert np.array_equal(out.evaluation_slice(), want)
+    T.free(); out.free()
+
+
+def test_config5_ntt_2_24_outputs_vs_the_definition():
+    """config[4]: sixteen random outputs (+ the corners) of the 2^24-point forward and inverse transforms against the
+    definition X[k] = sum_j x[j] w^(jk) evaluated by the oracle (orc_dft_point, fft/src/lib.rs:39-45): the 8+8+8 pass plan
+    exists only at this size, and a forward/inverse-symmetric addressing error would survive the round trip."""
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    lg = 24
+    x = MLE.random(c, lg, 0x5EED0000 + 5, 0)
+    X, Y = MLE.alloc(c, lg), MLE.alloc(c, lg)
+    zk_amd.ntt(c, x, X)
+    zk_amd.ntt(c, x, Y, inverse=True)
+    xs, Xs, Ys = x.evaluation_slice(), X.evaluation_slice(), Y.evaluation_slice()
+    rng = random.Random(0x2424)
+    ks = [0, 1, (1 << lg) - 1, 1 << 8, 1 << 16, (1 << 23) + 1] + [rng.randrange(1 << lg) for _ in range(16)]
+    for k in ks:
+        assert np.array_equal(Xs[k], orc.dft_point(field, xs, k)), f"forward output {k}"
+    for k in ks[:3] + ks[6:12]:
+        assert np.array_equal(Ys[k], orc.dft_point(field, xs, k, inverse=True)), f"inverse output {k}"
+    x.free(); X.free(); Y.free()
+
+
+@pytest.mark.parametrize("lg", [21, 22])
+def test_ntt_full_compare_at_2_21_and_2_22(lg):
+    """every output of the 3-pass plan at 2^21 (7+7+7) / 2^22 against the oracle's iterative transform (itself checked against
+    the faithful recursion at small sizes)"""
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    x = MLE.random(c, lg, 0x5EED0000 + lg, 0)
+    X, B = MLE.alloc(c, lg), MLE.alloc(c, lg)
+    zk_amd.ntt(c, x, X)
+    xs = x.evaluation_slice()
+    assert np.array_equal(X.evaluation_slice(), orc.ntt_fast(field, xs))
+    zk_amd.ntt(c, X, B, inverse=True)
+    assert np.array_equal(B.evaluation_slice(), xs)
+    x.free(); X.free(); B.free()
+
+
+def test_verify_with_per_round_lengths_on_the_device_path():
+    """zk_sumcheck_verify_lengths (verifier.rs:15-33 with each round interpolated at its own length, :55-58): an honest D = 2
+    proof re-stated with extra evaluations of the same round polynomials in some rounds still verifies only if the transcript
+    matches -- so the ragged proof is produced round by round with the oracle's transcript -- and equals the oracle's verdict."""
+    for field in FIELDS:
+        c = ctx_for(field)
+        n, k = 6, 2
+        tabs = [orc.fill_random(field, 8800 + f, 1 << n) for f in range(k)]
+        lens = [3, 4, 3, 5, 3, 4]
+        claimed = sum_elems(field, orc.prod_reduce(field, n, tabs))
+        tr = orc.Transcript()
+        tr.append(b"".join(orc.mle_to_bytes(field, n, t) for t in tabs))
+        tr.append(orc.to_bytes_be(field, claimed))
+        cur, rounds = [t.copy() for t in tabs], []
+        for r in range(n):
+            m = n - r
+            ys = []
+            for t in range(lens[r]):
+                parts = [orc.mle_partial_evaluate(field, m, q, 0, orc.from_int(field, t).reshape(1, 4)) for q in cur]
+                ys.append(sum_elems(field, orc.prod_reduce(field, m - 1, parts)))
+            ys = np.stack(ys)
+            rounds.append(ys)
+            tr.append(b"".join(orc.to_bytes_be(field, y) for y in ys))
+            ch = tr.sample_field_element(field)
+            cur = [orc.mle_partial_evaluate(field, m, q, 0, ch.reshape(1, 4)) for q in cur]
+        pp = ProductPoly.new([MLE.new(c, n, t) for t in tabs])
+        assert orc.sumcheck_verify_lengths(field, n, tabs, claimed, rounds) is True
+        assert SumcheckVerifier.verify(pp, SumcheckProof(claimed, rounds)) is True
+        rounds[3][4] = orc.add(field, rounds[3][4], orc.from_int(field, 1))   # the extra evaluation is part of the polynomial
+        try:
+            want = orc.sumcheck_verify_lengths(field, n, tabs, claimed, rounds)
+        except orc.OracleError:
+            want = "err"
+        try:
+            got = SumcheckVerifier.verify(pp, SumcheckProof(claimed, rounds))
+        except ZkError:
+            got = "err"
+        assert got == want and got is not True
+        with pytest.raises(ZkError, match="require 1 round poly"):
+            SumcheckVerifier.verify(pp, SumcheckProof(claimed, rounds[:-1]))

@@ -177,3 +177,54 @@ def test_transcript_chain_matches_model():
         assert t.sample_challenge() == m.sample_challenge()
     for field in FIELDS:
         assert orc.to_int(field, t.sample_field_element(field)) == m.sample_field_element(field)
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_dft_point_equals_the_faithful_fft_outputs(field):
+    """orc_dft_point (one output from the definition sum_j x[j] w^(jk), fft/src/lib.rs:39-45) against the faithful recursion
+    and the Python model's naive DFT; used by the GPU suite to pin single outputs of the 2^24-point transform."""
+    for lg in (0, 1, 4, 8, 13):
+        n = 1 << lg
+        v = orc.fill_random(field, 911 + lg, n)
+        f = orc.fft(field, v) if lg <= 8 else orc.ntt_fast(field, v)
+        g = orc.ifft(field, v) if lg <= 8 else orc.ntt_fast(field, v, inverse=True)
+        for k in sorted({0, min(1, n - 1), n // 2, n - 1, (7 * n) // 11}):
+            assert np.array_equal(orc.dft_point(field, v, k), f[k])
+            assert np.array_equal(orc.dft_point(field, v, k, inverse=True), g[k])
+    vals = rand_ints(field, 16, 5)
+    naive = pyref.dft_naive(field, vals)
+    for k in range(16):
+        assert orc.to_int(field, orc.dft_point(field, orc.from_ints(field, vals), k)) == naive[k]
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_ragged_verifier_matches_model(field):
+    """verifier.rs:55-58 interpolates each round at its own length: the C restatement against the Python model on proofs
+    whose rounds carry 0..6 evaluations (random, made to pass p(0) + p(1) round by round with the model's own claims)"""
+    import random
+
+    p = orc.modulus(field)
+    rng = random.Random(field + 77)
+    for lens in ([3, 2, 4, 1, 3], [1, 1], [5, 6, 2], [3, 0, 2], [2, 2, 2, 2]):
+        claimed = rng.randrange(p)
+        rounds, cur, alive = [], claimed, True
+        for ln in lens:
+            ys = [rng.randrange(p) for _ in range(ln)]
+            if ln >= 2:
+                ys[1] = (cur - ys[0]) % p
+            elif ln == 1:
+                ys[0] = cur * pow(2, -1, p) % p
+            rounds.append(ys)
+            if alive:
+                try:
+                    cur, _ = pyref.sumcheck_verify_partial(field, claimed, rounds)
+                except ValueError:
+                    alive = False
+        arrs = [orc.from_ints(field, ys).reshape(-1, 4) for ys in rounds]
+        if alive:
+            want_sum, want_ch = pyref.sumcheck_verify_partial(field, claimed, rounds)
+            got_sum, got_ch = orc.sumcheck_verify_partial_lengths(field, orc.from_int(field, claimed), arrs)
+            assert orc.to_int(field, got_sum) == want_sum and orc.to_ints(field, got_ch) == want_ch
+        else:
+            with pytest.raises(orc.OracleError):
+                orc.sumcheck_verify_partial_lengths(field, orc.from_int(field, claimed), arrs)

@@ -169,6 +169,33 @@ def test_one_cached_context_per_field():
     assert len(re.findall(r"ctx::<F>\(\)", code)) >= 5
 
 
+def test_layout_and_abi_invariants_are_in_the_source():
+    """`limbs()` casts *const F to *const u64: the shim must assert size 32 / alignment 8 at compile time for every field it
+    binds, and check the library's ABI revision (equal to the header's) before the first context is made."""
+    code = re.sub(r"//[^\n]*", "", open(SHIM).read())
+    fields = re.findall(r"impl GpuField for (\w+::Fr)", code)
+    assert len(fields) == 3
+    for f in fields:
+        pat = (r"const _: \(\) = assert!\(std::mem::size_of::<%s>\(\) == 32 && std::mem::align_of::<%s>\(\) == 8\);"
+               % (re.escape(f), re.escape(f)))
+        assert re.search(pat, code), f"no compile-time layout assertion for {f}"
+    header_ver = int(re.search(r"#define ZK_AMD_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    shim_ver = int(re.search(r"const ZK_AMD_ABI_VERSION: i32 = (\d+);", code).group(1))
+    assert shim_ver == header_ver
+    ctx_fn = code[code.index("fn ctx<F: GpuField>()"):]
+    ctx_fn = ctx_fn[:ctx_fn.index("zk_ctx_create(")]
+    assert "zk_abi_version() } != ZK_AMD_ABI_VERSION" in ctx_fn, "ABI version must be checked before zk_ctx_create"
+
+
+def test_verifier_passes_each_round_at_its_own_length():
+    """verifier.rs:55-58 interpolates every round polynomial at its own length: the shim must not reject ragged proofs"""
+    code = re.sub(r"//[^\n]*", "", open(SHIM).read())
+    body = code[code.index("impl<F: GpuField> SumcheckVerifier<F>"):]
+    body = body[:body.index("pub fn fft<F: GpuField>")]
+    assert "zk_sumcheck_verify_lengths(" in body and "zk_sumcheck_verify_partial_lengths(" in body
+    assert "r.len() != ns" not in body and "ZK_ERR_VERIFY_SUM" not in body
+
+
 def test_index_pair_formula_matches_the_reference_kats():
     """the shim's index_pair body, transliterated, against the literal lists of pairing_index.rs:61-96"""
     def index_pair(n_vars, index):

@@ -59,7 +59,7 @@ def declared_symbols():
 def check(rc):
     if rc < 0:
         msg = lib.zk_strerror(rc).decode()
-        if rc == -23:
+        if rc in (-23, -28):   # ZK_ERR_HIP / ZK_ERR_COMM: the runtime's (HIP's, RCCL's) own text
             msg += ": " + lib.zk_last_hip_error().decode()
         raise ZkError(rc, msg)
     return rc
@@ -130,6 +130,7 @@ _sig = {
     "zk_comm_create_host": [c.c_void_p, c.c_uint32, c.c_uint32, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, vpp],
     "zk_comm_destroy": [c.c_void_p],
     "zk_shard_prover_run": [c.c_void_p, c.c_void_p, c.c_uint32],
+    "zk_shard_prover_run_phases": [c.c_void_p, c.c_void_p, c.c_uint32, c.POINTER(c.c_double)],
     "zk_ntt_sharded": [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_void_p],
     "zk_ctx_device_alloc": [c.c_void_p, c.c_uint64, vpp],
     "zk_ctx_device_free": [c.c_void_p, c.c_void_p, c.c_uint64],
@@ -137,6 +138,9 @@ _sig = {
     "zk_ctx_memcpy_htod": [c.c_void_p, c.c_void_p, c.c_void_p, c.c_uint64],
     "zk_sumcheck_verify_partial": [c.c_int32, c.c_uint64, c.c_uint32, u64p, u64p, u64p, u64p],
     "zk_sumcheck_verify": [c.c_void_p, vpp, c.c_uint64, c.c_uint64, c.c_uint32, u64p, u64p, c.POINTER(c.c_int32)],
+    "zk_sumcheck_verify_partial_lengths": [c.c_int32, c.c_uint64, c.POINTER(c.c_uint32), u64p, u64p, u64p, u64p],
+    "zk_sumcheck_verify_lengths": [c.c_void_p, vpp, c.c_uint64, c.c_uint64, c.POINTER(c.c_uint32), u64p, u64p,
+                                   c.POINTER(c.c_int32)],
     "zk_sumcheck_prove_terms": [c.c_void_p, vpp, u64p, c.c_uint64, c.c_uint32, u64p, c.c_int32, u64p, u64p, u64p],
     "zk_eq_table": [c.c_void_p, u64p, c.c_uint64, vpp],
     "zk_circuit_create": [c.c_void_p, vpp],

@@ -393,29 +393,41 @@ class SumcheckProver:
         return self._run(poly, sum_, False, consume)
 
 
+def _ragged_rounds(round_polys):
+    """SumcheckProof.round_polys is a Vec<Vec<F>> (sumcheck/src/lib.rs:8-11): a (rounds, D+1, 4) array, or a list of
+    per-round (len_r, 4) arrays of different lengths -> (lens uint32, the evaluations back to back)."""
+    if isinstance(round_polys, np.ndarray) and round_polys.ndim == 3:
+        rp = np.ascontiguousarray(round_polys, dtype=np.uint64)
+        lens = np.full(rp.shape[0] + 1, rp.shape[1], dtype=np.uint32)
+        return rp.shape[0], lens, rp.reshape(-1, 4) if rp.size else np.zeros((1, 4), dtype=np.uint64)
+    rounds = [np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4) for r in round_polys]
+    lens = np.array([r.shape[0] for r in rounds] + [0], dtype=np.uint32)
+    flat = np.concatenate(rounds + [np.zeros((1, 4), dtype=np.uint64)], axis=0)
+    return len(rounds), lens, np.ascontiguousarray(flat)
+
+
 class SumcheckVerifier:
-    """SumcheckVerifier::<F> (verifier.rs:9-78)."""
+    """SumcheckVerifier::<F> (verifier.rs:9-78).  Each round polynomial is interpolated at its own length, as
+    verifier.rs:55-58 does (round_polys may be a list of arrays of different lengths)."""
 
     @staticmethod
     def verify(poly, proof):  # verifier.rs:15-33
-        rp = np.ascontiguousarray(proof.round_polys, dtype=np.uint64)
-        n_rp = rp.shape[0]
-        D = rp.shape[1] - 1 if rp.ndim == 3 and n_rp else 0
+        n_rp, lens, rp = _ragged_rounds(proof.round_polys)
         hp, keep = _handles(poly.polynomials)
         ok = c.c_int32()
         s = _elems(proof.sum, 1)
-        check(lib.zk_sumcheck_verify(poly.ctx._h, hp, len(poly.polynomials), n_rp, D, _p(s), _p(rp), c.byref(ok)))
+        check(lib.zk_sumcheck_verify_lengths(poly.ctx._h, hp, len(poly.polynomials), n_rp,
+                                             lens.ctypes.data_as(c.POINTER(c.c_uint32)), _p(s), _p(rp), c.byref(ok)))
         return bool(ok.value)
 
     @staticmethod
     def verify_partial(field, proof):  # verifier.rs:38-41
-        rp = np.ascontiguousarray(proof.round_polys, dtype=np.uint64)
-        n_rp = rp.shape[0]
-        D = rp.shape[1] - 1 if rp.ndim == 3 and n_rp else 0
+        n_rp, lens, rp = _ragged_rounds(proof.round_polys)
         s = _elems(proof.sum, 1)
         sub = np.zeros(4, dtype=np.uint64)
         ch = np.zeros((max(n_rp, 1), 4), dtype=np.uint64)
-        check(lib.zk_sumcheck_verify_partial(field, n_rp, D, _p(s), _p(rp), _p(sub), _p(ch)))
+        check(lib.zk_sumcheck_verify_partial_lengths(field, n_rp, lens.ctypes.data_as(c.POINTER(c.c_uint32)), _p(s), _p(rp),
+                                                     _p(sub), _p(ch)))
         return SubClaim(sub, ch[:n_rp])
 
 

@@ -140,7 +140,8 @@ static void pool_free(zk_ctx *c, void *ptr, size_t bytes) {
     c->pool_bytes += bytes;
     // cap: idle blocks never hold more than half of what the device has left (other contexts, other libraries and this
     // library's few raw hipMallocs must not fail while gigabytes sit here).  Checked only past 1 GiB: hipMemGetInfo is slow.
-    if (c->pool_bytes > ((size_t)1 << 30) && c->pool_bytes - c->pool_checked > ((size_t)1 << 30)) {
+    // (pool_alloc lowers pool_bytes without touching pool_checked: compare before subtracting, the difference is unsigned)
+    if (c->pool_bytes > ((size_t)1 << 30) && c->pool_bytes > c->pool_checked && c->pool_bytes - c->pool_checked > ((size_t)1 << 30)) {
         size_t fr = 0, tot = 0;
         c->pool_checked = c->pool_bytes;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess && c->pool_bytes > fr / 2) {
@@ -1542,10 +1543,9 @@ static int32_t prover_step(RoundState &st, bool *finished_in_kernel) {
     DeferredTail dt = {0, false};
     const bool enter = fast_degree(st.D) && pipe_wants_next(st, m_s);
     ZKCHK(round_enqueue(st, nullptr, enter ? &dt : nullptr));
+    // dt.blocks == 0: round_enqueue's contract for "the tail was launched after all" (a sums path that cannot defer it) --
+    // the round is closed and its challenge published, so the next round simply takes the classic path
     if (enter && dt.blocks) ZKCHK(pipe_enter(st, dt));
-    else if (enter) {   // the sums did not take the one-launch path: their tail has not been launched yet
-        return ZK_ERR_UNSUPPORTED;
-    }
     ++st.round;
     return ZK_OK;
 }
@@ -1950,52 +1950,85 @@ static Fe interp_eval(const std::vector<Fe> &ys, const std::vector<Fe> &w, const
     }
     return acc;
 }
-static int32_t verify_internal(const FieldParams &P, Sponge &sp, uint64_t n_rounds, uint32_t D, const uint64_t sum[4],
+// Each round polynomial is interpolated at ITS OWN length (proof.round_polys is a Vec<Vec<F>>; verifier.rs:55-58 hands
+// whatever the round carries to UnivariatePolynomial::interpolate): lens[r] evaluations for round r, stored back to back.
+// 0 evaluations -> the zero polynomial (interpolate of no points, evaluate of no coefficients = 0), 1 -> a constant.
+static int32_t verify_internal(const FieldParams &P, Sponge &sp, uint64_t n_rounds, const uint32_t *lens, const uint64_t sum[4],
                                const uint64_t *rps, Fe &claimed, uint64_t *out_ch) {   // verifier.rs:44-78
     absorb_elements(sp, sum, 1, P);                                      // :50
     claimed = fe_from_u64limbs(sum);
-    const std::vector<Fe> w = interp_weights(D, P);
+    std::vector<Fe> w;
+    uint32_t w_len = ~0u;
+    const uint64_t *rp = rps;
     for (uint64_t r = 0; r < n_rounds; ++r) {
-        const uint64_t *rp = rps + r * (D + 1) * 4;
-        absorb_elements(sp, rp, D + 1, P);                               // :56
-        std::vector<Fe> ys(D + 1);
-        for (uint32_t t = 0; t <= D; ++t) ys[t] = fe_from_u64limbs(rp + 4 * t);
+        const uint32_t len = lens[r];
+        if (len) absorb_elements(sp, rp, len, P);                        // :56 (no bytes for an empty round polynomial)
+        std::vector<Fe> ys(len);
+        for (uint32_t t = 0; t < len; ++t) ys[t] = fe_from_u64limbs(rp + 4 * t);
+        if (len && len != w_len) w = interp_weights(len - 1, P), w_len = len;
         // :61-62 p(0), p(1): the interpolant through (i, ys[i]) takes exactly ys[0], ys[1] at the nodes 0 and 1
-        const Fe p0 = ys[0], p1 = D >= 1 ? ys[1] : interp_eval(ys, w, fe_one(P), P);
+        const Fe p0 = len ? ys[0] : fe_zero(), p1 = len >= 2 ? ys[1] : (len ? ys[0] : fe_zero());
         if (!fe_eq(claimed, fe_add(p0, p1, P))) return ZK_ERR_VERIFY_SUM;                  // :64
         const Fe ch = squeeze_field_element(sp, P);                      // :69
-        claimed = interp_eval(ys, w, ch, P);                             // :70
+        claimed = len ? interp_eval(ys, w, ch, P) : fe_zero();           // :70
         fe_to_u64limbs(ch, out_ch + 4 * r);
+        rp += (size_t)len * 4;
     }
+    return ZK_OK;
+}
+static int32_t verify_internal(const FieldParams &P, Sponge &sp, uint64_t n_rounds, uint32_t D, const uint64_t sum[4],
+                               const uint64_t *rps, Fe &claimed, uint64_t *out_ch) {   // every round D + 1 evaluations
+    const std::vector<uint32_t> lens(n_rounds + 1, D + 1);
+    return verify_internal(P, sp, n_rounds, lens.data(), sum, rps, claimed, out_ch);
+}
+static int32_t check_lens(uint64_t n_rounds, const uint32_t *lens) {
+    for (uint64_t r = 0; r < n_rounds; ++r)
+        if (lens[r] > kMaxSums) return ZK_ERR_BAD_ARG;
+    return ZK_OK;
+}
+extern "C" int32_t zk_sumcheck_verify_partial_lengths(int32_t field, uint64_t n_rounds, const uint32_t *lens,
+                                                      const uint64_t sum[4], const uint64_t *rps, uint64_t out_sum[4],
+                                                      uint64_t *out_ch) {
+    const FieldInfo *fi = field_info(field);
+    if (!fi) return ZK_ERR_BAD_FIELD;
+    if (!sum || !out_sum || (n_rounds && (!lens || !rps || !out_ch))) return ZK_ERR_BAD_ARG;
+    ZKCHK(check_lens(n_rounds, lens));
+    Sponge sp;
+    sp.init();
+    Fe claimed;
+    ZKCHK(verify_internal(fi->P, sp, n_rounds, lens, sum, rps, claimed, out_ch));
+    fe_to_u64limbs(claimed, out_sum);
     return ZK_OK;
 }
 extern "C" int32_t zk_sumcheck_verify_partial(int32_t field, uint64_t n_rounds, uint32_t D, const uint64_t sum[4],
                                               const uint64_t *rps, uint64_t out_sum[4], uint64_t *out_ch) {
-    const FieldInfo *fi = field_info(field);
-    if (!fi) return ZK_ERR_BAD_FIELD;
-    if (!sum || !out_sum || (n_rounds && (!rps || !out_ch)) || D >= kMaxSums) return ZK_ERR_BAD_ARG;
-    Sponge sp;
-    sp.init();
-    Fe claimed;
-    ZKCHK(verify_internal(fi->P, sp, n_rounds, D, sum, rps, claimed, out_ch));
-    fe_to_u64limbs(claimed, out_sum);
-    return ZK_OK;
+    if (D >= kMaxSums) return ZK_ERR_BAD_ARG;
+    const std::vector<uint32_t> lens(n_rounds + 1, D + 1);
+    return zk_sumcheck_verify_partial_lengths(field, n_rounds, lens.data(), sum, rps, out_sum, out_ch);
 }
-extern "C" int32_t zk_sumcheck_verify(zk_ctx *c, const zk_mle *const *f, uint64_t k, uint64_t n_rps, uint32_t D,
-                                      const uint64_t sum[4], const uint64_t *rps, int32_t *out_ok) {
-    if (!sum || !out_ok || (n_rps && !rps) || D >= kMaxSums) return ZK_ERR_BAD_ARG;
+extern "C" int32_t zk_sumcheck_verify_lengths(zk_ctx *c, const zk_mle *const *f, uint64_t k, uint64_t n_rps,
+                                              const uint32_t *lens, const uint64_t sum[4], const uint64_t *rps,
+                                              int32_t *out_ok) {
+    if (!sum || !out_ok || (n_rps && (!rps || !lens))) return ZK_ERR_BAD_ARG;
     ZKCHK(product_args(c, f, k));
     if (n_rps != f[0]->n_vars) return ZK_ERR_VERIFY_ROUNDS;              // verifier.rs:17-19
+    ZKCHK(check_lens(n_rps, lens));
     Sponge sp;
     sp.init();
     ZKCHK(absorb_tables(c, sp, (zk_mle *const *)f, k));                  // :22
     std::vector<uint64_t> ch(4 * (n_rps + 1));
     Fe claimed;
-    ZKCHK(verify_internal(c->fi->P, sp, n_rps, D, sum, rps, claimed, ch.data()));
+    ZKCHK(verify_internal(c->fi->P, sp, n_rps, lens, sum, rps, claimed, ch.data()));
     uint64_t ev[4];
     ZKCHK(zk_product_evaluate(c, f, k, ch.data(), n_rps, ev));           // :27-29
     *out_ok = fe_eq(fe_from_u64limbs(ev), claimed) ? 1 : 0;              // :31
     return ZK_OK;
+}
+extern "C" int32_t zk_sumcheck_verify(zk_ctx *c, const zk_mle *const *f, uint64_t k, uint64_t n_rps, uint32_t D,
+                                      const uint64_t sum[4], const uint64_t *rps, int32_t *out_ok) {
+    if (D >= kMaxSums) return ZK_ERR_BAD_ARG;
+    const std::vector<uint32_t> lens(n_rps + 1, D + 1);
+    return zk_sumcheck_verify_lengths(c, f, k, n_rps, lens.data(), sum, rps, out_ok);
 }
 
 // ------------------------------------------------------------------------------------------------------------

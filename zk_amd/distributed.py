@@ -183,6 +183,13 @@ class GpuShardBackend:
         check(lib.zk_shard_prover_run(self._h, comm._h, gather_below))
         return self.results()
 
+    def run_phases(self, comm, gather_below=10):
+        """the same run with the library's HIP-event breakdown -> (round_polys, challenges, {phase: ms})"""
+        ms = (c.c_double * 4)()
+        check(lib.zk_shard_prover_run_phases(self._h, comm._h, gather_below, ms))
+        rp, ch = self.results()
+        return rp, ch, {"local_kernels_ms": ms[0], "allreduce_ms": ms[1], "gather_ms": ms[2], "tail_rounds_ms": ms[3]}
+
     def local_vars_left(self):
         """variables of the local shard tables that no completed round has consumed yet"""
         loc, done = c.c_uint64(), c.c_uint64()

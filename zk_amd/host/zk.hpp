@@ -254,33 +254,38 @@ public:
 
 template <class F>
 class SumcheckVerifier {
-    static std::vector<uint64_t> flatten(const SumcheckProof<F> &proof, uint32_t &D) {
-        D = proof.round_polys.empty() ? 0 : (uint32_t)proof.round_polys[0].size() - 1;
+    // round_polys is a Vec<Vec<F>>: every round goes to the library at its own length (verifier.rs:55-58)
+    static std::vector<uint64_t> flatten(const SumcheckProof<F> &proof, std::vector<uint32_t> &lens) {
         std::vector<uint64_t> rp;
-        for (auto &row : proof.round_polys)
+        lens.clear();
+        for (auto &row : proof.round_polys) {
+            lens.push_back((uint32_t)row.size());
             for (auto &e : row) rp.insert(rp.end(), e.l.begin(), e.l.end());
+        }
+        lens.push_back(0);
         rp.resize(rp.size() + 4);
         return rp;
     }
 
 public:
     static Result<bool> verify(const ProductPoly<F> &poly, const SumcheckProof<F> &proof) {   // verifier.rs:15-33
-        uint32_t D;
-        auto rp = flatten(proof, D);
+        std::vector<uint32_t> lens;
+        auto rp = flatten(proof, lens);
         auto h = poly.handles();
         int32_t ok = 0;
-        const int32_t rc = zk_sumcheck_verify(context<F>(), h.data(), h.size(), proof.round_polys.size(), D, proof.sum.l.data(),
-                                              rp.data(), &ok);
+        const int32_t rc = zk_sumcheck_verify_lengths(context<F>(), h.data(), h.size(), proof.round_polys.size(), lens.data(),
+                                                      proof.sum.l.data(), rp.data(), &ok);
         if (rc != ZK_OK) return rc;
         return ok != 0;
     }
     static Result<SubClaim<F>> verify_partial(const SumcheckProof<F> &proof) {   // verifier.rs:38-41
-        uint32_t D;
-        auto rp = flatten(proof, D);
+        std::vector<uint32_t> lens;
+        auto rp = flatten(proof, lens);
         const size_t n = proof.round_polys.size();
         std::vector<uint64_t> ch(4 * n + 4);
         SubClaim<F> sub;
-        const int32_t rc = zk_sumcheck_verify_partial(F::id, n, D, proof.sum.l.data(), rp.data(), sub.sum.l.data(), ch.data());
+        const int32_t rc = zk_sumcheck_verify_partial_lengths(F::id, n, lens.data(), proof.sum.l.data(), rp.data(),
+                                                              sub.sum.l.data(), ch.data());
         if (rc != ZK_OK) return rc;
         sub.challenges.resize(n);
         for (size_t r = 0; r < n; ++r)
