@@ -526,8 +526,7 @@ def test_skip1_rounds_bit_exact():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    base = {k: v for k, v in os.environ.items()
-            if k not in ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES", "ZK_LANE_ACC")}
+    base = {k: v for k, v in os.environ.items() if k not in ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES")}
     runs = [
         # SKIP1 kernels everywhere (no quad kernel, no pipeline: they would take the small rounds)
         dict(ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0"),
@@ -539,10 +538,6 @@ def test_skip1_rounds_bit_exact():
         dict(ZK_PIPE_MAX_PAIRS="131072", ZK_SKIP1_MIN_PAIRS="1", ZK_CHECK_SIZES="11,12,13,15,17"),
         # the pipeline with defaults at more sizes
         dict(ZK_CHECK_SIZES="10,12,14,16,18"),
-        # per-block partials + the classic tail instead of the lane accumulator (the sharded prover's and the runtime-k kernels'
-        # path), SKIP1 forced, and with the pipeline entered from it
-        dict(ZK_LANE_ACC="0", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0", ZK_CHECK_SIZES="3,7,11,13"),
-        dict(ZK_LANE_ACC="0", ZK_CHECK_SIZES="7,12,14,16"),
     ]
     for extra in runs:
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "skip1_check.py")], env=dict(base, **extra), capture_output=True,

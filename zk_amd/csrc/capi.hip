@@ -36,9 +36,6 @@ struct zk_ctx {
     hipStream_t own_stream;
     hipStream_t stream;
     uint64_t *d_partials;   // per-block partial sums of a round: kMaxGrid * kMaxSums elements
-    uint64_t *d_lane_acc;   // lane accumulator of the specialised round kernels (common.cuh): all zero between rounds
-    bool lane_acc_dirty;    // a failed launch may have left digits in it: cleared before the next use
-    Mul29 prep_r1;          // prepared multiplier of R mod p (fe_reduce_wide9)
     uint64_t *d_sums;       // final round sums (kMaxSums elements) + lanes area
     uint64_t *h_pinned;     // pinned staging: kMaxSums*8 u64
     uint8_t *h_results;     // pinned staging for proofs (grown on demand)
@@ -283,13 +280,6 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     c->fi = fi;
     c->own_stream = nullptr;
     c->d_partials = c->d_sums = c->h_pinned = nullptr;
-    c->d_lane_acc = nullptr;
-    c->lane_acc_dirty = false;
-    {
-        Fe r1;
-        for (int i = 0; i < 8; ++i) r1.v[i] = fi->P.r1[i];
-        c->prep_r1 = mul29_prepare(r1, fi->P);
-    }
     c->h_results = nullptr;
     c->h_results_bytes = 0;
     c->pool_bytes = c->pool_checked = 0;
@@ -304,8 +294,6 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     c->stream = c->own_stream;
     HIPCHK(hipMalloc(&c->d_partials, (size_t)kMaxGrid * kMaxSums * 32));
     HIPCHK(hipMalloc(&c->d_sums, (size_t)kMaxSums * 32 * 3));
-    HIPCHK(hipMalloc(&c->d_lane_acc, kLaneAccWords * 8));
-    HIPCHK(hipMemset(c->d_lane_acc, 0, kLaneAccWords * 8));
     HIPCHK(hipHostMalloc(&c->h_pinned, (size_t)kMaxSums * 32 * 3, hipHostMallocDefault));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
@@ -327,7 +315,6 @@ extern "C" int32_t zk_ctx_destroy(zk_ctx *c) {
     for (auto &kv : c->pool)
         for (void *q : kv.second) (void)hipFree(q);
     (void)hipFree(c->d_partials);
-    (void)hipFree(c->d_lane_acc);
     (void)hipFree(c->d_sums);
     (void)hipHostFree(c->h_pinned);
     if (c->h_results) (void)hipHostFree(c->h_results);
@@ -901,7 +888,7 @@ static int32_t results_staging(zk_ctx *c, size_t bytes, uint8_t **out) {
 }
 
 static inline RoundLaunchCtx launch_ctx(zk_ctx *c) {
-    RoundLaunchCtx lc = {c->stream, &c->fi->P, c->d_partials, (uint64_t)kMaxGrid * kMaxSums, nullptr};
+    RoundLaunchCtx lc = {c->stream, &c->fi->P, c->d_partials, (uint64_t)kMaxGrid * kMaxSums};
     return lc;
 }
 static inline bool fast_degree(uint32_t D) { return D >= 1 && D <= 4; }
@@ -936,27 +923,7 @@ static inline TermSpec single_term(int k) {
 struct DeferredTail {
     uint32_t blocks;
     bool skip1;
-    bool lanes;   // the sums sit in the context's lane accumulator, not in d_partials
 };
-// ZK_LANE_ACC=0 keeps per-block partials everywhere (A/B runs, tests of the classic tail)
-static bool lane_acc_on() {
-    static const bool v = [] {
-        const char *e = getenv("ZK_LANE_ACC");
-        return !(e && e[0] == '0');
-    }();
-    return v;
-}
-// the tail of a round whose kernels have just been launched: per-block partials (`blocks` of them) or the lane accumulator
-static int32_t launch_tail(zk_ctx *c, uint32_t blocks, bool lanes, uint32_t ns, const TailTargets &tt, const TailDerive &dv) {
-    if (lanes)
-        k_round_tail_lanes<<<1, kBlock, 0, c->stream>>>(c->d_lane_acc, ns, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge, c->fi->P,
-                                                        c->prep_r1, dv);
-    else
-        k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, blocks, ns, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge, tt.lanes,
-                                                  c->fi->P, dv);
-    HIPCHK(hipGetLastError());
-    return ZK_OK;
-}
 static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, uint64_t q, uint32_t D, bool fused,
                            const uint64_t *d_r, const TailTargets &tt, const TailDerive *dv = nullptr, DeferredTail *defer = nullptr) {
     if (defer) defer->blocks = 0;
@@ -965,31 +932,23 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
         uint32_t total = 0;
         int first = 0;
         bool skip1 = dv && dv->prev_rp && fused && !tt.lanes && D <= (uint32_t)kMaxSkipDegree && q >= skip1_min_pairs();
-        // lane accumulator instead of per-block partials: single-GPU rounds whose every term has a specialised kernel
-        bool lanes = lane_acc_on() && !tt.lanes && D + 1 <= (uint32_t)kLaneMaxSums;
-        for (int i = 0; i < ts.n_terms && lanes; ++i) lanes = round_shape_has_lanes(ts.term_k[i], D);
-        if (lanes && c->lane_acc_dirty) {
-            HIPCHK(hipMemsetAsync(c->d_lane_acc, 0, kLaneAccWords * 8, c->stream));
-            c->lane_acc_dirty = false;
-        }
         if (ts.n_terms == 2 && ts.term_k[1] == 1) {   // product + one single-factor term (a GKR layer): one pass
             uint32_t g = 0;
-            RoundLaunchCtx lc = launch_ctx(c);
-            if (lanes) lc.d_lane_acc = c->d_lane_acc;
-            const int lrc = launch_round_plus1(lc, fp, ts.term_k[0], q, D, fused, d_r, &g, &skip1);
+            const int lrc = launch_round_plus1(launch_ctx(c), fp, ts.term_k[0], q, D, fused, d_r, &g, &skip1);
             if (lrc == kLaunchHipError) {
                 g_hip_err = "round kernel launch failed";
-                c->lane_acc_dirty = lanes;
                 return ZK_ERR_HIP;
             }
             if (lrc == kLaunchOk) {
                 if (defer) {
                     defer->blocks = g;
                     defer->skip1 = skip1;
-                    defer->lanes = lanes;
                     return ZK_OK;
                 }
-                return launch_tail(c, g, lanes, D + 1, tt, skip1 ? *dv : TailDerive{});
+                k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, g, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
+                                                          tt.lanes, P, skip1 ? *dv : TailDerive{});
+                HIPCHK(hipGetLastError());
+                return ZK_OK;
             }
         }
         if (ts.n_terms != 1) skip1 = false;
@@ -1002,14 +961,11 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
             RoundLaunchCtx lc = launch_ctx(c);
             lc.d_partials += (size_t)total * (D + 1) * 4;
             lc.capacity_elems -= (uint64_t)total * (D + 1);
-            if (lanes) lc.d_lane_acc = c->d_lane_acc;   // every term adds into the same lanes: the sum over terms is free here too
             uint32_t g = 0;
             const int lrc = launch_round(lc, sub, ts.term_k[i], q, D, fused, d_r, &g, &skip1);
-            if (lrc != kLaunchOk) c->lane_acc_dirty = lanes && i > 0;
             if (lrc == kLaunchUnsupported) return ZK_ERR_UNSUPPORTED;
             if (lrc != kLaunchOk) {
                 g_hip_err = "round kernel launch failed";
-                c->lane_acc_dirty = lanes;
                 return ZK_ERR_HIP;
             }
             total += g;
@@ -1018,10 +974,12 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
         if (defer) {
             defer->blocks = total;
             defer->skip1 = skip1;
-            defer->lanes = lanes;
             return ZK_OK;
         }
-        return launch_tail(c, total, lanes, D + 1, tt, skip1 ? *dv : TailDerive{});
+        k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, total, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
+                                                  tt.lanes, P, skip1 ? *dv : TailDerive{});
+        HIPCHK(hipGetLastError());
+        return ZK_OK;
     }
     if (ts.n_terms != 1) return ZK_ERR_UNSUPPORTED;
     const int k = ts.term_k[0];
@@ -1438,10 +1396,6 @@ static int32_t pipe_enter(RoundState &st, const DeferredTail &dt) {
     pl.e_partials = epart_of_round(st, st.round + 1);
     pl.done_counter = epart_counter(st, st.round + 1);
     pl.tail = pipe_tail_args(st, 0, c->d_partials, dt.blocks, st.D + 1);
-    if (dt.lanes) {
-        pl.tail.lane_acc = c->d_lane_acc;
-        pl.tail.prep_r1 = c->prep_r1;
-    }
     if (dt.skip1) {
         pl.tail.dv = st.dv;
         pl.tail.dv.prev_rp = pl.tail.out_rp - (size_t)(st.D + 1) * 4;
@@ -1586,7 +1540,7 @@ static int32_t prover_step(RoundState &st, bool *finished_in_kernel) {
     // the table of this round has m_s variables; if the NEXT round belongs to the pipeline, this round's tail is merged
     // into the launch that prepares it
     const uint64_t m_s = st.pending_fold ? st.vars_left - 1 : st.vars_left;
-    DeferredTail dt = {0, false, false};
+    DeferredTail dt = {0, false};
     const bool enter = fast_degree(st.D) && pipe_wants_next(st, m_s);
     ZKCHK(round_enqueue(st, nullptr, enter ? &dt : nullptr));
     // dt.blocks == 0: round_enqueue's contract for "the tail was launched after all" (a sums path that cannot defer it) --

@@ -22,65 +22,7 @@ struct TermSpec {
     int n_terms;
     int term_k[kMaxTerms];
 };
-// ---- lane accumulators: a round's sums as exact integer digit lanes ---------------------------------------------------------
-// The big and middle round kernels do not store per-block partial sums (2048 blocks x (D+1) elements = 196 KB that ONE workgroup
-// of the tail then has to pull in from the memory side: 4-6 us of the serial chain at n = 24).  Every wave adds its (D+1) reduced
-// sums as 8 zero-extended 32-bit digits into uint64 lanes with device-scope atomic adds -- integer sums are exact, up to 2^32
-// addends cannot overflow a lane -- spread over kLaneSlots slots by block index; the tail reads kLaneSlots * (D+1) * 8 words,
-// adds the slots, carry-propagates and reduces mod p once (fe_reduce_wide9): the same canonical element as the modular sum.
-// Layout: acc[slot][t][8] u64, t < ns <= kLaneMaxSums.  The buffer is all zero between rounds: the tail that reads it zeroes it.
-constexpr int kLaneSlots = 16;
-constexpr int kLaneMaxSums = 5;                                           // the fast degrees: D <= 4
-constexpr size_t kLaneAccWords = (size_t)kLaneSlots * kLaneMaxSums * 8;   // u64 words per accumulator
 #if defined(__HIPCC__)
-// After every wave has left its reduced sums in red[wave][t][0..7] (LDS) and the workgroup has synchronised: threads
-// (wave, t, digit) add them to this block's slot.  One wave-instruction carries 8 * NS digits; nothing is returned or waited for.
-template <int NW, int NS, bool SKIP1 = false>
-ZK_D void lane_acc_add_block(uint64_t *__restrict__ acc, const uint32_t (*red)[NS][8]) {
-    if (threadIdx.x < (uint32_t)(NW * NS * 8)) {
-        const uint32_t w = threadIdx.x / (NS * 8), r = threadIdx.x % (NS * 8), t = r >> 3;
-        if (!(SKIP1 && t == 1))
-            atomicAdd(reinterpret_cast<unsigned long long *>(acc) + (size_t)(blockIdx.x & (kLaneSlots - 1)) * (NS * 8) + r,
-                      (unsigned long long)red[w][t][r & 7]);
-    }
-}
-// The consumer (all threads of a 256-thread workgroup): out[t] (LDS) = sum of slot sums mod p, t < ns; zeroes the accumulator.
-// lacc: LDS scratch of kLaneMaxSums * 8 words.  Ends with a barrier.
-ZK_D void lane_acc_collect(uint64_t *__restrict__ acc, uint32_t ns, Fe *out, unsigned long long *lacc, const Mul29 &prep_r1,
-                           const FieldParams &P) {
-    const uint32_t per = ns * 8, total = per * kLaneSlots;
-    unsigned long long v[(kLaneAccWords + 255) / 256];
-    // the loads first (one trip to the memory side for all of them), then the LDS scratch
-#pragma unroll
-    for (uint32_t u = 0; u < (uint32_t)((kLaneAccWords + 255) / 256); ++u) {
-        const uint32_t idx = threadIdx.x + u * blockDim.x;
-        v[u] = idx < total ? reinterpret_cast<const unsigned long long *>(acc)[idx] : 0ull;
-    }
-    if (threadIdx.x < per) lacc[threadIdx.x] = 0ull;
-    __syncthreads();
-#pragma unroll
-    for (uint32_t u = 0; u < (uint32_t)((kLaneAccWords + 255) / 256); ++u) {
-        const uint32_t idx = threadIdx.x + u * blockDim.x;
-        if (idx < total) {
-            acc[idx] = 0ull;   // ready for the next round that uses this accumulator (a later launch)
-            atomicAdd(&lacc[idx % per], v[u]);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < ns) {
-        uint32_t w[9];
-        unsigned long long carry = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            carry += lacc[threadIdx.x * 8 + i];
-            w[i] = (uint32_t)carry;
-            carry >>= 32;
-        }
-        w[8] = (uint32_t)carry;
-        out[threadIdx.x] = fe_reduce_wide9(w, prep_r1, P);
-    }
-    __syncthreads();
-}
 ZK_D Mul29 load_challenge29(const uint64_t *rptr) {
     const uint32_t *w = reinterpret_cast<const uint32_t *>(rptr) + 8;
     Mul29 r;

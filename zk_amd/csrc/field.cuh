@@ -516,22 +516,6 @@ ZK_HD Fe fe_mul29_t(const Fe &a, const Mul29 &c, const FieldParams &P) {
 }
 ZK_HD Fe fe_mul29(const Fe &a, const Mul29 &c, const FieldParams &P) { return fe_mul29_t<false>(a, c, P); }
 
-// V mod p for a 9-limb integer V (the exact integer sum of up to 2^32 field elements, e.g. of block sums accumulated as
-// digit lanes): V = lo + hi * 2^256 with lo any 256-bit integer and hi = limb 8.  The carry-free multiplier takes ANY 256-bit
-// integer as its first operand and returns the canonical representative, so
-//   lo mod p = lo * R * 2^-256 = fe_mul29(lo, prepare(R)),      hi * 2^256 mod p = hi * R^2 * 2^-256 = fe_mul29(hi, prepare(R^2))
-// (two independent multiplications and one addition; prep_r1 = mul29_prepare(R mod p), r2_29 is in the field parameters).
-ZK_HD Fe fe_reduce_wide9(const uint32_t v[9], const Mul29 &prep_r1, const FieldParams &P) {
-    Fe lo, hi = fe_zero();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) lo.v[i] = v[i];
-    hi.v[0] = v[8];
-    Mul29 r2;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r2.l[i] = P.r2_29[i];
-    return fe_add(fe_mul29(lo, prep_r1, P), fe_mul29(hi, r2, P), P);
-}
-
 // ---- 32-byte element I/O (two 16-byte accesses: global_load_dwordx4 / global_store_dwordx4) ---------------
 #if defined(__HIPCC__)
 ZK_D Fe fe_load(const uint64_t *base, uint64_t idx) {

@@ -301,54 +301,6 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
     }
 }
 
-// The same second stage for rounds whose kernels added their sums to the lane accumulator (common.cuh): nothing to pull in
-// but kLaneSlots * ns * 8 words; slots added in LDS, one carry propagation and one reduction mod p per sum (lane t), then the
-// derive / store / transcript steps of k_round_tail.  Leaves the accumulator zero.
-__global__ __launch_bounds__(kBlock) void k_round_tail_lanes(uint64_t *__restrict__ lane_acc, uint32_t ns, WordSponge *__restrict__ sponge,
-                                                             uint64_t *__restrict__ out_rp, uint64_t *__restrict__ out_ch,
-                                                             uint64_t *__restrict__ d_challenge, FieldParams P, Mul29 prep_r1, TailDerive dv) {
-    __shared__ Fe fin[kLaneMaxSums];
-    __shared__ Fe claim;
-    __shared__ unsigned long long lacc[kLaneMaxSums * 8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool wave0 = __builtin_amdgcn_readfirstlane(wave) == 0;
-    const bool derive1 = dv.prev_rp != nullptr;   // the accumulator carries no t = 1 sums (k_round_kd SKIP1)
-    const LaneKeccak L = lane_keccak_init();
-    LaneSponge sp = {0, 0};
-    if (sponge && wave0) sp = lane_sponge_load(sponge, L);
-    if (derive1 && __builtin_amdgcn_readfirstlane(wave) == 1) {
-        // claim = S_prev(r_prev) = sum_t prev[t] * w[t] * prod_{u != t} (r - u)   (lane t takes term t), while the lanes come in
-        const Fe r = fe_load(dv.prev_chal, 0);
-        Fe term = fe_zero();
-        if ((uint32_t)lane < ns) {
-            const Fe one = fe_one(P);
-            term = fe_mul(fe_load(dv.prev_rp, lane), fe_load(dv.w, lane), P);
-            Fe node = fe_zero();   // Montgomery form of u
-            for (uint32_t u = 0; u < ns; ++u) {
-                if (u != (uint32_t)lane) term = fe_mul(term, fe_sub(r, node, P), P);
-                node = fe_add(node, one, P);
-            }
-        }
-        term = fe_wave_sum(term, P, 8);
-        if (lane == 0) claim = term;
-    }
-    lane_acc_collect(lane_acc, ns, fin, lacc, prep_r1, P);   // (barriers inside: every thread takes part)
-    if (derive1) {
-        if (threadIdx.x == 0) fin[1] = fe_sub(claim, fin[0], P);   // S(1) = S_prev(r_prev) - S(0)
-        __syncthreads();
-    }
-    if (threadIdx.x == kBlock - 64) {   // the last wave stores the round polynomial while wave 0 runs the transcript
-        for (uint32_t t = 0; t < ns; ++t)
-            if (out_rp) fe_store(out_rp, t, fin[t]);
-    }
-    if (sponge && wave0) {
-        Mul29 ch29;
-        const Fe ch = transcript_step(sp, L, fin, ns, P, ch29);
-        publish_challenge(d_challenge, out_ch, ch, ch29, L.lane);
-        lane_sponge_store(sponge, sp, L);
-    }
-}
-
 // ---- finisher: all remaining rounds of the prover in ONE launch, once the tables are small ---------------------------
 // A round on a tiny table is pure latency (two launches, a trip through HBM for 96 bytes of sums, the serial transcript).
 // One workgroup keeps the K tables (<= 2^kFinishVars elements each) in LDS and the sponge in the registers of wave 0 and

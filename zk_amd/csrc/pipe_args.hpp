@@ -16,8 +16,6 @@ struct PipeTailArgs {
     uint64_t *out_rp, *out_ch;
     Fe inv2;
     TailDerive dv;              // mode 0 after a SKIP1 round kernel
-    uint64_t *lane_acc;         // mode 0: the round kernel added its sums to this lane accumulator (common.cuh) instead of `partials`
-    Mul29 prep_r1;              // ... and the prepared multiplier of R mod p its reduction needs (fe_reduce_wide9)
     uint64_t *dbg;              // optional: 100 MHz timestamps of the phases (ZK_PIPE_DEBUG), 32 slots per launch
 };
 

@@ -276,11 +276,7 @@ ZK_D void pipe_tail_block(const PipeTailArgs &ta, const FieldParams &P) {
     if (wave0) dbg_stamp(ta.dbg, 0);
     if (wave0) sp = lane_sponge_load(ta.sponge, L);   // in flight while the partials are reduced
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    __shared__ unsigned long long lacc[kLaneMaxSums * 8];
-    if (ta.lane_acc) {       // plain sums of a classic round kernel, left as digit lanes
-        lane_acc_collect(ta.lane_acc, ta.n_in, red, lacc, ta.prep_r1, P);
-        if (wave >= 2) return;
-    } else if (ta.nblocks == 1) {   // already reduced (the last work block of the launch before did it)
+    if (ta.nblocks == 1) {   // already reduced (the last work block of the launch before did it)
         if (wave >= 2) return;
         if (wave0 && lane < 16 && lane < ta.n_in) red[lane] = fe_load(ta.partials, lane);
     } else {

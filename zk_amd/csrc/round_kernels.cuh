@@ -8,10 +8,8 @@ namespace zk {
 
 // ---- workgroup reduction of NS field elements per thread -> partials[block][NS] -------------------------------
 // SKIP1: sum[1] is not computed by the caller (the tail derives S(1) from the previous round's claim): not reduced, not stored.
-// lane_acc != null: the waves' sums go to the lane accumulator instead (common.cuh: exact integer digit lanes, no per-block
-// partials for the tail to pull in).
 template <int NS, bool SKIP1 = false>
-ZK_D void block_reduce_store(Fe (&sum)[NS], uint64_t *__restrict__ partials, const FieldParams &P, uint64_t *__restrict__ lane_acc = nullptr) {
+ZK_D void block_reduce_store(Fe (&sum)[NS], uint64_t *__restrict__ partials, const FieldParams &P) {
     __shared__ uint32_t red[kBlock / 64][NS][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -24,10 +22,6 @@ ZK_D void block_reduce_store(Fe (&sum)[NS], uint64_t *__restrict__ partials, con
         }
     }
     __syncthreads();
-    if (lane_acc) {
-        lane_acc_add_block<kBlock / 64, NS, SKIP1>(lane_acc, red);
-        return;
-    }
     if (threadIdx.x < NS && !(SKIP1 && threadIdx.x == 1)) {
         const int t = threadIdx.x;
         Fe acc;
@@ -181,8 +175,7 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, u
 // is bit-identical to the computed one); k_round_tail rebuilds it from the previous round polynomial.
 template <int K, int D, bool FUSED, int EXTRA = 0, bool SKIP1 = false>
 __global__ __launch_bounds__(kBlock, (K + EXTRA <= 2 ? 2 : 1)) void k_round_kd(FactorPtrs fp, uint64_t q, FieldParams P,
-                                                        const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials,
-                                                        uint64_t *__restrict__ lane_acc) {
+                                                        const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials) {
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
     Mul29 r = {};
     if (FUSED) r = load_challenge29(rptr);
@@ -226,7 +219,7 @@ __global__ __launch_bounds__(kBlock, (K + EXTRA <= 2 ? 2 : 1)) void k_round_kd(F
         for (int t = 0; t < NS; ++t)
             if (!(SKIP1 && t == 1)) R.sum[t] = fe_add(R.sum[t], R.sum_b[t], P);
     }
-    block_reduce_store<NS, SKIP1>(R.sum, partials, P, lane_acc);
+    block_reduce_store<NS, SKIP1>(R.sum, partials, P);
 }
 
 // ---- small fused rounds: one FACTOR per lane, one EVALUATION POINT per lane, four lanes per pair index -----------------
@@ -237,10 +230,10 @@ __global__ __launch_bounds__(kBlock, (K + EXTRA <= 2 ? 2 : 1)) void k_round_kd(F
 // per pair index, spread over 4x the lanes: the per-lane chain drops to ~1100-1400 instructions.  K + EXTRA <= 4, D <= 3.
 template <int K, int D, int EXTRA>
 __global__ __launch_bounds__(kBlock) void k_round_quad(FactorPtrs fp, uint64_t q, FieldParams P, const uint64_t *__restrict__ rptr,
-                                                       uint64_t *__restrict__ partials, uint64_t *__restrict__ lane_acc) {
+                                                       uint64_t *__restrict__ partials) {
     constexpr int NF = K + EXTRA, NS = D + 1;
     static_assert(NF <= 4 && NS <= 4, "four lanes per pair index");
-    __shared__ uint32_t red[kBlock / 64][NS][8];
+    __shared__ uint32_t red[kBlock / 64][4][8];
     const Mul29 r = load_challenge29(rptr);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l4 = lane & 3;
     const bool has_factor = l4 < (uint32_t)NF;
@@ -322,15 +315,11 @@ __global__ __launch_bounds__(kBlock) void k_round_quad(FactorPtrs fp, uint64_t q
         s = fe_add(s, fe_dpp<0x128>(s), P);
         s = fe_add(s, fe_dpp<0x12C>(s), P);
     }
-    if (lane < (uint32_t)NS) {
+    if (lane < 4) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) red[wave][lane][i] = s.v[i];
     }
     __syncthreads();
-    if (lane_acc) {
-        lane_acc_add_block<kBlock / 64, NS>(lane_acc, red);
-        return;
-    }
     if (threadIdx.x < (uint32_t)NS) {
         Fe tot = fe_zero();
         for (int wv = 0; wv < kBlock / 64; ++wv) {

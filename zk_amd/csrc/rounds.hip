@@ -34,7 +34,7 @@ static uint32_t launch_quad(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint
     uint64_t g = (q + 63) / 64;
     const uint64_t cap = (q + 64ull * kMaxLazy - 1) / (64ull * kMaxLazy);
     if (g > 2048) g = cap > 2048 ? cap : 2048;
-    k_round_quad<K, D, EXTRA><<<(uint32_t)g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.d_lane_acc);
+    k_round_quad<K, D, EXTRA><<<(uint32_t)g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
     return (uint32_t)g;
 }
 static inline uint32_t round_grid(uint64_t q) {
@@ -52,8 +52,8 @@ static inline uint32_t capped_grid(uint64_t q) {
 
 template <int K, int D>
 static void launch_kd(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, bool fused, const uint64_t *d_r, uint32_t g) {
-    if (fused) k_round_kd<K, D, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.d_lane_acc);
-    else k_round_kd<K, D, false><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.d_lane_acc);
+    if (fused) k_round_kd<K, D, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+    else k_round_kd<K, D, false><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
 }
 template <int D>
 static void launch_generic(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, bool fused, const uint64_t *d_r, uint32_t g) {
@@ -61,16 +61,11 @@ static void launch_generic(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k
     else k_round<D, false><<<g, kBlock, 0, lc.stream>>>(fp, k, q, *lc.P, d_r, lc.d_partials);
 }
 
-bool round_shape_has_lanes(int k, uint32_t D) {
-    const int shape = k * 10 + (int)D;
-    return shape == 11 || shape == 12 || shape == 21 || shape == 22 || shape == 23 || shape == 32 || shape == 33;
-}
 int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused,
                  const uint64_t *d_r, uint32_t *out_grid, bool *skip1) {
     if (D < 1 || D > 4 || k < 1 || k > kMaxFactors) return kLaunchUnsupported;
-    if (lc.d_lane_acc && !round_shape_has_lanes(k, D)) return kLaunchUnsupported;   // the runtime-k kernel writes partials only
     uint32_t g = round_grid(q);
-    if (fused && q >= 16 && q <= 4 * quad_max_pairs() && (lc.d_lane_acc || (uint64_t)2048 * (D + 1) <= lc.capacity_elems)) {
+    if (fused && q >= 16 && q <= 4 * quad_max_pairs() && (uint64_t)2048 * (D + 1) <= lc.capacity_elems) {
         // measured cross-over (MI355X, BN254): 2^15 pairs for k = 2, 2^17 for k = 3 (its lane does 14 multiplies per pair index)
         const int shq = k * 10 + (int)D;
         uint32_t gq = 0;
@@ -84,10 +79,10 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
         }
     }
     if (skip1 && *skip1) {   // the variants without the t = 1 products exist for the GKR-style shapes, fused only
-        const bool fits1 = lc.d_lane_acc || (uint64_t)g * (D + 1) <= lc.capacity_elems;
+        const bool fits1 = (uint64_t)g * (D + 1) <= lc.capacity_elems;
         const int shape1 = (fits1 && fused) ? k * 10 + (int)D : 0;
-        if (shape1 == 22) k_round_kd<2, 2, true, 0, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.d_lane_acc);
-        else if (shape1 == 33) k_round_kd<3, 3, true, 0, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.d_lane_acc);
+        if (shape1 == 22) k_round_kd<2, 2, true, 0, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        else if (shape1 == 33) k_round_kd<3, 3, true, 0, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
         else *skip1 = false;
         if (*skip1) {
             if (hipGetLastError() != hipSuccess) return kLaunchHipError;
@@ -95,7 +90,7 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
             return kLaunchOk;
         }
     }
-    const bool fits = lc.d_lane_acc || (uint64_t)g * (D + 1) <= lc.capacity_elems;
+    const bool fits = (uint64_t)g * (D + 1) <= lc.capacity_elems;
     // specialised shapes (GKR-style products have D = k): everything else takes the runtime-k kernel
     const int shape = fits ? k * 10 + (int)D : 0;
     switch (shape) {
@@ -124,9 +119,9 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
 int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused,
                        const uint64_t *d_r, uint32_t *out_grid, bool *skip1) {
     const uint32_t g = round_grid(q);
-    if (!lc.d_lane_acc && (uint64_t)g * (D + 1) > lc.capacity_elems) return kLaunchUnsupported;
+    if ((uint64_t)g * (D + 1) > lc.capacity_elems) return kLaunchUnsupported;
     const int shape = k * 10 + (int)D;
-    if (fused && shape == 22 && q >= 16 && q <= quad_max_pairs() && (lc.d_lane_acc || (uint64_t)2048 * (D + 1) <= lc.capacity_elems)) {
+    if (fused && shape == 22 && q >= 16 && q <= quad_max_pairs() && (uint64_t)2048 * (D + 1) <= lc.capacity_elems) {
         const uint32_t gq = launch_quad<2, 2, 1>(lc, fp, q, d_r);
         if (skip1) *skip1 = false;
         if (hipGetLastError() != hipSuccess) return kLaunchHipError;
@@ -135,12 +130,12 @@ int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, ui
     }
     if (skip1 && *skip1 && !(shape == 22 && fused)) *skip1 = false;
     if (shape == 22) {
-        if (fused && skip1 && *skip1) k_round_kd<2, 2, true, 1, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.d_lane_acc);
-        else if (fused) k_round_kd<2, 2, true, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.d_lane_acc);
-        else k_round_kd<2, 2, false, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.d_lane_acc);
+        if (fused && skip1 && *skip1) k_round_kd<2, 2, true, 1, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        else if (fused) k_round_kd<2, 2, true, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        else k_round_kd<2, 2, false, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
     } else if (shape == 33) {
-        if (fused) k_round_kd<3, 3, true, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.d_lane_acc);
-        else k_round_kd<3, 3, false, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.d_lane_acc);
+        if (fused) k_round_kd<3, 3, true, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        else k_round_kd<3, 3, false, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
     } else {
         return kLaunchUnsupported;
     }
