@@ -2149,7 +2149,7 @@ static int32_t ntt_run_plan(zk_ctx *c, const NttPlan &pl, const uint64_t *in, ui
     const uint64_t *src = in;
     for (uint32_t p = 0; p < pl.n_pass && rc == ZK_OK; ++p) {
         const uint32_t R = 1u << pl.l[p];
-        const size_t lds = 2 * (size_t)R * kNttRowBytes + (size_t)(R / 2) * kTw29Words * 4;
+        const size_t lds = (size_t)R * kNttRowBytes + (size_t)(R / 2) * kTw29Words * 4;   // one plane (halves take turns) + twiddles
         const uint32_t tiles = (uint32_t)(n / ((uint64_t)R * kNttCols));
         const bool last = p + 1 == pl.n_pass;
         hipError_t e = ntt_launch_pass(pl, p, last, tiles, lds, c->stream, src, last ? out : scratch, P, scale, (last && inverse) ? 1 : 0);

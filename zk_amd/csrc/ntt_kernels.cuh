@@ -26,7 +26,7 @@ namespace zk {
 
 constexpr int kNttColsLog = 3;
 constexpr int kNttCols = 1 << kNttColsLog;   // tile columns (consecutive contiguous-axis indices)
-constexpr int kNttRowBytes = kNttCols * 16 + 16;   // one 16-B slot per column + 16 B pad: 2 x 256 rows = 72 KiB, two workgroups per CU (a 32-B pad no longer fits two: 2.95 ms)
+constexpr int kNttRowBytes = kNttCols * 16 + 16;   // one 16-B slot per column + 16 B pad; ONE plane of 256 rows = 36 KiB (+ 8 KiB of twiddles): three workgroups per CU
 constexpr int kNttThreads = 32 * kNttCols;
 constexpr int kNttMaxLog = 8;         // R <= 256
 
@@ -34,7 +34,7 @@ constexpr int kNttMaxLog = 8;         // R <= 256
 // has a table value as one operand, so the tables hold omega^e * 2^5 mod p -- the low table already split into nine
 // 29-bit limbs (Mul29, 64-byte records), the high table as a plain element so that two levels compose with one more
 // fe_mul29:  hi' (x) lo' = (w_hi 2^5)(w_lo 2^5) 2^-261 = (w_hi w_lo) 2^5, again a prepared value.
-constexpr int kTw29Words = 16;   // record stride of a stored Mul29 (9 words used)
+constexpr int kTw29Words = 16;   // record stride of a stored Mul29 (9 words used; 48 bytes keeps the two 16-byte reads aligned)
 struct NttPlan {
     uint32_t log_n;
     uint32_t n_pass;
@@ -82,6 +82,22 @@ ZK_D Fe lds_get(const unsigned char *lo_plane, const unsigned char *hi_plane, ui
 ZK_D void lds_put(unsigned char *lo_plane, unsigned char *hi_plane, uint32_t row, uint32_t col, const Fe &v) {
     *reinterpret_cast<uint4 *>(lo_plane + lds_off(row, col)) = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
     *reinterpret_cast<uint4 *>(hi_plane + lds_off(row, col)) = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+}
+
+// Half-element forms: the tile crosses LDS one 16-byte half at a time (low 128 bits of every element, then the high ones)
+// through ONE plane, so a workgroup holds 36 KiB + twiddles instead of 72 KiB and three workgroups share a CU (the passes
+// are bound by VALU issue: rocprofv3 r03 shows 2 waves per SIMD parked 23 % and issue-stalled 29 % of their cycles).
+ZK_D void lds_put_half(unsigned char *plane, uint32_t row, uint32_t col, const Fe &v, int half) {
+    *reinterpret_cast<uint4 *>(plane + lds_off(row, col)) =
+        half ? make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]) : make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+}
+ZK_D void lds_get_half(const unsigned char *plane, uint32_t row, uint32_t col, Fe &v, int half) {
+    const uint4 a = *reinterpret_cast<const uint4 *>(plane + lds_off(row, col));
+    if (half) {
+        v.v[4] = a.x; v.v[5] = a.y; v.v[6] = a.z; v.v[7] = a.w;
+    } else {
+        v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w;
+    }
 }
 
 // ---- lazy arithmetic inside a transform ------------------------------------------------------------------------------------
@@ -167,6 +183,8 @@ ZK_D void ntt_group_stages(Fe (&x)[1 << (S_HI - S_LO + 1)], uint32_t post, const
 
 // One pass over one tile.  LAST = false: pass p < P (strided axis, inter-pass twiddle, same addresses in and out);
 // LAST = true: pass P (contiguous axis, transposing store, optional scaling by n^-1 for the inverse transform).
+// (measured on one box, 2^24 forward: two planes / 2 workgroups per CU 1.885 ms; this form, 3 per CU, 1.807; an unpadded swizzled
+// plane with 48-byte twiddle records capped at 128 VGPRs for 4 per CU spills 27 dwords and is back at 1.889: profiles/r03_ntt_*)
 template <int L, bool LAST>
 __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
                                                           NttPlan pl, uint32_t pass, FieldParams P, Mul29 scale, int do_scale) {
@@ -174,9 +192,8 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
     constexpr uint32_t l = L, R = 1u << L;
     using GR = NttGroups<L>;
     constexpr int G0 = GR::g0, G1 = GR::g1, G2 = GR::g2;
-    unsigned char *lo_plane = smem;
-    unsigned char *hi_plane = smem + (size_t)R * kNttRowBytes;
-    uint32_t *tws = reinterpret_cast<uint32_t *>(smem + 2 * (size_t)R * kNttRowBytes);   // prepared omega_R^j, j < R/2
+    unsigned char *plane = smem;                                                          // ONE plane of R rows (halves take turns)
+    uint32_t *tws = reinterpret_cast<uint32_t *>(smem + (size_t)R * kNttRowBytes);       // prepared omega_R^j, j < R/2
 
     uint32_t lo_sum = 0;   // log2 O_p
     for (uint32_t p = 0; p < pass; ++p) lo_sum += pl.l[p];
@@ -216,35 +233,34 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
     }
     const uint64_t *w_full = LAST ? nullptr : pl.w_full[pass];
     const Mod2p M2 = mod2p_of(P);
-    __syncthreads();   // tws ready
 
+    // Every thread owns at most ONE work item per group ((R >> G) * kNttCols <= kNttThreads for R <= 2^8), so a group's 2^G
+    // elements stay in its registers across the exchange: rows out / rows in are written and read one 16-byte half at a time.
     // ---- group 0: stages l-1 .. l-G0, rows (u << (l-G0)) | post, straight from HBM ----
     // thread -> (post, t).  MID: t fastest (512-B runs along the contiguous axis); LAST: post fastest (runs along the DFT axis)
     constexpr uint32_t items0 = (R >> G0) * kNttCols;
-    {
-        constexpr int S_LO = L - G0;
-        for (uint32_t it = tid; it < items0; it += kNttThreads) {
-            uint32_t t, post;
-            if (!LAST) {
-                t = it & (kNttCols - 1);
-                post = it >> kNttColsLog;
-            } else {
-                post = it & ((1u << S_LO) - 1);
-                t = it >> S_LO;
-            }
-            Fe x[1 << G0];
+    static_assert(items0 <= (uint32_t)kNttThreads, "one item per thread and group");
+    constexpr int S_LO0 = L - G0;
+    const bool has0 = tid < items0;
+    uint32_t t0, post0;
+    if (!LAST) {
+        t0 = tid & (kNttCols - 1);
+        post0 = tid >> kNttColsLog;
+    } else {
+        post0 = tid & ((1u << S_LO0) - 1);
+        t0 = tid >> S_LO0;
+    }
+    Fe x0[1 << G0];
+    if (has0) {
 #pragma unroll
-            for (int u = 0; u < (1 << G0); ++u) {
-                const uint32_t a = ((uint32_t)u << S_LO) | post;
-                x[u] = LAST ? fe_load(in, base_in + ((uint64_t)t << t_shift) + a) : fe_load(in, base_in + ((uint64_t)a << log_inner) + t);
-            }
-            ntt_group_stages<L, L - 1, S_LO>(x, post, tws, P, M2);
-#pragma unroll
-            for (int u = 0; u < (1 << G0); ++u) lds_put(lo_plane, hi_plane, ((uint32_t)u << S_LO) | post, t, x[u]);
+        for (int u = 0; u < (1 << G0); ++u) {
+            const uint32_t a = ((uint32_t)u << S_LO0) | post0;
+            x0[u] = LAST ? fe_load(in, base_in + ((uint64_t)t0 << t_shift) + a) : fe_load(in, base_in + ((uint64_t)a << log_inner) + t0);
         }
     }
-    __syncthreads();
-    // ---- group 1 (and 2): in registers between LDS exchanges; the LAST group of the tile stores to HBM ----
+    __syncthreads();   // tws ready
+    if (has0) ntt_group_stages<L, L - 1, S_LO0>(x0, post0, tws, P, M2);
+
     auto store_out = [&](uint32_t row, uint32_t t, Fe v) {
         const uint32_t k = __brev(row) >> (32 - l);   // DIF leaves frequency k in row bitrev(k)
         if (!LAST) {
@@ -270,38 +286,77 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt_pass(const uint64_t *__rest
     } else if constexpr (GR::n == 2) {
         constexpr int S_HI = L - G0 - 1;   // group 1 covers S_HI .. 0
         constexpr uint32_t items1 = (R >> G1) * kNttCols;
-        for (uint32_t it = tid; it < items1; it += kNttThreads) {
-            const uint32_t t = it & (kNttCols - 1), pre = it >> kNttColsLog;
-            Fe x[1 << G1];
+        static_assert(items1 <= (uint32_t)kNttThreads, "one item per thread and group");
+        const bool has1 = tid < items1;
+        const uint32_t t1 = tid & (kNttCols - 1), pre1 = tid >> kNttColsLog;
+        Fe x1[1 << G1];
 #pragma unroll
-            for (int u = 0; u < (1 << G1); ++u) x[u] = lds_get(lo_plane, hi_plane, (pre << G1) | u, t);
-            ntt_group_stages<L, S_HI, 0>(x, 0, tws, P, M2);
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();   // everybody has read the low halves
+            if (has0) {
 #pragma unroll
-            for (int u = 0; u < (1 << G1); ++u) store_out((pre << G1) | u, t, x[u]);
+                for (int u = 0; u < (1 << G0); ++u) lds_put_half(plane, ((uint32_t)u << S_LO0) | post0, t0, x0[u], half);
+            }
+            __syncthreads();
+            if (has1) {
+#pragma unroll
+                for (int u = 0; u < (1 << G1); ++u) lds_get_half(plane, (pre1 << G1) | u, t1, x1[u], half);
+            }
+        }
+        if (has1) {
+            ntt_group_stages<L, S_HI, 0>(x1, 0, tws, P, M2);
+#pragma unroll
+            for (int u = 0; u < (1 << G1); ++u) store_out((pre1 << G1) | u, t1, x1[u]);
         }
     } else {
         constexpr int S_HI1 = L - G0 - 1, S_LO1 = S_HI1 - G1 + 1;   // group 1: S_HI1 .. S_LO1, group 2: S_LO1-1 .. 0
-        constexpr uint32_t items1 = (R >> G1) * kNttCols;
-        for (uint32_t it = tid; it < items1; it += kNttThreads) {
-            const uint32_t t = it & (kNttCols - 1), rr = it >> kNttColsLog;
-            const uint32_t post = rr & ((1u << S_LO1) - 1), pre = rr >> S_LO1;
-            Fe x[1 << G1];
+        constexpr uint32_t items1 = (R >> G1) * kNttCols, items2 = (R >> G2) * kNttCols;
+        static_assert(items1 <= (uint32_t)kNttThreads && items2 <= 2 * (uint32_t)kNttThreads, "one item per thread in group 1, at most two in group 2");
+        constexpr uint32_t IPT2 = items2 > (uint32_t)kNttThreads ? 2 : 1;   // (L = 8: 3 + 3 + 2 stages -> two 4-row items per thread)
+        const bool has1 = tid < items1;
+        const uint32_t t1 = tid & (kNttCols - 1), rr1 = tid >> kNttColsLog;
+        const uint32_t post1 = rr1 & ((1u << S_LO1) - 1), pre1 = rr1 >> S_LO1;
+        Fe x1[1 << G1];
 #pragma unroll
-            for (int u = 0; u < (1 << G1); ++u) x[u] = lds_get(lo_plane, hi_plane, (pre << (S_HI1 + 1)) | ((uint32_t)u << S_LO1) | post, t);
-            ntt_group_stages<L, S_HI1, S_LO1>(x, post, tws, P, M2);
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();
+            if (has0) {
 #pragma unroll
-            for (int u = 0; u < (1 << G1); ++u) lds_put(lo_plane, hi_plane, (pre << (S_HI1 + 1)) | ((uint32_t)u << S_LO1) | post, t, x[u]);
+                for (int u = 0; u < (1 << G0); ++u) lds_put_half(plane, ((uint32_t)u << S_LO0) | post0, t0, x0[u], half);
+            }
+            __syncthreads();
+            if (has1) {
+#pragma unroll
+                for (int u = 0; u < (1 << G1); ++u) lds_get_half(plane, (pre1 << (S_HI1 + 1)) | ((uint32_t)u << S_LO1) | post1, t1, x1[u], half);
+            }
         }
-        __syncthreads();
-        constexpr uint32_t items2 = (R >> G2) * kNttCols;
-        for (uint32_t it = tid; it < items2; it += kNttThreads) {
-            const uint32_t t = it & (kNttCols - 1), pre = it >> kNttColsLog;
-            Fe x[1 << G2];
+        if (has1) ntt_group_stages<L, S_HI1, S_LO1>(x1, post1, tws, P, M2);
+        Fe x2[IPT2][1 << G2];
 #pragma unroll
-            for (int u = 0; u < (1 << G2); ++u) x[u] = lds_get(lo_plane, hi_plane, (pre << G2) | u, t);
-            ntt_group_stages<L, G2 - 1, 0>(x, 0, tws, P, M2);
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();   // the plane is free again (group 1's reads of the high halves / group 2's of the low halves are done)
+            if (has1) {
 #pragma unroll
-            for (int u = 0; u < (1 << G2); ++u) store_out((pre << G2) | u, t, x[u]);
+                for (int u = 0; u < (1 << G1); ++u) lds_put_half(plane, (pre1 << (S_HI1 + 1)) | ((uint32_t)u << S_LO1) | post1, t1, x1[u], half);
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t w = 0; w < IPT2; ++w) {
+                const uint32_t it = tid + w * kNttThreads, t2 = it & (kNttCols - 1), pre2 = it >> kNttColsLog;
+                if (it < items2) {
+#pragma unroll
+                    for (int u = 0; u < (1 << G2); ++u) lds_get_half(plane, (pre2 << G2) | u, t2, x2[w][u], half);
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t w = 0; w < IPT2; ++w) {
+            const uint32_t it = tid + w * kNttThreads, t2 = it & (kNttCols - 1), pre2 = it >> kNttColsLog;
+            if (it < items2) {
+                ntt_group_stages<L, G2 - 1, 0>(x2[w], 0, tws, P, M2);
+#pragma unroll
+                for (int u = 0; u < (1 << G2); ++u) store_out((pre2 << G2) | u, t2, x2[w][u]);
+            }
         }
     }
 }
