@@ -34,7 +34,7 @@ constexpr int kNttMaxLog = 8;         // R <= 256
 // has a table value as one operand, so the tables hold omega^e * 2^5 mod p -- the low table already split into nine
 // 29-bit limbs (Mul29, 64-byte records), the high table as a plain element so that two levels compose with one more
 // fe_mul29:  hi' (x) lo' = (w_hi 2^5)(w_lo 2^5) 2^-261 = (w_hi w_lo) 2^5, again a prepared value.
-constexpr int kTw29Words = 16;   // record stride of a stored Mul29 (9 words used; 48 bytes keeps the two 16-byte reads aligned)
+constexpr int kTw29Words = 16;   // record stride of a stored Mul29 (9 words used)
 struct NttPlan {
     uint32_t log_n;
     uint32_t n_pass;
