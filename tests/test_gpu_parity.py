@@ -526,7 +526,8 @@ def test_skip1_rounds_bit_exact():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    base = {k: v for k, v in os.environ.items() if k not in ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES")}
+    base = {k: v for k, v in os.environ.items()
+            if k not in ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES", "ZK_LEAD_MIN_PAIRS")}
     runs = [
         # SKIP1 kernels everywhere (no quad kernel, no pipeline: they would take the small rounds)
         dict(ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0"),
@@ -538,6 +539,12 @@ def test_skip1_rounds_bit_exact():
         dict(ZK_PIPE_MAX_PAIRS="131072", ZK_SKIP1_MIN_PAIRS="1", ZK_CHECK_SIZES="11,12,13,15,17"),
         # the pipeline with defaults at more sizes
         dict(ZK_CHECK_SIZES="10,12,14,16,18"),
+        # LEAD kernels everywhere (slot D = leading coefficient, the tail rebuilds S(D)): with SKIP1 in every fused round, classic tails
+        dict(ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0"),
+        # ... and with the pipeline entered right after a LEAD + SKIP1 round (the transcript block derives S(1), then rebuilds S(D))
+        dict(ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="11,12,13,15"),
+        # LEAD in round 0 only (sums-only kernel), everything else default
+        dict(ZK_LEAD_MIN_PAIRS="1", ZK_CHECK_SIZES="3,9,14,16"),
     ]
     for extra in runs:
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "skip1_check.py")], env=dict(base, **extra), capture_output=True,

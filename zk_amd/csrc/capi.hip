@@ -923,7 +923,17 @@ static inline TermSpec single_term(int k) {
 struct DeferredTail {
     uint32_t blocks;
     bool skip1;
+    bool lead;    // slot D of the partials holds the leading coefficient (k_round_kd LEAD)
 };
+// Rounds with at least this many pairs accumulate the leading coefficient instead of S(D) (k_round_kd LEAD): one modular
+// addition per factor and pair index fewer against three to six more in the tail.  ZK_LEAD_MIN_PAIRS overrides (tests).
+static uint64_t lead_min_pairs() {
+    static const uint64_t v = [] {
+        const char *e = getenv("ZK_LEAD_MIN_PAIRS");
+        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)1 << 18;
+    }();
+    return v;
+}
 static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, uint64_t q, uint32_t D, bool fused,
                            const uint64_t *d_r, const TailTargets &tt, const TailDerive *dv = nullptr, DeferredTail *defer = nullptr) {
     if (defer) defer->blocks = 0;
@@ -932,9 +942,15 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
         uint32_t total = 0;
         int first = 0;
         bool skip1 = dv && dv->prev_rp && fused && !tt.lanes && D <= (uint32_t)kMaxSkipDegree && q >= skip1_min_pairs();
+        bool lead = !tt.lanes && q >= lead_min_pairs();   // (the launchers clear it for shapes without the variant)
+        auto tail_dv = [&]() {
+            TailDerive t = skip1 && dv ? *dv : TailDerive{};
+            t.lead = lead ? D : 0;
+            return t;
+        };
         if (ts.n_terms == 2 && ts.term_k[1] == 1) {   // product + one single-factor term (a GKR layer): one pass
             uint32_t g = 0;
-            const int lrc = launch_round_plus1(launch_ctx(c), fp, ts.term_k[0], q, D, fused, d_r, &g, &skip1);
+            const int lrc = launch_round_plus1(launch_ctx(c), fp, ts.term_k[0], q, D, fused, d_r, &g, &skip1, &lead);
             if (lrc == kLaunchHipError) {
                 g_hip_err = "round kernel launch failed";
                 return ZK_ERR_HIP;
@@ -943,15 +959,16 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
                 if (defer) {
                     defer->blocks = g;
                     defer->skip1 = skip1;
+                    defer->lead = lead;
                     return ZK_OK;
                 }
                 k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, g, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
-                                                          tt.lanes, P, skip1 ? *dv : TailDerive{});
+                                                          tt.lanes, P, tail_dv());
                 HIPCHK(hipGetLastError());
                 return ZK_OK;
             }
         }
-        if (ts.n_terms != 1) skip1 = false;
+        if (ts.n_terms != 1) skip1 = lead = false;
         for (int i = 0; i < ts.n_terms; ++i) {
             FactorPtrs sub = {};
             for (int f = 0; f < ts.term_k[i]; ++f) {
@@ -962,7 +979,7 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
             lc.d_partials += (size_t)total * (D + 1) * 4;
             lc.capacity_elems -= (uint64_t)total * (D + 1);
             uint32_t g = 0;
-            const int lrc = launch_round(lc, sub, ts.term_k[i], q, D, fused, d_r, &g, &skip1);
+            const int lrc = launch_round(lc, sub, ts.term_k[i], q, D, fused, d_r, &g, &skip1, &lead);
             if (lrc == kLaunchUnsupported) return ZK_ERR_UNSUPPORTED;
             if (lrc != kLaunchOk) {
                 g_hip_err = "round kernel launch failed";
@@ -974,10 +991,11 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
         if (defer) {
             defer->blocks = total;
             defer->skip1 = skip1;
+            defer->lead = lead;
             return ZK_OK;
         }
         k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, total, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
-                                                  tt.lanes, P, skip1 ? *dv : TailDerive{});
+                                                  tt.lanes, P, tail_dv());
         HIPCHK(hipGetLastError());
         return ZK_OK;
     }
@@ -1401,6 +1419,7 @@ static int32_t pipe_enter(RoundState &st, const DeferredTail &dt) {
         pl.tail.dv.prev_rp = pl.tail.out_rp - (size_t)(st.D + 1) * 4;
         pl.tail.dv.prev_chal = chal_prev(st);
     }
+    pl.tail.dv.lead = dt.lead ? st.D : 0;
     FactorPtrs fp = {};
     for (uint64_t i = 0; i < st.k; ++i) fp.in[i] = fp.out[i] = st.cur[i];
     uint32_t g = 0;
@@ -1540,7 +1559,7 @@ static int32_t prover_step(RoundState &st, bool *finished_in_kernel) {
     // the table of this round has m_s variables; if the NEXT round belongs to the pipeline, this round's tail is merged
     // into the launch that prepares it
     const uint64_t m_s = st.pending_fold ? st.vars_left - 1 : st.vars_left;
-    DeferredTail dt = {0, false};
+    DeferredTail dt = {0, false, false};
     const bool enter = fast_degree(st.D) && pipe_wants_next(st, m_s);
     ZKCHK(round_enqueue(st, nullptr, enter ? &dt : nullptr));
     // dt.blocks == 0: round_enqueue's contract for "the tail was launched after all" (a sums path that cannot defer it) --

@@ -89,7 +89,20 @@ struct TailDerive {
     const uint64_t *prev_rp;   // null: nothing to derive
     const uint64_t *prev_chal; // challenge record of the previous round (r_{i-1})
     const uint64_t *w;         // the D + 1 weights, device memory (one buffer per context and degree)
+    uint32_t lead;             // D > 0: slot D of the sums holds the leading coefficient L (k_round_kd LEAD); rebuild S(D)
 };
+// S(D) of a degree-D round polynomial from S(0..D-1) and its leading coefficient L (in S[D]): D <= 3
+ZK_HD Fe lead_rebuild(uint32_t D, const Fe *S, const FieldParams &P) {
+    const Fe L = S[D];
+    if (D == 1) return fe_add(S[0], L, P);                                       // S1 = S0 + L
+    if (D == 2) {                                                                // S2 = 2 (S1 + L) - S0
+        const Fe a = fe_add(S[1], L, P);
+        return fe_sub(fe_add(a, a, P), S[0], P);
+    }
+    Fe b = fe_add(fe_sub(S[2], S[1], P), fe_add(L, L, P), P);                    // S3 = S0 + 3 (S2 - S1 + 2 L)
+    b = fe_add(fe_add(b, b, P), b, P);
+    return fe_add(S[0], b, P);
+}
 
 // Sum of one field element per lane over a wave, entirely on the VALU: v_permlane32_swap / v_permlane16_swap (gfx950)
 // across wave halves and 16-lane rows, DPP row rotations inside a row -- no ds_bpermute round trips.  Lanes >= width

@@ -282,8 +282,11 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
         if (lane == 0) fin[t] = s;
     }
     __syncthreads();
-    if (derive1) {
-        if (threadIdx.x == 0) fin[1] = fe_sub(claim, fin[0], P);   // S(1) = S_prev(r_prev) - S(0)
+    if (derive1 || dv.lead) {
+        if (threadIdx.x == 0) {
+            if (derive1) fin[1] = fe_sub(claim, fin[0], P);        // S(1) = S_prev(r_prev) - S(0)
+            if (dv.lead) fin[dv.lead] = lead_rebuild(dv.lead, fin, P);   // slot D held the leading coefficient (k_round_kd LEAD)
+        }
         __syncthreads();
     }
     if (threadIdx.x == kBlock - 64) {   // the last wave stores the round polynomial while wave 0 runs the transcript

@@ -17,12 +17,14 @@ enum { kLaunchOk = 0, kLaunchUnsupported = -1, kLaunchHipError = -2 };
 // One round: (fold at *d_r when fused +) sums for t = 0..D over q pairs -> per-block partials; *out_grid blocks.
 // skip1 (optional, in/out): request the variant that leaves out the t = 1 sums (S(1) is derived by the tail); set to false
 // when the shape has no such variant and the full kernel was launched instead.
+// lead (optional, in/out): request the variant whose slot D accumulates the leading coefficient instead of S(D) (k_round_kd
+// LEAD; the tail rebuilds S(D)); set to false when the launched kernel has no such variant.
 int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused,
-                 const uint64_t *d_r, uint32_t *out_grid, bool *skip1 = nullptr);
+                 const uint64_t *d_r, uint32_t *out_grid, bool *skip1 = nullptr, bool *lead = nullptr);
 // Terms {k, 1} of a sum of products in one pass: fp = the k factors of the product, then the single-factor term
 // ((k, D) = (2, 2) or (3, 3); anything else returns kLaunchUnsupported and the caller launches term by term).
 int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused,
-                       const uint64_t *d_r, uint32_t *out_grid, bool *skip1 = nullptr);
+                       const uint64_t *d_r, uint32_t *out_grid, bool *skip1 = nullptr, bool *lead = nullptr);
 // One evaluation point (any degree): sums of prod_f (lo - t*(lo-hi)) -> per-block partials (1 sum per block).
 int launch_round_single_t(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, const Fe &tval, uint32_t *out_grid);
 

@@ -321,6 +321,12 @@ ZK_D void pipe_tail_block(const PipeTailArgs &ta, const FieldParams &P) {
                 const Fe s0 = red[0];
                 if (lane == 1) s = fe_sub(c0, s0, P);
             }
+            if (ta.dv.lead) {   // slot D holds the leading coefficient (k_round_kd LEAD): lane D rebuilds S(D) from the others
+                if (lane < (uint32_t)NS) fin[lane] = s;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == ta.dv.lead) s = lead_rebuild(ta.dv.lead, fin, P);
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         if (lane < (uint32_t)NS) {
             fin[lane] = s;

@@ -125,9 +125,15 @@ struct RoundRegs {
     Fe sum_b[EXTRA ? NS : 1];
     WideAcc acc[K > 1 ? NS : 1];
 };
-template <int F, int K, int D, bool FUSED, int EXTRA, bool SKIP1 = false>
+// LEAD (K == D, big rounds): the last evaluation point is not formed.  The round polynomial has degree D with leading
+// coefficient L = sum_x prod_f (hi_f - lo_f), so slot D accumulates prod_f diff_f instead of prod_f (v_f(D-1) + diff_f) -- one
+// modular addition per factor and pair index fewer -- and the tail rebuilds S(D) = sum_{i<D} (-1)^(D-1-i) C(D,i) S(i) + D! L
+// (the D-th finite difference of a degree-D polynomial is D! times its leading coefficient; exact in F_p, so the same
+// canonical element the reference's direct sum gives).  The single-factor extra term is linear: it adds nothing to L.
+template <int F, int K, int D, bool FUSED, int EXTRA, bool SKIP1 = false, bool LEAD = false>
 ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, uint64_t j, uint64_t jn, bool more, uint64_t q,
                        const Mul29 &r, const FieldParams &P, uint64_t jnn = 0, bool more2 = false) {
+    static_assert(!LEAD || (K == D && D >= 1), "the leading-coefficient slot needs deg = K = D");
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
     Fe lo, hi;
     if (FUSED) {
@@ -158,9 +164,11 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, u
     Fe v = lo;
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
-        if (t == 1) v = hi;
+        if (LEAD && t == D) v = diff;                                   // slot D: the leading coefficient
+        else if (t == 1) v = hi;
         else if (t > 1) v = fe_add(v, diff, P);
         if (SKIP1 && t == 1) continue;                                  // S(1) = claim - S(0): derived in the tail
+        if (LEAD && t == D && F == K) continue;                         // a linear term has no degree-D coefficient
         if (F == K) R.sum_b[t] = fe_add(R.sum_b[t], v, P);            // the extra single-factor term
         else if (K == 1) R.sum[t] = fe_add(R.sum[t], v, P);
         else if (F == 0) R.prod[t] = v;
@@ -173,7 +181,7 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, u
 // SKIP1 (big fused rounds): the products for t = 1 are not formed at all -- S_i(0) + S_i(1) = S_{i-1}(r_{i-1}) holds
 // identically for the sums the prover itself computed in the previous round (exact field arithmetic, so the derived S_i(1)
 // is bit-identical to the computed one); k_round_tail rebuilds it from the previous round polynomial.
-template <int K, int D, bool FUSED, int EXTRA = 0, bool SKIP1 = false>
+template <int K, int D, bool FUSED, int EXTRA = 0, bool SKIP1 = false, bool LEAD = false>
 __global__ __launch_bounds__(kBlock, (K + EXTRA <= 2 ? 2 : 1)) void k_round_kd(FactorPtrs fp, uint64_t q, FieldParams P,
                                                         const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials) {
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
@@ -203,10 +211,10 @@ __global__ __launch_bounds__(kBlock, (K + EXTRA <= 2 ? 2 : 1)) void k_round_kd(F
     while (j < q) {
         const uint64_t jn = j + stride, jnn = jn + stride;
         const bool more = jn < q, more2 = jnn < q;
-        round_factor<0, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P, jnn, more2);
-        if constexpr (K + EXTRA > 1) round_factor<1, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P, jnn, more2);
-        if constexpr (K + EXTRA > 2) round_factor<2, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P, jnn, more2);
-        if constexpr (K + EXTRA > 3) round_factor<3, K, D, FUSED, EXTRA, SKIP1>(R, fp, j, jn, more, q, r, P, jnn, more2);
+        round_factor<0, K, D, FUSED, EXTRA, SKIP1, LEAD>(R, fp, j, jn, more, q, r, P, jnn, more2);
+        if constexpr (K + EXTRA > 1) round_factor<1, K, D, FUSED, EXTRA, SKIP1, LEAD>(R, fp, j, jn, more, q, r, P, jnn, more2);
+        if constexpr (K + EXTRA > 2) round_factor<2, K, D, FUSED, EXTRA, SKIP1, LEAD>(R, fp, j, jn, more, q, r, P, jnn, more2);
+        if constexpr (K + EXTRA > 3) round_factor<3, K, D, FUSED, EXTRA, SKIP1, LEAD>(R, fp, j, jn, more, q, r, P, jnn, more2);
         j = jn;
     }
     if (K > 1) {

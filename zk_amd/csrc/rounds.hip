@@ -62,9 +62,33 @@ static void launch_generic(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k
 }
 
 int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused,
-                 const uint64_t *d_r, uint32_t *out_grid, bool *skip1) {
+                 const uint64_t *d_r, uint32_t *out_grid, bool *skip1, bool *lead) {
     if (D < 1 || D > 4 || k < 1 || k > kMaxFactors) return kLaunchUnsupported;
     uint32_t g = round_grid(q);
+    bool no_lead = false;
+    if (!lead) lead = &no_lead;
+    // LEAD variants: (2,2) and (3,3), sums-only (round 0) or fused with SKIP1 (the big rounds after it)
+    if (*lead && !((k == 2 && D == 2) || (k == 3 && D == 3))) *lead = false;
+    if (*lead && (uint64_t)g * (D + 1) <= lc.capacity_elems) {
+        const int shl = k * 10 + (int)D;
+        bool done = true;
+        if (!fused) {
+            if (shl == 22) k_round_kd<2, 2, false, 0, false, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+            else k_round_kd<3, 3, false, 0, false, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+            if (skip1) *skip1 = false;
+        } else if (skip1 && *skip1) {
+            if (shl == 22) k_round_kd<2, 2, true, 0, true, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+            else k_round_kd<3, 3, true, 0, true, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        } else {
+            done = false;
+        }
+        if (done) {
+            if (hipGetLastError() != hipSuccess) return kLaunchHipError;
+            *out_grid = g;
+            return kLaunchOk;
+        }
+    }
+    *lead = false;
     if (fused && q >= 16 && q <= 4 * quad_max_pairs() && (uint64_t)2048 * (D + 1) <= lc.capacity_elems) {
         // measured cross-over (MI355X, BN254): 2^15 pairs for k = 2, 2^17 for k = 3 (its lane does 14 multiplies per pair index)
         const int shq = k * 10 + (int)D;
@@ -117,10 +141,24 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
 
 // Terms {k, 1}: the k-factor product plus one single-factor term in one pass (fp lists the k factors, then the extra one).
 int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused,
-                       const uint64_t *d_r, uint32_t *out_grid, bool *skip1) {
+                       const uint64_t *d_r, uint32_t *out_grid, bool *skip1, bool *lead) {
     const uint32_t g = round_grid(q);
     if ((uint64_t)g * (D + 1) > lc.capacity_elems) return kLaunchUnsupported;
     const int shape = k * 10 + (int)D;
+    bool no_lead = false;
+    if (!lead) lead = &no_lead;
+    if (*lead && shape == 22 && (!fused || (skip1 && *skip1))) {   // the GKR layer polynomial W*H + B: sums-only or fused + SKIP1
+        if (!fused) {
+            k_round_kd<2, 2, false, 1, false, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+            if (skip1) *skip1 = false;
+        } else {
+            k_round_kd<2, 2, true, 1, true, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        }
+        if (hipGetLastError() != hipSuccess) return kLaunchHipError;
+        *out_grid = g;
+        return kLaunchOk;
+    }
+    *lead = false;
     if (fused && shape == 22 && q >= 16 && q <= quad_max_pairs() && (uint64_t)2048 * (D + 1) <= lc.capacity_elems) {
         const uint32_t gq = launch_quad<2, 2, 1>(lc, fp, q, d_r);
         if (skip1) *skip1 = false;
