@@ -47,6 +47,7 @@ struct zk_ctx {
     std::map<size_t, std::vector<void *>> pool;                // freed device blocks by exact size (stream-ordered reuse)
     size_t pool_bytes, pool_checked;
     Fe inv2;                // 1/2 (pipelined rounds interpolate on the nodes 0, 1, -1, inf)
+    PipeConsts pipe_consts; // its prepared multiplier + the constant 2^266 mod p (pipe_kernels.cuh pipe_eval_canon)
     uint64_t *d_dbg;        // ZK_PIPE_DEBUG: phase timestamps of the pipelined launches (64 launches x 32 slots + finisher)
     uint32_t dbg_launch;
     uint8_t *h_absorb[2];   // pinned staging of absorb_tables (prove / verify), kept across calls
@@ -284,6 +285,12 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     c->h_results_bytes = 0;
     c->pool_bytes = c->pool_checked = 0;
     c->inv2 = fe_inverse(fe_from_u32(2, fi->P), fi->P);
+    c->pipe_consts.inv2p = mul29_prepare(c->inv2, fi->P);
+    {
+        Fe v = {{1, 0, 0, 0, 0, 0, 0, 0}};   // the integer 1; doubled 266 times modulo p (fe_add works on any residues < p)
+        for (int i = 0; i < 266; ++i) v = fe_add(v, v, fi->P);
+        split29(v.v, c->pipe_consts.k266.l);
+    }
     c->d_dbg = nullptr;
     c->dbg_launch = 0;
     c->h_absorb[0] = c->h_absorb[1] = nullptr;
@@ -1360,7 +1367,7 @@ static int32_t finish_pipe_enqueue(RoundState &st) {
     fl.entry = st.pipe_active ? 2 : (st.pending_fold ? 1 : 0);
     fl.e_partials = epart_of_round(st, st.round);
     fl.e_blocks = 1;   // slot 0 of the buffer holds the total
-    fl.inv2 = c->inv2;
+    fl.pc = c->pipe_consts;
     fl.chal_in = chal_prev(st);
     const uint64_t remaining = st.pending_fold ? st.vars_left - 1 : st.vars_left;
     fl.chal_last = chal_of_round(st, st.round + remaining - 1);
@@ -1394,7 +1401,7 @@ static PipeTailArgs pipe_tail_args(const RoundState &st, int mode, const uint64_
     ta.sponge = st.ps.d_sponge;
     ta.out_rp = st.ps.d_rp + st.round * (st.D + 1) * 4;
     ta.out_ch = st.ps.d_ch + st.round * 4;
-    ta.inv2 = st.c->inv2;
+    ta.pc = st.c->pipe_consts;
     return ta;
 }
 // Classic round st.round whose sums kernel has just been launched with its tail deferred (dt): ONE launch closes it

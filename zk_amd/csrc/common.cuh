@@ -13,9 +13,12 @@ struct FactorPtrs {
     uint64_t *out[kMaxFactors];
 };
 
-// Challenge record in device memory (written by the on-device transcript): 8 words of r (Montgomery form) followed by
-// the 9 words of its prepared multiplier form (Mul29 of r).  kChallengeBytes is the allocation size.
-constexpr int kChallengeBytes = 96;
+// Challenge record in device memory (written by the on-device transcript): 8 words of r (Montgomery form), the 9 words of
+// its prepared multiplier form (Mul29 of r: what folds multiply by), and the 9 words of the prepared form of the CANONICAL
+// challenge (Mul29 of r * R^-1: a Montgomery-form value times it is a canonical product -- the pipelined rounds close with
+// it, pipe_kernels.cuh pipe_eval_canon).  kChallengeBytes is the allocation size.
+constexpr int kChallengeBytes = 128;
+constexpr int kChalCanonWord = 17;   // 32-bit word offset of the canonical prepared form
 // A sum of products sum_i prod_{f in term i} T_f: the factors are listed flat (FactorPtrs), term after term.
 constexpr int kMaxTerms = 4;
 struct TermSpec {
@@ -23,6 +26,13 @@ struct TermSpec {
     int term_k[kMaxTerms];
 };
 #if defined(__HIPCC__)
+ZK_D Mul29 load_challenge29c(const uint64_t *rptr) {   // the prepared canonical form (wave-uniform -> SGPRs)
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(rptr) + kChalCanonWord;
+    Mul29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = __builtin_amdgcn_readfirstlane(w[i]);
+    return r;
+}
 ZK_D Mul29 load_challenge29(const uint64_t *rptr) {
     const uint32_t *w = reinterpret_cast<const uint32_t *>(rptr) + 8;
     Mul29 r;

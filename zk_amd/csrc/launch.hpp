@@ -59,7 +59,7 @@ struct FinishPipeLaunch {
     int entry;
     const uint64_t *e_partials;
     uint32_t e_blocks;
-    Fe inv2;
+    PipeConsts pc;
     const uint64_t *chal_in;
     uint64_t *chal_last;      // record the last challenge is published in
     WordSponge *sponge;

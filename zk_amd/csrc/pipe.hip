@@ -72,7 +72,7 @@ static hipError_t launch_fin_shape(const RoundLaunchCtx &lc, const FactorPtrs &f
     const size_t lds = finish_pipe_lds_bytes(K, EXTRA, fl.m_in);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_finish_pipe<K, D, EXTRA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_finish_pipe<K, D, EXTRA><<<1, kFinishPipeThreads, lds, lc.stream>>>(fp, fl.m_in, fl.entry, fl.e_partials, fl.e_blocks, *lc.P, fl.inv2, fl.chal_in,
+    k_finish_pipe<K, D, EXTRA><<<1, kFinishPipeThreads, lds, lc.stream>>>(fp, fl.m_in, fl.entry, fl.e_partials, fl.e_blocks, *lc.P, fl.pc, fl.chal_in,
                                                                          fl.chal_last, fl.sponge, fl.out_rp, fl.out_ch, fl.out_final, fl.dbg);
     return hipGetLastError();
 }

@@ -5,6 +5,12 @@
 
 namespace zk {
 
+// Constants of the transcript wave's evaluation (pipe_kernels.cuh pipe_eval_canon), prepared once per context on the host.
+struct PipeConsts {
+    Mul29 inv2p;   // prepared multiplier of 1/2 in Montgomery form (the K = 3 nodes 1 and -1)
+    Mul29 k266;    // limbs of 2^266 mod p: fe_mul29(x, k266) = x * 2^5 mod p, whose 29-bit split is the prepared CANONICAL challenge
+};
+
 struct PipeTailArgs {
     const uint64_t *partials;   // per-block partials of the round being closed: [block][n_in] elements
     uint32_t nblocks;
@@ -14,7 +20,7 @@ struct PipeTailArgs {
     uint64_t *chal_out;         // challenge record this round's challenge is published in
     WordSponge *sponge;
     uint64_t *out_rp, *out_ch;
-    Fe inv2;
+    PipeConsts pc;
     TailDerive dv;              // mode 0 after a SKIP1 round kernel
     uint64_t *dbg;              // optional: 100 MHz timestamps of the phases (ZK_PIPE_DEBUG), 32 slots per launch
 };

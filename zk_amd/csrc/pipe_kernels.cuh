@@ -214,22 +214,78 @@ ZK_D Fe hex_rows_sum(Fe s, const FieldParams &P) {
     return fe_add(a, b, P);
 }
 
-// S(t) from E(t; .) once the challenge r is known.  r29 = prepared multiplier form of r; inv2 = 1/2 (K == 3).
-template <int K>
-ZK_D Fe pipe_eval(const Fe (&e)[K + 1], const Mul29 &r29, const Fe &inv2, const FieldParams &P) {
+// S(t) from E(t; .) once the challenge r is known, in CANONICAL form, with the fewest DEPENDENT multiplications: the transcript
+// wave is the prover's serial chain and a lone wave pays ~0.8 us per carry-free multiplication whatever else it could overlap.
+//   * a Montgomery-form value times the prepared CANONICAL challenge (rc29) is a canonical product, so the LAST Horner step
+//     delivers canonical S directly -- no Montgomery -> canonical conversion in front of the absorb;
+//   * everything that does not depend on a previous product shares ONE multiplication, lane-parallel: row 0 (lanes t) takes the
+//     first Horner product e_inf * r, row 1 (lanes 16 + t) the canonical e_0 (times 2^5: a Montgomery reduction), rows 2 / 3 the
+//     halvings (e_1 +- e_-1) / 2 of K = 3; their per-lane multiplier comes from a small LDS table.
+// Dependent multiplications per round: K (plus the challenge's own conversion) instead of K + 2 (+ 1 for K = 3's halvings).
+// Exact field arithmetic: the canonical S is the reference's element (every prover test compares with the oracle).
+struct alignas(16) PipeEvalLds {
+    uint32_t cop[3][12];   // per-row multipliers, 48-byte slots (read 16 bytes at a time): [0] the challenge (prepared, Montgomery;
+                           // K = 1: canonical), [1] the constant 2^5 (a Montgomery reduction), [2] 1/2
+    Fe xch[3][4];          // what rows 1..3 hand to row 0: [0] canonical e_0, [1] (e_1 + e_-1)/2, [2] (e_1 - e_-1)/2
+};
+ZK_D Mul29 lds_mul29_load(const uint32_t *slot) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(slot);
+    const uint4 a = q[0], b = q[1];
+    Mul29 m = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, slot[8]}};
+    return m;
+}
+ZK_D void pipe_eval_set(PipeEvalLds &W, int slot, const Mul29 &m) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) W.cop[slot][i] = m.l[i];
+}
+// wave-uniform constants of the table (any lanes may call it; lanes 1, 2 write)
+ZK_D void pipe_eval_consts(PipeEvalLds &W, const PipeConsts &pc, uint32_t lane) {
+    if (lane == 1) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) W.cop[1][i] = i == 0 ? 32u : 0u;
+    }
+    if (lane == 2) pipe_eval_set(W, 2, pc.inv2p);
+}
+// red: E totals in LDS, [t * STRIDE + node].  rh29 / rc29: the two prepared forms of the challenge (wave-uniform).  Every lane of
+// the wave executes this; the result is valid on lanes t < D + 1.  Callers make W.cop[0] = (K == 1 ? rc29 : rh29) beforehand.
+template <int K, int D, int STRIDE = K + 1>
+ZK_D Fe pipe_eval_canon(const Fe *red, PipeEvalLds &W, const Mul29 &rh29, const Mul29 &rc29, uint32_t lane, const FieldParams &P) {
+    constexpr int NS = D + 1, NR = K + 1;
+    const uint32_t t = (lane & 15) < (uint32_t)NS ? (lane & 15) : 0, row = lane >> 4;
+    Fe e[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) e[i] = red[t * STRIDE + i];
+    // the first, shared multiplication
+    Fe a = row == 0 ? e[kPipeNodeInf] : e[kPipeNodeZero];
+    if constexpr (K == 3) {
+        const Fe sm = fe_add(e[kPipeNodeOne], e[kPipeNodeMinus], P), df = fe_sub(e[kPipeNodeOne], e[kPipeNodeMinus], P);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.v[i] = row == 2 ? sm.v[i] : (row == 3 ? df.v[i] : a.v[i]);
+    }
+    const Mul29 cm = lds_mul29_load(W.cop[row == 0 ? 0 : (row == 1 ? 1 : 2)]);
+    const Fe m1 = fe_mul29(a, cm, P);
+    if (row >= 1 && row <= (K == 3 ? 3u : 1u) && (lane & 15) < (uint32_t)NS) lds_fe_store(&W.xch[row - 1][t], m1);
+    __builtin_amdgcn_wave_barrier();   // same wave: LDS operations execute in order
+    const Fe e0c = lds_fe_load(&W.xch[0][t]);
     if constexpr (K == 1) {
-        return fe_add(e[kPipeNodeZero], fe_mul29(e[kPipeNodeInf], r29, P), P);
+        return fe_add(e0c, m1, P);                                                        // e0 + r * e_inf
     } else if constexpr (K == 2) {
         const Fe c1 = fe_sub(fe_sub(e[kPipeNodeOne], e[kPipeNodeZero], P), e[kPipeNodeInf], P);
-        return fe_add(e[kPipeNodeZero], fe_mul29(fe_add(c1, fe_mul29(e[kPipeNodeInf], r29, P), P), r29, P), P);
+        return fe_add(e0c, fe_mul29(fe_add(c1, m1, P), rc29, P), P);                      // e0 + r (c1 + r e_inf)
     } else {
-        // p(1) + p(-1) = 2(c0 + c2),  p(1) - p(-1) = 2(c1 + c3)
-        const Fe h = fe_mul(fe_add(e[kPipeNodeOne], e[kPipeNodeMinus], P), inv2, P), g = fe_mul(fe_sub(e[kPipeNodeOne], e[kPipeNodeMinus], P), inv2, P);
+        // p(1) + p(-1) = 2 (c0 + c2),  p(1) - p(-1) = 2 (c1 + c3)
+        const Fe h = lds_fe_load(&W.xch[1][t]), g = lds_fe_load(&W.xch[2][t]);
         const Fe c2 = fe_sub(h, e[kPipeNodeZero], P), c1 = fe_sub(g, e[kPipeNodeInf], P);
-        Fe acc = fe_add(c2, fe_mul29(e[kPipeNodeInf], r29, P), P);
-        acc = fe_add(c1, fe_mul29(acc, r29, P), P);
-        return fe_add(e[kPipeNodeZero], fe_mul29(acc, r29, P), P);
+        const Fe acc = fe_add(c1, fe_mul29(fe_add(c2, m1, P), rh29, P), P);
+        return fe_add(e0c, fe_mul29(acc, rc29, P), P);                                    // e0 + r (c1 + r (c2 + r e_inf))
     }
+}
+// the proof records Montgomery form: canonical -> Montgomery is one multiplication by R^2 (any wave, off the serial chain)
+ZK_D Fe fe_from_canonical29(const Fe &c, const FieldParams &P) {
+    Mul29 k0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k0.l[i] = P.r2_29[i];
+    return fe_mul29(c, k0, P);
 }
 
 ZK_D void dbg_stamp(uint64_t *dbg, int slot) {
@@ -265,10 +321,12 @@ ZK_D void pipe_reduce_partials(const uint64_t *__restrict__ partials, uint32_t n
 
 template <int K, int D>
 ZK_D void pipe_tail_block(const PipeTailArgs &ta, const FieldParams &P) {
-    constexpr int NS = D + 1, NR = K + 1;
+    constexpr int NS = D + 1;
     __shared__ Fe red[16];
     __shared__ Fe stage[4][16];
     __shared__ Fe fin[4];
+    __shared__ PipeEvalLds W;
+    __shared__ int fin_canonical;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const bool wave0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
     const LaneKeccak L = lane_keccak_init();
@@ -292,12 +350,11 @@ ZK_D void pipe_tail_block(const PipeTailArgs &ta, const FieldParams &P) {
         dbg_stamp(ta.dbg, 1);
         Fe s = fe_zero();
         if (ta.mode == 1) {
-            const Mul29 r29 = load_challenge29(ta.chal_in);
-            Fe e[NR];
-            const uint32_t t = lane < (uint32_t)NS ? lane : 0;
-#pragma unroll
-            for (int i = 0; i < NR; ++i) e[i] = red[t * NR + i];
-            s = pipe_eval<K>(e, r29, ta.inv2, P);
+            const Mul29 rh29 = load_challenge29(ta.chal_in), rc29 = load_challenge29c(ta.chal_in);
+            pipe_eval_consts(W, ta.pc, lane);
+            if (lane == 0) pipe_eval_set(W, 0, K == 1 ? rc29 : rh29);
+            __builtin_amdgcn_wave_barrier();
+            s = pipe_eval_canon<K, D>(red, W, rh29, rc29, lane, P);   // CANONICAL
         } else {
             s = red[lane < (uint32_t)NS ? lane : 0];
             if (ta.dv.prev_rp) {
@@ -330,21 +387,31 @@ ZK_D void pipe_tail_block(const PipeTailArgs &ta, const FieldParams &P) {
         }
         if (lane < (uint32_t)NS) {
             fin[lane] = s;
-            fe_store(ta.out_rp, lane, s);
+            if (ta.mode != 1) fe_store(ta.out_rp, lane, s);   // (mode 1: canonical here; wave 1 stores the Montgomery form)
         }
+        if (lane == 0) fin_canonical = ta.mode == 1;
         dbg_stamp(ta.dbg, 2);
-        lane_absorb_elems(sp, L, fin, NS, P);
+        if (ta.mode == 1) lane_absorb_elems<true>(sp, L, fin, NS, P);
+        else lane_absorb_elems(sp, L, fin, NS, P);
         x = lane_squeeze_x(sp, L);
         if (lane == 0) digest_x = x;
         dbg_stamp(ta.dbg, 3);
     }
     __syncthreads();   // waves 0 and 1 (the others have left)
     if (wave0) {
-        publish_challenge29(ta.chal_out, challenge29_of(x, P), L.lane);
+        publish_challenge29_both(ta.chal_out, challenge29_both(x, ta.pc.k266, lane, P), lane);   // lane 0 / lane 16: the two forms
         lane_sponge_store(ta.sponge, sp, L);
         dbg_stamp(ta.dbg, 4);
     } else {
-        publish_challenge_fe(ta.chal_out, ta.out_ch, challenge_fe_of(digest_x, P), (int)lane);
+        // wave 1, one multiplication by R^2 for all of it: lanes t < NS the round polynomial (canonical -> Montgomery, mode 1),
+        // lane 16 the challenge the proof records
+        const bool rp = fin_canonical && lane < (uint32_t)NS;
+        const Fe v = fe_from_canonical29(rp ? fin[lane] : digest_x, P);
+        if (rp) fe_store(ta.out_rp, lane, v);
+        if (lane == 16) {
+            fe_store(ta.chal_out, 0, v);
+            fe_store(ta.out_ch, 0, v);
+        }
     }
 }
 
@@ -461,10 +528,14 @@ struct FinLds {   // carved from the dynamic region (32-byte aligned offsets)
     Fe *red;                         // [16]
     Fe *fin;                         // [4]
     Fe *xr;                          // [2] by round parity: the raw digest of the round's squeeze (for the Montgomery conversion)
-    Mul29 *r29;                      // [2] by round parity
+    Fe (*finc)[4];                   // [2] by round parity: the round polynomial in CANONICAL form (converted for the proof a round later)
+    PipeEvalLds *W;
+    Mul29 *r29;                      // [2] by round parity: prepared Montgomery form of the challenge
+    Mul29 *rc29;                     // [2] by round parity: prepared canonical form
     ZK_D uint32_t *red_u32() const { return reinterpret_cast<uint32_t *>(red); }
 };
-constexpr size_t kFinMiscBytes = kFinStageBytes + sizeof(Fe) * (2 * kFinWorkWaves * 16 + kFinWorkWaves * 16 + 16 * 16 + 16 + 4 + 2) + 2 * sizeof(Mul29) + 64;
+constexpr size_t kFinMiscBytes = kFinStageBytes + sizeof(Fe) * (2 * kFinWorkWaves * 16 + kFinWorkWaves * 16 + 16 * 16 + 16 + 4 + 2 + 8) +
+                                 sizeof(PipeEvalLds) + 16 + 4 * 48 + 64;
 
 // One pass set of the work rows over the pair indices j < q of the NEXT round.  src: tables with 8q (FOLD: folded at r into
 // the 4q-element tables dst first) or 4q elements per factor.
@@ -520,7 +591,7 @@ ZK_D void fin_gather_e(Fe (*ew)[16], uint32_t nactive, Fe *red, Fe (&e)[K + 1], 
 
 template <int K, int D, int EXTRA>
 __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs fp, uint32_t m_in, int entry, const uint64_t *__restrict__ e_partials,
-                                                                    uint32_t e_blocks, FieldParams P, Fe inv2, const uint64_t *__restrict__ chal_in,
+                                                                    uint32_t e_blocks, FieldParams P, PipeConsts pc, const uint64_t *__restrict__ chal_in,
                                                                     uint64_t *__restrict__ chal_last, WordSponge *gsponge, uint64_t *out_rp,
                                                                     uint64_t *out_ch, uint64_t *out_final, uint64_t *dbg) {
     constexpr int NF = K + EXTRA, NS = D + 1, NR = K + 1, NE = NS * NR;
@@ -549,7 +620,13 @@ __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs f
     carve += sizeof(Fe) * 4;
     S.xr = reinterpret_cast<Fe *>(carve);
     carve += sizeof(Fe) * 2;
-    S.r29 = reinterpret_cast<Mul29 *>(carve);
+    S.finc = reinterpret_cast<Fe(*)[4]>(carve);
+    carve += sizeof(Fe) * 8;
+    S.W = reinterpret_cast<PipeEvalLds *>(carve);          // (32-byte aligned so far: the multiplier records are read 16 bytes at a time)
+    carve += (sizeof(PipeEvalLds) + 15) / 16 * 16;
+    S.r29 = reinterpret_cast<Mul29 *>(carve);              // 48-byte slots
+    S.rc29 = reinterpret_cast<Mul29 *>(carve + 2 * 48);
+    if (wave0) pipe_eval_consts(*S.W, pc, lane);
 
     const LaneKeccak L = lane_keccak_init();
     LaneSponge sp = {0, 0};
@@ -589,8 +666,9 @@ __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs f
     uint32_t round = 0;    // rounds closed so far
     int par = 0;           // parity of the ew buffer that holds the E of round `round`
     uint32_t nact = 0;     // work waves that wrote it
-    Mul29 rprev = {};
+    Mul29 rprev = {}, rcprev = {};   // prepared Montgomery / canonical forms of the challenge of the round before
     if (entry != kFinEntryFresh) rprev = load_challenge29(chal_in);
+    if (entry == kFinEntryPipe) rcprev = load_challenge29c(chal_in);
 
     // ---- entry ----
     if (entry == kFinEntryPipe) {
@@ -633,12 +711,13 @@ __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs f
                 S.fin[lane] = s;
                 fe_store(out_rp, lane, s);
             }
-            Mul29 ch29;
-            const Fe ch = transcript_step(sp, L, S.fin, NS, P, ch29);
-            if (lane == 0) {
-                fe_store(out_ch, 0, ch);
-                S.r29[0] = ch29;
-            }
+            lane_absorb_elems(sp, L, S.fin, NS, P);
+            const Fe x = lane_squeeze_x(sp, L);
+            if (lane == 0) S.xr[0] = x;
+            if (!n_work_waves) publish_challenge_fe(nullptr, out_ch, challenge_fe_of(x, P), (int)lane);   // (else: the converter wave, below)
+            const Mul29 both = challenge29_both(x, pc.k266, lane, P);
+            if (lane == 0) S.r29[0] = both;
+            if (lane == 16) S.rc29[0] = both;
         }
         __syncthreads();
         round = 1;
@@ -652,7 +731,10 @@ __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs f
             src_global = true;
         }
 #pragma unroll
-        for (int i = 0; i < 9; ++i) rprev.l[i] = __builtin_amdgcn_readfirstlane(S.r29[0].l[i]);
+        for (int i = 0; i < 9; ++i) {
+            rprev.l[i] = __builtin_amdgcn_readfirstlane(S.r29[0].l[i]);
+            rcprev.l[i] = __builtin_amdgcn_readfirstlane(S.rc29[0].l[i]);
+        }
     }
 
     // ---- uniform loop: close round `round` (its table has m - 1 variables) while the next one is prepared ----
@@ -661,32 +743,44 @@ __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs f
     // the wave that turns digests into Montgomery-form challenges: the LAST work wave (the rows of a small round fill the work
     // waves from the first one up, so it is the one most often idle); with no work wave at all, the transcript wave itself
     const bool converter = n_work_waves ? (worker && my_work_wave == n_work_waves - 1) : wave0;
-    bool conv_pending = false;   // a round of this loop has squeezed a digest that is not converted yet
+    // a round has squeezed a digest (and, in the loop, left a canonical round polynomial) that the converter has not turned into
+    // the proof's Montgomery form yet; conv_rp: the round polynomial too (the entry round stored its own)
+    bool conv_pending = entry != kFinEntryPipe && n_work_waves != 0, conv_rp = false;
+    // converter: one multiplication by R^2 for the challenge (lane 16) and the round polynomial (lanes t < NS) of round `rd`
+    auto convert_round = [&](uint32_t rd, bool with_rp, uint64_t *also_chal) {
+        const bool rp = with_rp && lane < (uint32_t)NS;
+        const Fe v = fe_from_canonical29(rp ? S.finc[rd & 1][lane < (uint32_t)NS ? lane : 0] : S.xr[rd & 1], P);
+        if (rp) fe_store(out_rp, (uint64_t)rd * NS + lane, v);
+        if (lane == 16) {
+            fe_store(out_ch, rd, v);
+            if (also_chal) fe_store(also_chal, 0, v);
+        }
+    };
     while (m >= 2) {
         uint64_t *rdbg = dbg ? dbg + 16 * round : nullptr;
         if (wave0) {
             dbg_stamp(rdbg, 0);
             Fe e[NR];
-            fin_gather_e<K, D>(S.ew[par], nact, S.red, e, lane, P);
+            fin_gather_e<K, D>(S.ew[par], nact, S.red, e, lane, P);   // (leaves the totals in S.red, [4 t + node])
             dbg_stamp(rdbg, 1);
-            const Fe s = pipe_eval<K>(e, rprev, inv2, P);
+            if (lane == 0) pipe_eval_set(*S.W, 0, K == 1 ? rcprev : rprev);
+            __builtin_amdgcn_wave_barrier();
+            const Fe s = pipe_eval_canon<K, D, 4>(S.red, *S.W, rprev, rcprev, lane, P);   // CANONICAL
             dbg_stamp(rdbg, 2);
-            if (lane < (uint32_t)NS) {
-                S.fin[lane] = s;
-                fe_store(out_rp, (uint64_t)round * NS + lane, s);
-            }
-            // the transcript wave keeps only what the next round needs: the multiplier form of the challenge.  The Montgomery form
-            // (the proof's record) is converted from the raw digest by the last work wave, one round later (below)
-            lane_absorb_elems(sp, L, S.fin, NS, P);
+            if (lane < (uint32_t)NS) S.finc[round & 1][lane] = s;
+            // the transcript wave keeps only what the next round needs: the two multiplier forms of the challenge.  The Montgomery
+            // forms the proof records (round polynomial, challenge) are converted by the last work wave, one round later (below)
+            lane_absorb_elems<true>(sp, L, S.finc[round & 1], NS, P);
             const Fe x = lane_squeeze_x(sp, L);
             if (lane == 0) S.xr[round & 1] = x;
-            if (converter) publish_challenge_fe(nullptr, out_ch + 4 * (uint64_t)round, challenge_fe_of(x, P), (int)lane);   // no work wave exists
-            const Mul29 ch29 = challenge29_of(x, P);
-            if (lane == 0) S.r29[round & 1] = ch29;
-            if (m == 2) publish_challenge29(chal_last, ch29, (int)lane);
+            if (converter) convert_round(round, true, nullptr);   // no work wave exists
+            const Mul29 both = challenge29_both(x, pc.k266, lane, P);
+            if (lane == 0) S.r29[round & 1] = both;
+            if (lane == 16) S.rc29[round & 1] = both;
+            if (m == 2) publish_challenge29_both(chal_last, both, lane);
             dbg_stamp(rdbg, 3);
         } else if (worker) {
-            if (converter && conv_pending) publish_challenge_fe(nullptr, out_ch + 4 * (uint64_t)(round - 1), challenge_fe_of(S.xr[(round - 1) & 1], P), (int)lane);
+            if (converter && conv_pending) convert_round(round - 1, conv_rp, nullptr);
             if (m >= 3) {
             if (my_work_wave == 0) dbg_stamp(rdbg, 8);
             const uint32_t q = 1u << (m - 3);
@@ -696,12 +790,16 @@ __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs f
             }
         }
         conv_pending = true;
+        conv_rp = true;
         __syncthreads();
         if (wave0) dbg_stamp(rdbg, 4);
         if (m >= 3) nact = fin_active_waves<K, D, EXTRA, false>(1u << (m - 3), n_work_waves);
         if (m > 2 || out_final) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) rprev.l[i] = __builtin_amdgcn_readfirstlane(S.r29[round & 1].l[i]);
+            for (int i = 0; i < 9; ++i) {
+                rprev.l[i] = __builtin_amdgcn_readfirstlane(S.r29[round & 1].l[i]);
+                rcprev.l[i] = __builtin_amdgcn_readfirstlane(S.rc29[round & 1].l[i]);
+            }
         }
         par ^= 1;
         src_global = false;
@@ -709,10 +807,9 @@ __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs f
         --m;
     }
     if (wave0) lane_sponge_store(gsponge, sp, L);
-    if (converter && conv_pending) {   // the last round's challenge (the barrier that ended the loop has published its digest)
-        const Fe ch = challenge_fe_of(S.xr[(round - 1) & 1], P);
-        publish_challenge_fe(chal_last, out_ch + 4 * (uint64_t)(round - 1), ch, (int)lane);
-    }
+    // the last round's challenge and round polynomial (the barrier that ended the loop has published them)
+    if (converter && conv_pending && n_work_waves) convert_round(round - 1, conv_rp, chal_last);
+    else if (converter && conv_pending && lane == 16) fe_store(chal_last, 0, fe_load(out_ch, round - 1));   // (converted in the loop already)
     // out_final: the factors at the whole challenge point.  LDS holds the 4-element tables of the second-to-last round; they
     // are folded at the last two challenges (rprev = the last one; the one before sits in the other slot)
     if (out_final && tid < (uint32_t)NF) {

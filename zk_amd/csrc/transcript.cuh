@@ -149,11 +149,13 @@ ZK_D void lane_sponge_store(WordSponge *gsp, const LaneSponge &sp, const LaneKec
     if (L.lane == 0) gsp->pos = sp.pos;
 }
 // absorb ns elements (Montgomery form; read by lane, so `sums` may be LDS or global memory) as 32-byte big-endian canonical images
+// CANON: the elements are already canonical integers (the pipelined rounds evaluate their sums straight into that form).
+template <bool CANON = false>
 ZK_D void lane_absorb_elems(LaneSponge &sp, const LaneKeccak &L, const Fe *sums, uint32_t ns, const FieldParams &P) {
     for (uint32_t base = 0; base < ns; base += 64) {
         // lane t converts sum (base + t): Montgomery -> canonical, in parallel across lanes
         const uint32_t mine = base + (uint32_t)L.lane < ns ? base + (uint32_t)L.lane : ns - 1;
-        const Fe c = fe_to_canonical(sums[mine], P);
+        const Fe c = CANON ? sums[mine] : fe_to_canonical(sums[mine], P);
         uint64_t w[4];   // the element's 32-byte big-endian image as 4 little-endian lane words
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -217,6 +219,26 @@ ZK_D Mul29 challenge29_of(const Fe &x, const FieldParams &P) {
     const Fe chs = fe_mul29(x, k1, P);
     split29(chs.v, ch29.l);
     return ch29;
+}
+// Both prepared forms of the challenge in ONE multiplication, lane-parallel: lane 0 multiplies the digest by R^2 * 2^5 (the
+// Montgomery-form challenge times 2^5: split, it is the multiplier folds use), lane 16 by 2^266 (the canonical challenge times
+// 2^5: split, the multiplier that turns a Montgomery-form value into a CANONICAL product).  Valid on lanes 0 / 16 respectively.
+ZK_D Mul29 challenge29_both(const Fe &x, const Mul29 &k266, uint32_t lane, const FieldParams &P) {
+    Mul29 k;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k.l[i] = lane == 16 ? k266.l[i] : P.r2s_29[i];
+    const Fe v = fe_mul29(x, k, P);
+    Mul29 m;
+    split29(v.v, m.l);
+    return m;
+}
+// lane 0 stores the Montgomery prepared form, lane 16 the canonical one (the values challenge29_both left on them)
+ZK_D void publish_challenge29_both(uint64_t *d_challenge, const Mul29 &m, uint32_t lane) {
+    if (lane == 0 || lane == 16) {
+        uint32_t *rec = reinterpret_cast<uint32_t *>(d_challenge) + (lane == 0 ? 8 : kChalCanonWord);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) rec[i] = m.l[i];
+    }
 }
 ZK_D Fe challenge_fe_of(const Fe &x, const FieldParams &P) {
     Mul29 k0;
