@@ -779,3 +779,20 @@ def test_verify_with_per_round_lengths_on_the_device_path():
         assert got == want and got is not True
         with pytest.raises(ZkError, match="require 1 round poly"):
             SumcheckVerifier.verify(pp, SumcheckProof(claimed, rounds[:-1]))
+
+
+def test_round_sums_through_the_lead_kernels_at_their_real_size():
+    """zk_round_sums (prover.rs:49-56 for one round) at 2^18 pairs, where the (2,2) and (3,3) sums-only kernels accumulate the
+    leading coefficient and the tail rebuilds S(D) (k_round_kd LEAD): all D + 1 sums equal to the oracle's
+    fold -> prod_reduce -> sum, and the round-0 identity S(0) + S(1) = sum of the product table."""
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    n = 19
+    for k, D in ((2, 2), (3, 3)):
+        polys = [MLE.random(c, n, 0x1EAD + k, f << n) for f in range(k)]
+        tabs = [q.evaluation_slice() for q in polys]
+        got = ProductPoly.new(polys).round_sums(D)
+        want = oracle_round_sums(field, n, tabs, D)
+        assert np.array_equal(got, want), (k, D)
+        for q in polys:
+            q.free()
