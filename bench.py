@@ -348,7 +348,11 @@ def sharded_leg(args, ctx, field, dist, torch, rank, world, ns, tdev, rehearse, 
         dist.all_reduce(lanes)
     torch.cuda.synchronize()
     coll_us = (time.perf_counter() - t1) / 200 * 1e6
-    ok = verified_all and (equals_unsharded is not False)
+    # one verdict for every rank (rank 0 alone knows whether the sharded proof equals the unsharded one): a rank that left with
+    # a different exit path would strand the others in the closing barrier
+    okt = torch.tensor([int(verified_all and (equals_unsharded is not False))], device=tdev)
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    ok = bool(okt.item())
     if rank == 0 and per_gb:
         key = f"n24_k2_d2_world{world}"
         best = min(per_gb, key=per_gb.get)
