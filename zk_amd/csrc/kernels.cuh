@@ -297,9 +297,11 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
         }
     }
     if (sponge && wave0) {
+        lane_absorb_elems(sp, L, fin, ns, P);
         Mul29 ch29;
-        const Fe ch = transcript_step(sp, L, fin, ns, P, ch29);
-        publish_challenge(d_challenge, out_ch, ch, ch29, L.lane);
+        Fe ch;
+        challenge_forms(lane_squeeze_x(sp, L), (uint32_t)lane, P, ch29, ch);   // lane 0: multiplier form, lane 16: Montgomery form
+        publish_challenge_forms(d_challenge, out_ch, ch, ch29, (uint32_t)lane);
         lane_sponge_store(sponge, sp, L);
     }
 }
@@ -428,13 +430,13 @@ __global__ __launch_bounds__(kBlock) void k_finish(FactorPtrs fp, uint32_t m_in,
         }
         // ---- transcript step on wave 0, challenge to everyone through LDS ----
         if (wave0) {
+            lane_absorb_elems(sp, L, fin, NS, P);
             Mul29 ch29;
-            const Fe ch = transcript_step(sp, L, fin, NS, P, ch29);
-            if (lane == 0) {
-                fe_store(out_ch, round, ch);
-                *sh_r29p = ch29;
-            }
-            if (m == 1) publish_challenge(d_challenge, nullptr, ch, ch29, (int)lane);   // last one: for the sharded tail
+            Fe ch;
+            challenge_forms(lane_squeeze_x(sp, L), lane, P, ch29, ch);   // lane 0: multiplier form, lane 16: Montgomery form
+            if (lane == 16) fe_store(out_ch, round, ch);
+            if (lane == 0) *sh_r29p = ch29;
+            if (m == 1) publish_challenge_forms(d_challenge, nullptr, ch, ch29, lane);   // last one: for the sharded tail
         }
         __syncthreads();
         // ---- fold at the challenge, in LDS (prover.rs:64); the fold after the last round is dropped by the reference
@@ -592,13 +594,13 @@ __global__ __launch_bounds__(kBlock) void k_finish_terms(FactorPtrs fp, TermSpec
         }
         // ---- transcript step on wave 0, challenge to everyone through LDS ----
         if (wave0) {
+            lane_absorb_elems(sp, L, fin, NS, P);
             Mul29 ch29;
-            const Fe ch = transcript_step(sp, L, fin, NS, P, ch29);
-            if (lane == 0) {
-                fe_store(out_ch, round, ch);
-                *sh_r29p = ch29;
-            }
-            if (m == 1) publish_challenge(d_challenge, nullptr, ch, ch29, (int)lane);   // last one: for the sharded tail
+            Fe ch;
+            challenge_forms(lane_squeeze_x(sp, L), lane, P, ch29, ch);   // lane 0: multiplier form, lane 16: Montgomery form
+            if (lane == 16) fe_store(out_ch, round, ch);
+            if (lane == 0) *sh_r29p = ch29;
+            if (m == 1) publish_challenge_forms(d_challenge, nullptr, ch, ch29, lane);   // last one: for the sharded tail
         }
         __syncthreads();
         // ---- fold at the challenge, in LDS (prover.rs:64); the fold after the last round is dropped by the reference
