@@ -652,7 +652,10 @@ __global__ void k_lanes_transcript(const uint64_t *__restrict__ lanes, uint32_t 
                                    uint64_t *__restrict__ d_challenge, FieldParams P) {
     __shared__ Fe fin[256];
     if (blockIdx.x != 0 || threadIdx.x >= 64) return;   // one wave, uniform control flow
-    for (uint32_t t = 0; t < ns; ++t) {
+    // lane t takes sum t (t, t + 64, ...): the carry propagation and the 17-step ladder run once for all sums of a batch instead
+    // of once per sum on every lane (the ladder is ~350 dependent steps: ~1 us of the serial chain of every exchanging round)
+    for (uint32_t t0 = 0; t0 < ns; t0 += 64) {
+        const uint32_t t = t0 + threadIdx.x < ns ? t0 + threadIdx.x : ns - 1;
         uint32_t v[9];
         uint64_t carry = 0;
 #pragma unroll
@@ -666,7 +669,7 @@ __global__ void k_lanes_transcript(const uint64_t *__restrict__ lanes, uint32_t 
         Fe r;
 #pragma unroll
         for (int i = 0; i < 8; ++i) r.v[i] = v[i];
-        if (threadIdx.x == 0) {
+        if (t0 + threadIdx.x < ns) {
             fin[t] = r;
             fe_store(out_rp, t, r);
         }
