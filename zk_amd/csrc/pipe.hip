@@ -36,13 +36,21 @@ uint32_t pipe_work_blocks(int k, uint32_t D, int extra, uint64_t q) {
     return (uint32_t)(g ? g : 1);
 }
 
+// ZK_PIPE_SC1_HANDOFF=1: the fence-free partial hand-off of k_round_pipe (experimental, off by default)
+static int sc1_handoff() {
+    static const int v = [] {
+        const char *e = getenv("ZK_PIPE_SC1_HANDOFF");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
 template <int K, int D, int EXTRA>
 static void launch_shape(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t g) {
     constexpr int kThreads = pipe_block_threads<K, D, EXTRA>();
     if (pl.fold)
-        k_round_pipe<K, D, EXTRA, true><<<g + 1, kThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail);
+        k_round_pipe<K, D, EXTRA, true><<<g + 1, kThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail, sc1_handoff());
     else
-        k_round_pipe<K, D, EXTRA, false><<<g + 1, kThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail);
+        k_round_pipe<K, D, EXTRA, false><<<g + 1, kThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail, sc1_handoff());
 }
 
 int launch_round_pipe(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t *out_work_blocks) {

@@ -288,6 +288,25 @@ ZK_D Fe fe_from_canonical29(const Fe &c, const FieldParams &P) {
     return fe_mul29(c, k0, P);
 }
 
+// Write-through / L1-bypassing element accesses (global_store / global_load ... sc1 = relaxed agent-scope atomics, 8 bytes each):
+// the EXPERIMENTAL fence-free hand-off of the block partials (ZK_PIPE_SC1_HANDOFF=1; see k_round_pipe)
+ZK_D void fe_store_sc1(uint64_t *base, uint64_t idx, const Fe &r) {
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(base + 4 * idx);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        __hip_atomic_store(q + i, (unsigned long long)r.v[2 * i] | ((unsigned long long)r.v[2 * i + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+ZK_D Fe fe_load_sc1(const uint64_t *base, uint64_t idx) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(base + 4 * idx);
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned long long w = __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.v[2 * i] = (uint32_t)w;
+        r.v[2 * i + 1] = (uint32_t)(w >> 32);
+    }
+    return r;
+}
 ZK_D void dbg_stamp(uint64_t *dbg, int slot) {
     if (dbg && (threadIdx.x & 63) == 0) dbg[slot] = wall_clock64();
 }
@@ -295,6 +314,7 @@ ZK_D void dbg_stamp(uint64_t *dbg, int slot) {
 // ---- the transcript block ----------------------------------------------------------------------------------------------
 // Reduce the block partials: value idx (< n_in <= 16) summed over the blocks -> red[idx].  256 threads: thread (idx =
 // tid % 16, slice = tid / 16) adds its share, lanes 16/32 apart combine on the VALU, the four waves through LDS.
+template <bool SC1 = false>
 ZK_D void pipe_reduce_partials(const uint64_t *__restrict__ partials, uint32_t nblocks, uint32_t n_in, Fe *red /* LDS, 16 */, Fe (*stage)[16] /* LDS [4][16] */,
                                const FieldParams &P) {
     const uint32_t tid = threadIdx.x, idx = tid & 15, slice = tid >> 4, lane = tid & 63, wave = tid >> 6;
@@ -304,7 +324,9 @@ ZK_D void pipe_reduce_partials(const uint64_t *__restrict__ partials, uint32_t n
         for (uint32_t b = slice; b < nblocks; b += 16 * kStep) {   // sixteen independent loads in flight (the partials of other
             Fe x[16];                                               // XCDs come from the memory side: ~1 us per dependent batch)
 #pragma unroll
-            for (int u = 0; u < 16; ++u) x[u] = b + u * kStep < nblocks ? fe_load(partials, (uint64_t)(b + u * kStep) * n_in + idx) : fe_zero();
+            for (int u = 0; u < 16; ++u)
+                x[u] = b + u * kStep < nblocks ? (SC1 ? fe_load_sc1(partials, (uint64_t)(b + u * kStep) * n_in + idx) : fe_load(partials, (uint64_t)(b + u * kStep) * n_in + idx))
+                                               : fe_zero();
 #pragma unroll
             for (int w = 8; w >= 1; w >>= 1)
 #pragma unroll
@@ -431,7 +453,7 @@ template <int K, int D, int EXTRA, bool FOLD>
 __global__ __launch_bounds__((pipe_block_threads<K, D, EXTRA>())) void k_round_pipe(FactorPtrs fp, uint64_t q, int emit, FieldParams P,
                                                                                   const uint64_t *__restrict__ chal_fold,
                                                                                   uint64_t *__restrict__ e_partials, uint32_t *done_counter,
-                                                                                  PipeTailArgs ta) {
+                                                                                  PipeTailArgs ta, int sc1_handoff) {
     using S = PipeShape<K, D, EXTRA>;
     using C = HexCfg<K, D, EXTRA, false>;
     constexpr int kThreads = pipe_block_threads<K, D, EXTRA>(), kPipeRows = kThreads / 16, kWaves = kThreads / 64;
@@ -478,24 +500,36 @@ __global__ __launch_bounds__((pipe_block_threads<K, D, EXTRA>())) void k_round_p
             Fe tot = redw[0][threadIdx.x];
 #pragma unroll
             for (int w = 1; w < kWaves; ++w) tot = fe_add(tot, redw[w][threadIdx.x], P);
-            fe_store(e_partials, (uint64_t)(wb + 1) * S::NE + t * S::NR + node, tot);   // slot 0 is the total
+            if (sc1_handoff) fe_store_sc1(e_partials, (uint64_t)(wb + 1) * S::NE + t * S::NR + node, tot);
+            else fe_store(e_partials, (uint64_t)(wb + 1) * S::NE + t * S::NR + node, tot);   // slot 0 is the total
         }
     }
     if (threadIdx.x < 64) dbg_stamp(wdbg, 3);
     // The block that finishes last adds the partials up (slot 0), so the NEXT launch's transcript block -- the critical path --
     // reads NE values instead of reducing nwork * NE.  Release / acquire at agent scope: the other blocks may sit on other XCDs.
+    // EXPERIMENTAL (ZK_PIPE_SC1_HANDOFF=1, off by default): the same hand-off without the two fences -- write-through (sc1)
+    // partial stores, the storing wave's s_waitcnt vmcnt(0), ONE lane's agent-scope counter add, and sc1 loads in the block whose
+    // add came last (MI355X_MICROARCH.md "Valid forms": measured valid on gfx950 / ROCm 7.2, not an architectural guarantee).
     __shared__ uint32_t is_last;
     __shared__ Fe lred[16];
     __shared__ Fe lstage[4][16];
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    if (sc1_handoff) {
+        if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the storing lanes (tid < 16) are all in wave 0
+        if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwork - 1 ? 1u : 0u;
+        __syncthreads();
+        if (!is_last) return;
+        pipe_reduce_partials<true>(e_partials + S::NE * 4, nwork, S::NE, lred, lstage, P);
+    } else {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            is_last = atomicAdd(done_counter, 1u) == nwork - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!is_last) return;
         __threadfence();
-        is_last = atomicAdd(done_counter, 1u) == nwork - 1 ? 1u : 0u;
+        pipe_reduce_partials(e_partials + S::NE * 4, nwork, S::NE, lred, lstage, P);
     }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    pipe_reduce_partials(e_partials + S::NE * 4, nwork, S::NE, lred, lstage, P);
     if (threadIdx.x < 16) {
         const uint32_t t = threadIdx.x / S::NR, node = threadIdx.x % S::NR;
         if (threadIdx.x < (uint32_t)S::NE) fe_store(e_partials, t * S::NR + node, lred[threadIdx.x]);
