@@ -188,49 +188,71 @@ __global__ __launch_bounds__(kBlock) void k_gkr_phase2_heavy(const uint32_t *__r
     }
 }
 
-// phase 1 bookkeeping: one thread per x (row of the by-left CSR).  A CSR entry is {z, other | op << 31}: the gate's
-// output index and its OTHER input (right for the by-left index), so a row needs no second indirection through the gate
-// arrays -- the only random accesses left are the two 32-byte elements E[z] and W[y].
-__global__ __launch_bounds__(kBlock) void k_gkr_phase1(const uint32_t *__restrict__ lptr, const uint2 *__restrict__ lent,
-                                                       const uint64_t *__restrict__ E, const uint64_t *__restrict__ W,
-                                                       uint64_t n_in, uint64_t *__restrict__ H, uint64_t *__restrict__ B1,
-                                                       FieldParams P) {
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < n_in; x += stride) {
-        if (lptr[x + 1] - lptr[x] > kGkrHeavyRow) continue;   // a whole workgroup takes that row (k_gkr_phase1_heavy)
-        Fe h = fe_zero(), b = fe_zero();
-        for (uint32_t e = lptr[x]; e < lptr[x + 1]; ++e) {
-            const uint2 ent = lent[e];
-            const Fe ez = fe_load(E, ent.x), t = fe_mul(ez, fe_load(W, ent.y & 0x7FFFFFFFu), P);
-            if (ent.y >> 31) {
-                h = fe_add(h, t, P);
-            } else {
-                h = fe_add(h, ez, P);
-                b = fe_add(b, t, P);
+// Bookkeeping tables of the two sumchecks of a layer (Libra's phase 1 / phase 2) from the CSR of the wiring by left / right
+// input.  An entry is {z, other | op << 31}: the gate's output index and its OTHER input, so a row needs no second indirection
+// through the gate arrays -- the only random accesses are the two 32-byte elements E[z] and T[other].
+//   PHASE 1 (rows x, T = W):    H[x]  = sum_mul E[z] W[y] + sum_add E[z],   B1[x] = sum_add E[z] W[y]
+//   PHASE 2 (rows y, T = eq_u): a = sum_add E[z] eq_u[x], m = sum_mul E[z] eq_u[x]:  H2[y] = a + W(u) m,  C2[y] = W(u) a
+// ENTRY-parallel: a workgroup owns kGkrRows consecutive rows and walks THEIR entries one per thread (coalesced entry reads, one
+// pair of gathers and one multiplication per lane, all lanes busy), parks the two addends of every entry in LDS, and the row's
+// thread adds up its own (LDS reads and modular additions only).  The row-parallel form ran as many gather rounds per wave as
+// its longest row (4-5 with random wiring, where the row lengths are Poisson(1)); this one runs one.  kGkrRows = 224: the
+// entries of 224 rows of a random wiring (224 +- 15) fit one 256-entry chunk 98 % of the time.  Rows longer than kGkrHeavyRow
+// are empty in the CSR this kernel is given (k_gkr_phase*_heavy, launched after it, owns their outputs).
+constexpr uint32_t kGkrRows = 224;
+static inline uint32_t gkr_phase_grid(uint64_t n_rows) { return (uint32_t)((n_rows + kGkrRows - 1) / kGkrRows); }
+template <int PHASE>
+__global__ __launch_bounds__(kBlock) void k_gkr_phase(const uint32_t *__restrict__ ptr, const uint2 *__restrict__ ent,
+                                                      const uint64_t *__restrict__ E, const uint64_t *__restrict__ T,
+                                                      const uint64_t *__restrict__ wu, uint64_t n_rows, uint64_t *__restrict__ out0,
+                                                      uint64_t *__restrict__ out1, FieldParams P) {
+    __shared__ uint32_t park[2][8][kBlock];   // [addend][word][entry of the chunk]
+    const uint64_t x0 = (uint64_t)blockIdx.x * kGkrRows;
+    const uint64_t x_end = x0 + kGkrRows < n_rows ? x0 + kGkrRows : n_rows;
+    const uint64_t x = x0 + threadIdx.x;
+    const bool row = threadIdx.x < kGkrRows && x < n_rows;
+    const uint32_t rs = row ? ptr[x] : 0, re = row ? ptr[x + 1] : 0;
+    const uint32_t e_lo = ptr[x0], e_hi = ptr[x_end];
+    Fe acc0 = fe_zero(), acc1 = fe_zero();
+    for (uint32_t c0 = e_lo; c0 < e_hi; c0 += kBlock) {   // block-uniform trip count
+        const uint32_t e = c0 + threadIdx.x;
+        if (e < e_hi) {
+            const uint2 en = ent[e];
+            const Fe ez = fe_load(E, en.x), t = fe_mul(ez, fe_load(T, en.y & 0x7FFFFFFFu), P);
+            const uint32_t mul = 0u - (en.y >> 31);   // all ones for a mul gate
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (PHASE == 1) {   // {h, b} += mul ? {t, 0} : {ez, t}
+                    park[0][i][threadIdx.x] = (t.v[i] & mul) | (ez.v[i] & ~mul);
+                    park[1][i][threadIdx.x] = t.v[i] & ~mul;
+                } else {            // {a, m} += mul ? {0, t} : {t, 0}
+                    park[0][i][threadIdx.x] = t.v[i] & ~mul;
+                    park[1][i][threadIdx.x] = t.v[i] & mul;
+                }
             }
         }
-        fe_store(H, x, h);
-        fe_store(B1, x, b);
-    }
-}
-// phase 2 bookkeeping: one thread per y (row of the by-right CSR, entries {z, left | op << 31}); wu = W(u), one device element
-__global__ __launch_bounds__(kBlock) void k_gkr_phase2(const uint32_t *__restrict__ rptr, const uint2 *__restrict__ rent,
-                                                       const uint64_t *__restrict__ E, const uint64_t *__restrict__ eq_u,
-                                                       const uint64_t *__restrict__ wu, uint64_t n_in,
-                                                       uint64_t *__restrict__ H2, uint64_t *__restrict__ C2, FieldParams P) {
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    const Fe w = fe_load(wu, 0);
-    for (uint64_t y = (uint64_t)blockIdx.x * kBlock + threadIdx.x; y < n_in; y += stride) {
-        if (rptr[y + 1] - rptr[y] > kGkrHeavyRow) continue;   // k_gkr_phase2_heavy
-        Fe a = fe_zero(), m = fe_zero();
-        for (uint32_t e = rptr[y]; e < rptr[y + 1]; ++e) {
-            const uint2 ent = rent[e];
-            const Fe t = fe_mul(fe_load(E, ent.x), fe_load(eq_u, ent.y & 0x7FFFFFFFu), P);
-            if (ent.y >> 31) m = fe_add(m, t, P);
-            else a = fe_add(a, t, P);
+        __syncthreads();
+        const uint32_t lo = rs > c0 ? rs : c0, hi = re < c0 + kBlock ? re : c0 + kBlock;
+        for (uint32_t q = lo; q < hi; ++q) {
+            Fe v0, v1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v0.v[i] = park[0][i][q - c0];
+                v1.v[i] = park[1][i][q - c0];
+            }
+            acc0 = fe_add(acc0, v0, P);
+            acc1 = fe_add(acc1, v1, P);
         }
-        fe_store(H2, y, fe_add(a, fe_mul(w, m, P), P));
-        fe_store(C2, y, fe_mul(w, a, P));
+        __syncthreads();
+    }
+    if (!row) return;
+    if (PHASE == 1) {
+        fe_store(out0, x, acc0);
+        fe_store(out1, x, acc1);
+    } else {
+        const Fe w = fe_load(wu, 0);
+        fe_store(out0, x, fe_add(acc0, fe_mul(w, acc1, P), P));
+        fe_store(out1, x, fe_mul(w, acc0, P));
     }
 }
 
