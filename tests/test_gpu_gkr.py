@@ -109,7 +109,7 @@ def test_prove_terms_argument_errors():
 
 
 @pytest.mark.parametrize("field", FIELDS)
-@pytest.mark.parametrize("logs", [[0, 1], [2, 3, 2], [3, 2, 4, 3], [1, 1, 1, 1, 1], [6, 7, 5], [0, 10, 11]])
+@pytest.mark.parametrize("logs", [[0, 1], [2, 3, 2], [3, 2, 4, 3], [1, 1, 1, 1, 1], [6, 7, 5], [0, 10, 11], [4, 13, 12]])
 def test_gkr_vs_model(field, logs):
     c = ctx_for(field)
     p = zk_amd.modulus(field)
