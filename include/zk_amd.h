@@ -275,7 +275,9 @@ int32_t zk_gkr_evaluate(const zk_circuit *c, const zk_mle *input, zk_mle **out_o
  * elements, per layer [round polys #1 (log_in*3) | round polys #2 (log_in*3) | W(u) | W(v)].  Returns the outputs table. */
 int32_t zk_gkr_prove(const zk_circuit *c, const zk_mle *input, const uint8_t seed[32], zk_mle **out_outputs,
                      uint64_t *out_proof);
-/* ZK_OK = accept; ZK_ERR_VERIFY_SUM = a sumcheck round check failed; ZK_ERR_GKR_REJECT = wiring / input check failed */
+/* ZK_OK = accept; ZK_ERR_VERIFY_SUM = a sumcheck round check failed; ZK_ERR_GKR_REJECT = wiring / input check failed.
+ * The round checks of all layers are made first (host, while the device sums the wiring predicates), the wiring checks after
+ * them: a proof with defects of both kinds reports the round check. */
 int32_t zk_gkr_verify(const zk_circuit *c, const zk_mle *input, const zk_mle *outputs, const uint8_t seed[32],
                       const uint64_t *proof);
 
