@@ -22,7 +22,7 @@ while time.time() < t_end:
     f = rng.randrange(3)
     c = ctxs[f]
     p = zk_amd.modulus(f)
-    kind = rng.choice(["prove", "prove", "terms", "evaluate", "fold", "gkr"])
+    kind = rng.choice(["prove", "prove", "terms", "evaluate", "fold", "gkr", "gkr_wide"])
     if kind == "prove":
         k = rng.choice([1, 2, 2, 3, 3, 4, 5, 8])
         D = rng.choice([max(1, k), k, k + 1, rng.randrange(1, 7)])
@@ -66,6 +66,37 @@ while time.time() < t_end:
         bad = proof.copy()
         bad[rng.randrange(len(want_proof))] = zk_amd.fe_from_int(f, rng.randrange(p))
         assert not gkr.gkr_verify(circ, x, out, seed, bad) or zk_amd.fe_to_ints(f, bad) == want_proof, ("gkr tamper", f, logs)
+    elif kind == "gkr_wide":
+        # widths around the bookkeeping kernels' tiling (224 rows per workgroup, 256 entries per chunk, rows of more than 256
+        # entries on their own kernel and emptied in the light CSR): uniform, skewed (rows of tens of entries: several chunks)
+        # and heavy (a few rows take most of the gates) wirings, against the big-int model
+        depth = rng.randrange(1, 3)
+        logs = [rng.randrange(6, 12)] + [rng.randrange(5, 11) for _ in range(depth)]
+        layers = []
+        for i in range(depth):
+            ng, nin = 1 << logs[i], 1 << logs[i + 1]
+            mode = rng.choice(["uniform", "skew", "heavy", "heavy_both"])
+            def pick(side):
+                if mode == "skew":
+                    return rng.randrange(max(nin // 32, 1)) if rng.random() < 0.7 else rng.randrange(nin)
+                if mode == "heavy" and side == 0 or mode == "heavy_both":
+                    return rng.choice([3 % nin, nin - 1]) if rng.random() < 0.6 else rng.randrange(nin)
+                return rng.randrange(nin)
+            layers.append((logs[i], logs[i + 1], [rng.randrange(2) for _ in range(ng)], [pick(0) for _ in range(ng)], [pick(1) for _ in range(ng)]))
+        inputs = [rng.randrange(p) for _ in range(1 << logs[-1])]
+        seed = bytes(rng.randrange(256) for _ in range(32))
+        want_out, want_proof = gkr_ref.gkr_prove(f, layers, inputs, seed)
+        circ = gkr.Circuit(c)
+        for lo, li, op, left, right in layers:
+            circ.add_layer(lo, li, op, left, right)
+        x = MLE.new(c, logs[-1], zk_amd.fe_from_ints(f, inputs))
+        out, proof = gkr.gkr_prove(circ, x, seed)
+        assert zk_amd.fe_to_ints(f, proof) == want_proof and zk_amd.fe_to_ints(f, out.evaluation_slice()) == want_out, ("gkr_wide", f, logs)
+        assert gkr.gkr_verify(circ, x, out, seed, proof), ("gkr_wide verify", f, logs)
+        bad = proof.copy()
+        bad[rng.randrange(len(want_proof))] = zk_amd.fe_from_int(f, rng.randrange(p))
+        assert not gkr.gkr_verify(circ, x, out, seed, bad) or zk_amd.fe_to_ints(f, bad) == want_proof, ("gkr_wide tamper", f, logs)
+        circ.free()
     elif kind == "evaluate":
         n = rng.randrange(0, 19)
         t = orc.fill_random(f, rng.randrange(1 << 30), 1 << n)
