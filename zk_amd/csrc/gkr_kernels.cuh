@@ -48,18 +48,6 @@ __global__ __launch_bounds__(kBlock) void k_eq_outer(const uint64_t *__restrict_
     }
 }
 
-// out[idx] = hi1[..] * lo1[..] + hi2[..] * lo2[..]: E = alpha*eq(g1,.) + beta*eq(g2,.) in ONE pass over the table (the scales are
-// folded into the hi halves) instead of a write pass plus a read-modify-write pass
-__global__ __launch_bounds__(kBlock) void k_eq_outer2(const uint64_t *__restrict__ hi1, const uint64_t *__restrict__ lo1,
-                                                      const uint64_t *__restrict__ hi2, const uint64_t *__restrict__ lo2, uint32_t lo_bits,
-                                                      uint64_t n, uint64_t *__restrict__ out, FieldParams P) {
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock, mask = (1ull << lo_bits) - 1;
-    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
-        const Fe a = fe_mul(fe_load(hi1, j >> lo_bits), fe_load(lo1, j & mask), P), b = fe_mul(fe_load(hi2, j >> lo_bits), fe_load(lo2, j & mask), P);
-        fe_store(out, j, fe_add(a, b, P));
-    }
-}
-
 // The two half tables of eq(point, .) for m <= 30 in one launch: workgroup 0 builds hi (the first m/2 variables, scale
 // folded in), workgroup 1 builds lo.  A half of nv <= 15 variables is itself the outer product of two quarter tables that
 // are built by direct products in LDS (<= 8 dependent multiplies), so the whole chain is <= 9 multiplies deep; the point
@@ -102,6 +90,22 @@ __global__ __launch_bounds__(kBlock) void k_eq_halves(const uint64_t *__restrict
     __syncthreads();
     uint64_t *dst = is_hi ? d_hi : d_lo;
     for (uint32_t i = threadIdx.x; i < (1u << nv); i += kBlock) fe_store(dst, i, fe_mul(fe_load(qa, i >> b), fe_load(qb, i & (nb - 1)), P));
+}
+
+// An eq table that is never written out: v[i] = hi[i >> lo_bits] * lo[i & mask] (+ hi2[..] * lo2[..] for alpha*eq(g1,.) +
+// beta*eq(g2,.); the scales sit in the hi halves), read where it is needed from the two halves k_eq_halves leaves -- 2^(m/2)
+// entries each, a few dozen KB that stay in L2 -- at the price of one (two) multiplications.  The GKR kernels gather
+// E[z], eq_u[x], eq_v[y] at random indices: out of a 32-MiB table that is a 32-byte read from the memory side per gate (what
+// bounded those kernels); out of the halves it is two cache hits.  Exact field arithmetic: the same values as the table's.
+struct EqFactor {
+    const uint64_t *hi, *lo, *hi2, *lo2;   // hi2 == nullptr: one point
+    uint32_t lo_bits;
+};
+ZK_D Fe eq_factor_at(const EqFactor &f, uint32_t i, const FieldParams &P) {
+    const uint32_t h = i >> f.lo_bits, l = i & ((1u << f.lo_bits) - 1);
+    Fe v = fe_mul(fe_load(f.hi, h), fe_load(f.lo, l), P);
+    if (f.hi2) v = fe_add(v, fe_mul(fe_load(f.hi2, h), fe_load(f.lo2, l), P), P);   // kernel-uniform branch
+    return v;
 }
 
 // layer evaluation: out[z] = W[left[z]] (+|*) W[right[z]]
@@ -147,14 +151,14 @@ ZK_D void gkr_block_sum2(Fe (&sum)[2], const FieldParams &P) {
 }
 // heavy rows of phase 1 / phase 2: workgroup b takes row heavy[b]
 __global__ __launch_bounds__(kBlock) void k_gkr_phase1_heavy(const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ lptr,
-                                                             const uint2 *__restrict__ lent, const uint64_t *__restrict__ E,
+                                                             const uint2 *__restrict__ lent, EqFactor E,
                                                              const uint64_t *__restrict__ W, uint64_t *__restrict__ H,
                                                              uint64_t *__restrict__ B1, FieldParams P) {
     const uint32_t x = heavy[blockIdx.x];
     Fe s[2] = {fe_zero(), fe_zero()};   // h, b
     for (uint32_t e = lptr[x] + threadIdx.x; e < lptr[x + 1]; e += kBlock) {
         const uint2 ent = lent[e];
-        const Fe ez = fe_load(E, ent.x), t = fe_mul(ez, fe_load(W, ent.y & 0x7FFFFFFFu), P);
+        const Fe ez = eq_factor_at(E, ent.x, P), t = fe_mul(ez, fe_load(W, ent.y & 0x7FFFFFFFu), P);
         if (ent.y >> 31) {
             s[0] = fe_add(s[0], t, P);
         } else {
@@ -169,14 +173,14 @@ __global__ __launch_bounds__(kBlock) void k_gkr_phase1_heavy(const uint32_t *__r
     }
 }
 __global__ __launch_bounds__(kBlock) void k_gkr_phase2_heavy(const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ rptr,
-                                                             const uint2 *__restrict__ rent, const uint64_t *__restrict__ E,
-                                                             const uint64_t *__restrict__ eq_u, const uint64_t *__restrict__ wu,
+                                                             const uint2 *__restrict__ rent, EqFactor E,
+                                                             EqFactor eq_u, const uint64_t *__restrict__ wu,
                                                              uint64_t *__restrict__ H2, uint64_t *__restrict__ C2, FieldParams P) {
     const uint32_t y = heavy[blockIdx.x];
     Fe s[2] = {fe_zero(), fe_zero()};   // a, m
     for (uint32_t e = rptr[y] + threadIdx.x; e < rptr[y + 1]; e += kBlock) {
         const uint2 ent = rent[e];
-        const Fe t = fe_mul(fe_load(E, ent.x), fe_load(eq_u, ent.y & 0x7FFFFFFFu), P);
+        const Fe t = fe_mul(eq_factor_at(E, ent.x, P), eq_factor_at(eq_u, ent.y & 0x7FFFFFFFu, P), P);
         if (ent.y >> 31) s[1] = fe_add(s[1], t, P);
         else s[0] = fe_add(s[0], t, P);
     }
@@ -202,8 +206,8 @@ __global__ __launch_bounds__(kBlock) void k_gkr_phase2_heavy(const uint32_t *__r
 constexpr uint32_t kGkrRows = 224;
 static inline uint32_t gkr_phase_grid(uint64_t n_rows) { return (uint32_t)((n_rows + kGkrRows - 1) / kGkrRows); }
 template <int PHASE>
-__global__ __launch_bounds__(kBlock) void k_gkr_phase(const uint32_t *__restrict__ ptr, const uint2 *__restrict__ ent,
-                                                      const uint64_t *__restrict__ E, const uint64_t *__restrict__ T,
+__global__ __launch_bounds__(kBlock) void k_gkr_phase(const uint32_t *__restrict__ ptr, const uint2 *__restrict__ ent, EqFactor E,
+                                                      const uint64_t *__restrict__ W /* PHASE 1 */, EqFactor eq_u /* PHASE 2 */,
                                                       const uint64_t *__restrict__ wu, uint64_t n_rows, uint64_t *__restrict__ out0,
                                                       uint64_t *__restrict__ out1, FieldParams P) {
     __shared__ uint32_t park[2][8][kBlock];   // [addend][word][entry of the chunk]
@@ -218,7 +222,8 @@ __global__ __launch_bounds__(kBlock) void k_gkr_phase(const uint32_t *__restrict
         const uint32_t e = c0 + threadIdx.x;
         if (e < e_hi) {
             const uint2 en = ent[e];
-            const Fe ez = fe_load(E, en.x), t = fe_mul(ez, fe_load(T, en.y & 0x7FFFFFFFu), P);
+            const Fe ez = eq_factor_at(E, en.x, P);
+            const Fe t = fe_mul(ez, PHASE == 1 ? fe_load(W, en.y & 0x7FFFFFFFu) : eq_factor_at(eq_u, en.y & 0x7FFFFFFFu, P), P);
             const uint32_t mul = 0u - (en.y >> 31);   // all ones for a mul gate
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -260,14 +265,13 @@ __global__ __launch_bounds__(kBlock) void k_gkr_phase(const uint32_t *__restrict
 //   add~E(u,v) = sum_{add (z,x,y)} E[z]*eq_u[x]*eq_v[y],  mul~E(u,v) = the same over mul gates
 // -> per-block partials [block][2] (reduced by k_round_tail with ns = 2)
 __global__ __launch_bounds__(kBlock) void k_gkr_wiring_eval(const uint8_t *__restrict__ op, const uint32_t *__restrict__ left,
-                                                            const uint32_t *__restrict__ right, const uint64_t *__restrict__ E,
-                                                            const uint64_t *__restrict__ eq_u, const uint64_t *__restrict__ eq_v,
+                                                            const uint32_t *__restrict__ right, EqFactor E, EqFactor eq_u, EqFactor eq_v,
                                                             uint64_t n_gates, uint64_t *__restrict__ partials, FieldParams P) {
     __shared__ uint32_t red[kBlock / 64][2][8];
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     Fe sum[2] = {fe_zero(), fe_zero()};
     for (uint64_t z = (uint64_t)blockIdx.x * kBlock + threadIdx.x; z < n_gates; z += stride) {
-        const Fe t = fe_mul(fe_mul(fe_load(E, z), fe_load(eq_u, left[z]), P), fe_load(eq_v, right[z]), P);
+        const Fe t = fe_mul(fe_mul(eq_factor_at(E, (uint32_t)z, P), eq_factor_at(eq_u, left[z], P), P), eq_factor_at(eq_v, right[z], P), P);
         if (op[z]) sum[1] = fe_add(sum[1], t, P);
         else sum[0] = fe_add(sum[0], t, P);
     }
