@@ -639,9 +639,14 @@ def main():
                     out_t, proof = gkr.gkr_prove(circ, xin, seed)
                     ts.append(time.perf_counter() - t1)
                 extra["gkr_depth8_width2p20_addmul_prove_ms"] = sorted(ts)[2] * 1e3
-                t1 = time.perf_counter()
-                ok = gkr.gkr_verify(circ, xin, out_t, seed, proof)
-                extra["gkr_depth8_width2p20_addmul_verify_ms"] = (time.perf_counter() - t1) * 1e3
+                ok = gkr.gkr_verify(circ, xin, out_t, seed, proof)   # warm (the first call sizes the pinned staging block)
+                ts = []
+                for _ in range(5):
+                    ctx.synchronize()
+                    t1 = time.perf_counter()
+                    ok = gkr.gkr_verify(circ, xin, out_t, seed, proof) and ok
+                    ts.append(time.perf_counter() - t1)
+                extra["gkr_depth8_width2p20_addmul_verify_ms"] = sorted(ts)[2] * 1e3
                 extra["gkr_depth8_width2p20_addmul_verified"] = bool(ok)
                 extra["gkr_proof_bytes"] = int(proof.size * 8)
                 out_t.free(); circ.free()
