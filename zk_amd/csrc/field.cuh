@@ -471,16 +471,24 @@ ZK_HD Mul29 mul29_prepare(const Fe &c, const FieldParams &P) {
 }
 // LAZY = true leaves out the final conditional subtraction: the result is in [0, 2p) for ANY 256-bit a (a*c*2^-261 + p < 2p
 // since c < p < 2^255 makes the first term < 2^250) -- the NTT keeps its values in [0, 2p) inside a transform and reduces once.
-template <bool LAZY = false>
-ZK_HD Fe fe_mul29_t(const Fe &a, const Mul29 &c, const FieldParams &P) {
+// TWO = true adds a second product before the ONE reduction: a*c + a2*c2 (a dot product of length two for the price of one and
+// a half multiplications).  The columns stay carry-free: at most 18 products of two 29-bit limbs plus 9 of the reduction,
+// 27 * 2^58 < 2^63; the value bound doubles to 2^251 + p, still below 2p.
+template <bool LAZY = false, bool TWO = false>
+ZK_HD Fe fe_mul29_t(const Fe &a, const Mul29 &c, const FieldParams &P, const Fe *a2 = nullptr, const Mul29 *c2 = nullptr) {
     constexpr uint32_t M = (1u << 29) - 1;
-    uint32_t x[9], m[9], r[9];
+    uint32_t x[9], y[9], m[9], r[9];
     split29(a.v, x);
+    if constexpr (TWO) split29(a2->v, y);
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
 #pragma unroll
         for (int i = 0; i <= k; ++i) acc += (uint64_t)x[i] * c.l[k - i];
+        if constexpr (TWO) {
+#pragma unroll
+            for (int i = 0; i <= k; ++i) acc += (uint64_t)y[i] * c2->l[k - i];
+        }
 #pragma unroll
         for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P.p29[k - i];
         m[k] = ((uint32_t)acc * P.inv29) & M;
@@ -491,6 +499,10 @@ ZK_HD Fe fe_mul29_t(const Fe &a, const Mul29 &c, const FieldParams &P) {
     for (int k = 9; k < 17; ++k) {
 #pragma unroll
         for (int i = k - 8; i < 9; ++i) acc += (uint64_t)x[i] * c.l[k - i];
+        if constexpr (TWO) {
+#pragma unroll
+            for (int i = k - 8; i < 9; ++i) acc += (uint64_t)y[i] * c2->l[k - i];
+        }
 #pragma unroll
         for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * P.p29[k - i];
         r[k - 9] = (uint32_t)acc & M;
@@ -513,6 +525,10 @@ ZK_HD Fe fe_mul29_t(const Fe &a, const Mul29 &c, const FieldParams &P) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) o.v[i] = borrow ? s.v[i] : d.v[i];
     return o;
+}
+// a*c + a2*c2 (both right operands prepared), one reduction
+ZK_HD Fe fe_dot2_29(const Fe &a, const Mul29 &c, const Fe &a2, const Mul29 &c2, const FieldParams &P) {
+    return fe_mul29_t<false, true>(a, c, P, &a2, &c2);
 }
 ZK_HD Fe fe_mul29(const Fe &a, const Mul29 &c, const FieldParams &P) { return fe_mul29_t<false>(a, c, P); }
 

@@ -53,6 +53,21 @@ __global__ __launch_bounds__(kBlock) void k_eq_outer(const uint64_t *__restrict_
 // are built by direct products in LDS (<= 8 dependent multiplies), so the whole chain is <= 9 multiplies deep; the point
 // is read from DEVICE memory once.  k_eq_outer then needs ONE multiply per element of the full table.
 // With a second point (point2 != null, grid = 4) workgroups 2, 3 build its halves into d_hi2 / d_lo2 with *d_scale2.
+
+// ---- eq tables that are never written out (the GKR kernels' operands) ----------------------------------------------------------
+constexpr uint32_t kEqLoWords = 12;   // a prepared multiplier: nine 29-bit limbs, padded to three 16-byte loads
+ZK_D void store_eq_lo(uint32_t *q, const Mul29 &m) {
+    uint4 *o = reinterpret_cast<uint4 *>(q);
+    o[0] = make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]);
+    o[1] = make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]);
+    o[2] = make_uint4(m.l[8], 0, 0, 0);
+}
+ZK_D Mul29 load_eq_lo(const uint32_t *q) {
+    const uint4 *o = reinterpret_cast<const uint4 *>(q);
+    const uint4 a = o[0], b = o[1], c = o[2];
+    Mul29 m = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x}};
+    return m;
+}
 __global__ __launch_bounds__(kBlock) void k_eq_halves(const uint64_t *__restrict__ point, uint32_t m, Fe scale,
                                                       uint64_t *__restrict__ d_hi, uint64_t *__restrict__ d_lo, FieldParams P,
                                                       const uint64_t *__restrict__ d_scale = nullptr, const uint64_t *__restrict__ point2 = nullptr,
@@ -94,18 +109,70 @@ __global__ __launch_bounds__(kBlock) void k_eq_halves(const uint64_t *__restrict
 
 // An eq table that is never written out: v[i] = hi[i >> lo_bits] * lo[i & mask] (+ hi2[..] * lo2[..] for alpha*eq(g1,.) +
 // beta*eq(g2,.); the scales sit in the hi halves), read where it is needed from the two halves k_eq_halves leaves -- 2^(m/2)
-// entries each, a few dozen KB that stay in L2 -- at the price of one (two) multiplications.  The GKR kernels gather
+// entries each, a few dozen KB that stay in L2 -- at the price of one multiplication (one and a half for two points: the lo
+// halves are stored as prepared 29-bit multipliers, so both products share one reduction, fe_dot2_29).  The GKR kernels gather
 // E[z], eq_u[x], eq_v[y] at random indices: out of a 32-MiB table that is a 32-byte read from the memory side per gate (what
 // bounded those kernels); out of the halves it is two cache hits.  Exact field arithmetic: the same values as the table's.
 struct EqFactor {
-    const uint64_t *hi, *lo, *hi2, *lo2;   // hi2 == nullptr: one point
+    const uint64_t *hi, *hi2;    // hi2 == nullptr: one point
+    const uint32_t *lo, *lo2;    // prepared multipliers (k_eq_halves lo_prepared), kEqLoWords words per entry
     uint32_t lo_bits;
 };
 ZK_D Fe eq_factor_at(const EqFactor &f, uint32_t i, const FieldParams &P) {
     const uint32_t h = i >> f.lo_bits, l = i & ((1u << f.lo_bits) - 1);
-    Fe v = fe_mul(fe_load(f.hi, h), fe_load(f.lo, l), P);
-    if (f.hi2) v = fe_add(v, fe_mul(fe_load(f.hi2, h), fe_load(f.lo2, l), P), P);   // kernel-uniform branch
-    return v;
+    const Fe a = fe_load(f.hi, h);
+    const Mul29 c = load_eq_lo(f.lo + (size_t)l * kEqLoWords);
+    if (!f.hi2) return fe_mul29(a, c, P);   // kernel-uniform branch
+    return fe_dot2_29(a, c, fe_load(f.hi2, h), load_eq_lo(f.lo2 + (size_t)l * kEqLoWords), P);   // both products, ONE reduction
+}
+
+// The two halves EqFactor reads, for one or two points in one launch: hi = eq over the first m - lo_bits variables with *scale
+// folded in (plain elements), lo = eq over the last lo_bits variables (prepared multipliers).  The split is NOT down the middle:
+// both halves are indexed at random, so the lo half -- the wider records, three loads each -- is kept small enough to sit in a
+// CU's L1 (2^7 entries x 48 B = 6 KiB per table; the hi half of a 2^20 table is then 2^13 elements = 256 KiB, L2-resident).
+// Against a 10 + 10 split: k_gkr_phase<1> 56.1 -> 52.7 us, <2> 79.5 -> 77.8 us (the kernels are VALU-bound by then, see the PMC
+// counters in profiles/r03_gkr_pmc.log).  grid = points * (bh + bl) workgroups, 1024 entries each; every workgroup rebuilds the
+// two quarter tables of its half in LDS (direct products, <= 8 multiplications deep; <= 16 variables per half, so <= 2^8
+// entries per quarter).
+struct EqSplitJob {
+    const uint64_t *point, *scale;   // scale: device scalar or null (= 1)
+    uint64_t *hi;
+    uint32_t *lo;
+};
+static inline uint32_t eq_split_lo_bits(uint64_t m) { return (uint32_t)(m <= 7 ? m : (m > 23 ? m - 16 : 7)); }   // hi <= 16 variables
+__global__ __launch_bounds__(kBlock) void k_eq_split(EqSplitJob j0, EqSplitJob j1, uint32_t m, uint32_t lo_bits, uint32_t bh, uint32_t bl,
+                                                     FieldParams P) {
+    __shared__ uint64_t qa[256 * 4], qb[256 * 4], pt[2 * 16 * 4];
+    const uint32_t per = bh + bl, slot = blockIdx.x % per;
+    const EqSplitJob job = blockIdx.x / per ? j1 : j0;   // (block-uniform)
+    const bool is_hi = slot < bh;
+    const uint32_t slice = is_hi ? slot : slot - bh;
+    const uint32_t nv = is_hi ? m - lo_bits : lo_bits, first = is_hi ? 0 : m - lo_bits;
+    const uint32_t a = nv / 2, b = nv - a, na = 1u << a, nb = 1u << b;
+    Fe one;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
+    if (threadIdx.x < nv) {   // (1 - g, g) pairs of this half's variables
+        const Fe g = fe_load(job.point, first + threadIdx.x);
+        fe_store(pt, 2 * threadIdx.x, fe_sub(one, g, P));
+        fe_store(pt, 2 * threadIdx.x + 1, g);
+    }
+    __syncthreads();
+    const Fe scale = (is_hi && job.scale) ? fe_load(job.scale, 0) : one;
+    for (uint32_t e = threadIdx.x; e < na + nb; e += kBlock) {
+        const bool in_a = e < na;
+        const uint32_t j = in_a ? e : e - na, cnt = in_a ? a : b, off = in_a ? 0 : a;
+        Fe acc = in_a ? scale : one;
+        for (uint32_t w = 0; w < cnt; ++w) acc = fe_mul(acc, fe_load(pt, 2 * (off + w) + ((j >> (cnt - 1 - w)) & 1)), P);
+        fe_store(in_a ? qa : qb, j, acc);
+    }
+    __syncthreads();
+    const uint32_t end = (slice + 1) * 1024 < (1u << nv) ? (slice + 1) * 1024 : (1u << nv);
+    for (uint32_t i = slice * 1024 + threadIdx.x; i < end; i += kBlock) {
+        const Fe v = fe_mul(fe_load(qa, i >> b), fe_load(qb, i & (nb - 1)), P);
+        if (is_hi) fe_store(job.hi, i, v);
+        else store_eq_lo(job.lo + (size_t)i * kEqLoWords, mul29_prepare(v, P));
+    }
 }
 
 // layer evaluation: out[z] = W[left[z]] (+|*) W[right[z]]
