@@ -126,6 +126,13 @@ ZK_D Fe eq_factor_at(const EqFactor &f, uint32_t i, const FieldParams &P) {
     return fe_dot2_29(a, c, fe_load(f.hi2, h), load_eq_lo(f.lo2 + (size_t)l * kEqLoWords), P);   // both products, ONE reduction
 }
 
+// Phase 2's eq_u: its EqFactor carries the SAME point twice, the second hi half scaled by W(u) (free when the halves are built).
+// A mul gate's term is wanted times W(u) (H2 = a + W(u) m), an add gate's plain, so the gate type picks the hi half and the row
+// is closed with one multiplication (C2 = W(u) a) instead of two.
+ZK_D Fe eq_u_at(const EqFactor &f, uint32_t i, bool scaled, const FieldParams &P) {
+    const uint32_t h = i >> f.lo_bits, l = i & ((1u << f.lo_bits) - 1);
+    return fe_mul29(fe_load(scaled ? f.hi2 : f.hi, h), load_eq_lo(f.lo + (size_t)l * kEqLoWords), P);
+}
 // The two halves EqFactor reads, for one or two points in one launch: hi = eq over the first m - lo_bits variables with *scale
 // folded in (plain elements), lo = eq over the last lo_bits variables (prepared multipliers).  The split is NOT down the middle:
 // both halves are indexed at random, so the lo half -- the wider records, three loads each -- is kept small enough to sit in a
@@ -247,15 +254,14 @@ __global__ __launch_bounds__(kBlock) void k_gkr_phase2_heavy(const uint32_t *__r
     Fe s[2] = {fe_zero(), fe_zero()};   // a, m
     for (uint32_t e = rptr[y] + threadIdx.x; e < rptr[y + 1]; e += kBlock) {
         const uint2 ent = rent[e];
-        const Fe t = fe_mul(eq_factor_at(E, ent.x, P), eq_factor_at(eq_u, ent.y & 0x7FFFFFFFu, P), P);
+        const Fe t = fe_mul(eq_factor_at(E, ent.x, P), eq_u_at(eq_u, ent.y & 0x7FFFFFFFu, ent.y >> 31, P), P);   // mul gates: times W(u)
         if (ent.y >> 31) s[1] = fe_add(s[1], t, P);
         else s[0] = fe_add(s[0], t, P);
     }
     gkr_block_sum2(s, P);
     if (threadIdx.x == 0) {
-        const Fe w = fe_load(wu, 0);
-        fe_store(H2, y, fe_add(s[0], fe_mul(w, s[1], P), P));
-        fe_store(C2, y, fe_mul(w, s[0], P));
+        fe_store(H2, y, fe_add(s[0], s[1], P));
+        fe_store(C2, y, fe_mul(fe_load(wu, 0), s[0], P));
     }
 }
 
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void k_gkr_phase2_heavy(const uint32_t *__r
 // input.  An entry is {z, other | op << 31}: the gate's output index and its OTHER input, so a row needs no second indirection
 // through the gate arrays -- the only random accesses are the two 32-byte elements E[z] and T[other].
 //   PHASE 1 (rows x, T = W):    H[x]  = sum_mul E[z] W[y] + sum_add E[z],   B1[x] = sum_add E[z] W[y]
-//   PHASE 2 (rows y, T = eq_u): a = sum_add E[z] eq_u[x], m = sum_mul E[z] eq_u[x]:  H2[y] = a + W(u) m,  C2[y] = W(u) a
+//   PHASE 2 (rows y, T = eq_u): a = sum_add E[z] eq_u[x], m = sum_mul E[z] W(u) eq_u[x]:  H2[y] = a + m,  C2[y] = W(u) a
 // ENTRY-parallel: a workgroup owns kGkrRows consecutive rows and walks THEIR entries one per thread (coalesced entry reads, one
 // pair of gathers and one multiplication per lane, all lanes busy), parks the two addends of every entry in LDS, and the row's
 // thread adds up its own (LDS reads and modular additions only).  The row-parallel form ran as many gather rounds per wave as
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void k_gkr_phase(const uint32_t *__restrict
         if (e < e_hi) {
             const uint2 en = ent[e];
             const Fe ez = eq_factor_at(E, en.x, P);
-            const Fe t = fe_mul(ez, PHASE == 1 ? fe_load(W, en.y & 0x7FFFFFFFu) : eq_factor_at(eq_u, en.y & 0x7FFFFFFFu, P), P);
+            const Fe t = fe_mul(ez, PHASE == 1 ? fe_load(W, en.y & 0x7FFFFFFFu) : eq_u_at(eq_u, en.y & 0x7FFFFFFFu, en.y >> 31, P), P);
             const uint32_t mul = 0u - (en.y >> 31);   // all ones for a mul gate
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -322,9 +328,8 @@ __global__ __launch_bounds__(kBlock) void k_gkr_phase(const uint32_t *__restrict
         fe_store(out0, x, acc0);
         fe_store(out1, x, acc1);
     } else {
-        const Fe w = fe_load(wu, 0);
-        fe_store(out0, x, fe_add(acc0, fe_mul(w, acc1, P), P));
-        fe_store(out1, x, fe_mul(w, acc0, P));
+        fe_store(out0, x, fe_add(acc0, acc1, P));   // the mul gates' terms came multiplied by W(u) (eq_u_at)
+        fe_store(out1, x, fe_mul(fe_load(wu, 0), acc0, P));
     }
 }
 
