@@ -181,8 +181,16 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, u
 // SKIP1 (big fused rounds): the products for t = 1 are not formed at all -- S_i(0) + S_i(1) = S_{i-1}(r_{i-1}) holds
 // identically for the sums the prover itself computed in the previous round (exact field arithmetic, so the derived S_i(1)
 // is bit-identical to the computed one); k_round_tail rebuilds it from the previous round polynomial.
+// Workgroups per CU the register budget is set for.  Two tables: two (<= 256 VGPRs, two waves per SIMD).  Three tables as ONE
+// product (K = 3): also two -- the kernels then spill 52-184 bytes per lane but two waves per SIMD hide more of the loads than the
+// spills cost (k = 3, n = 20: 0.527 -> 0.515 ms).  Three tables as a product plus a single-factor term (the GKR layer polynomial,
+// EXTRA = 1): one -- capped at 256 registers its round 0 spills 108 bytes and the GKR proof got 0.7 % slower
+// (profiles/r03_round_kd_occupancy_ab.log).
+#ifndef ZK_KD_MIN_BLOCKS
+#define ZK_KD_MIN_BLOCKS(K, EXTRA) (((K) + (EXTRA) <= 2 || ((K) == 3 && (EXTRA) == 0)) ? 2 : 1)
+#endif
 template <int K, int D, bool FUSED, int EXTRA = 0, bool SKIP1 = false, bool LEAD = false>
-__global__ __launch_bounds__(kBlock, (K + EXTRA <= 2 ? 2 : 1)) void k_round_kd(FactorPtrs fp, uint64_t q, FieldParams P,
+__global__ __launch_bounds__(kBlock, ZK_KD_MIN_BLOCKS(K, EXTRA)) void k_round_kd(FactorPtrs fp, uint64_t q, FieldParams P,
                                                         const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials) {
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
     Mul29 r = {};
