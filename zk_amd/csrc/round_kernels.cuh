@@ -118,8 +118,12 @@ __global__ __launch_bounds__(kBlock) void k_round(FactorPtrs fp, int k, uint64_t
 template <int K, int D, bool FUSED, int EXTRA = 0>
 struct RoundRegs {
     static constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
+    // sums-only kernels over two tables prefetch TWO pair indices ahead (see round_factor); over three tables the second buffer
+    // (48 registers) is what pushed them past 256 registers, i.e. down to one wave per SIMD: they prefetch one ahead, as the fused
+    // kernels do, and run two waves per SIMD
+    static constexpr bool DEEP = !FUSED && K + EXTRA <= 2;
     Fe cur[K + EXTRA][NL];
-    Fe nxt[FUSED ? 1 : K + EXTRA][FUSED ? 1 : NL];   // sums-only kernels prefetch TWO pair indices ahead (see round_factor)
+    Fe nxt[DEEP ? K + EXTRA : 1][DEEP ? NL : 1];
     Fe prod[NS];
     Fe sum[NS];
     Fe sum_b[EXTRA ? NS : 1];
@@ -145,7 +149,8 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, u
         lo = R.cur[F][0];
         hi = R.cur[F][1];
     }
-    if (FUSED) {
+    constexpr bool DEEP = RoundRegs<K, D, FUSED, EXTRA>::DEEP;
+    if (!DEEP) {
         if (more) {   // this factor's input registers are free: start the next pair's loads now
 #pragma unroll
             for (int l = 0; l < NL; ++l) R.cur[F][l] = fe_load(fp.in[F], jn + (uint64_t)l * q);
@@ -181,16 +186,17 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, u
 // SKIP1 (big fused rounds): the products for t = 1 are not formed at all -- S_i(0) + S_i(1) = S_{i-1}(r_{i-1}) holds
 // identically for the sums the prover itself computed in the previous round (exact field arithmetic, so the derived S_i(1)
 // is bit-identical to the computed one); k_round_tail rebuilds it from the previous round polynomial.
-// Workgroups per CU the register budget is set for.  Two tables: two (<= 256 VGPRs, two waves per SIMD).  Three tables as ONE
-// product (K = 3): also two -- the kernels then spill 52-184 bytes per lane but two waves per SIMD hide more of the loads than the
-// spills cost (k = 3, n = 20: 0.527 -> 0.515 ms).  Three tables as a product plus a single-factor term (the GKR layer polynomial,
-// EXTRA = 1): one -- capped at 256 registers its round 0 spills 108 bytes and the GKR proof got 0.7 % slower
-// (profiles/r03_round_kd_occupancy_ab.log).
+// Workgroups per CU the register budget is set for (two = at most 256 VGPRs = two waves per SIMD).  Two tables: two.  Three
+// tables as ONE product (K = 3): two -- the fused kernels then spill 52-184 bytes per lane, but a second wave per SIMD hides more
+// of the loads than the spills cost (k = 3, n = 20: 0.527 -> 0.515 ms).  A product plus a single-factor term (the GKR layer
+// polynomial, EXTRA = 1): two for the fused SKIP1 kernels (12-44 bytes spilled; GKR proof 7.95 -> 7.76 ms), one for the fused
+// kernels without SKIP1 (212 bytes).  The sums-only kernels over three tables need 212-222 registers since they prefetch one pair
+// index ahead instead of two (RoundRegs::DEEP) and run two waves per SIMD on their own.  profiles/r03_round_kd_occupancy_ab.log
 #ifndef ZK_KD_MIN_BLOCKS
-#define ZK_KD_MIN_BLOCKS(K, EXTRA) (((K) + (EXTRA) <= 2 || ((K) == 3 && (EXTRA) == 0)) ? 2 : 1)
+#define ZK_KD_MIN_BLOCKS(K, EXTRA, FUSED, SKIP1) (((K) + (EXTRA) <= 2 || ((K) == 3 && (EXTRA) == 0) || ((EXTRA) == 1 && (FUSED) && (SKIP1))) ? 2 : 1)
 #endif
 template <int K, int D, bool FUSED, int EXTRA = 0, bool SKIP1 = false, bool LEAD = false>
-__global__ __launch_bounds__(kBlock, ZK_KD_MIN_BLOCKS(K, EXTRA)) void k_round_kd(FactorPtrs fp, uint64_t q, FieldParams P,
+__global__ __launch_bounds__(kBlock, ZK_KD_MIN_BLOCKS(K, EXTRA, FUSED, SKIP1)) void k_round_kd(FactorPtrs fp, uint64_t q, FieldParams P,
                                                         const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials) {
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
     Mul29 r = {};
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(kBlock, ZK_KD_MIN_BLOCKS(K, EXTRA)) void k_round_kd
 #pragma unroll
             for (int l = 0; l < NL; ++l) R.cur[f][l] = fe_load(fp.in[f], j + (uint64_t)l * q);
     }
-    if (!FUSED && j + stride < q) {
+    if (RoundRegs<K, D, FUSED, EXTRA>::DEEP && j + stride < q) {
 #pragma unroll
         for (int f = 0; f < K + EXTRA; ++f)
 #pragma unroll
