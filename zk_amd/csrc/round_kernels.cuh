@@ -120,7 +120,8 @@ struct RoundRegs {
     static constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
     // sums-only kernels over two tables prefetch TWO pair indices ahead (see round_factor); over three tables the second buffer
     // (48 registers) is what pushed them past 256 registers, i.e. down to one wave per SIMD: they prefetch one ahead, as the fused
-    // kernels do, and run two waves per SIMD
+    // kernels do, and run two waves per SIMD.  (Over two tables it makes no difference either way: 150 instead of 182 registers,
+    // three waves instead of two, n = 24 within noise -- profiles/r03_round_kd_occupancy_ab.log.)
     static constexpr bool DEEP = !FUSED && K + EXTRA <= 2;
     Fe cur[K + EXTRA][NL];
     Fe nxt[DEEP ? K + EXTRA : 1][DEEP ? NL : 1];
