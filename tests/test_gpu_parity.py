@@ -682,13 +682,13 @@ def _prove_vs_oracle(field, n, k, D, seed):
 def test_config2_n20_prover_bit_exact_at_default_thresholds(k, D):
     """BASELINE config[1] ("20-var MLE fold + full sumcheck on 1xMI355X, bit-exact vs CPU"): the whole proof -- every round
     polynomial and challenge -- equal to the faithful oracle's, with the kernel thresholds the product ships (SKIP1 rounds from
-    2^17 pairs, quad rounds, pipelined rounds, finisher: every path at its real size).  prover.rs:44-68."""
+    2^16 pairs, quad rounds, pipelined rounds, finisher: every path at its real size).  prover.rs:44-68."""
     _prove_vs_oracle(zk_amd.BN254_FR, 20, k, D, 0x5EED0000 + 20)
 
 
 def test_config3_n24_prover_and_fold_bit_exact():
     """The metric's own size: n = 24, k = 2, D = 2 proof equal to the faithful oracle's (round 0 on 2 x 512 MiB, SKIP1 fused
-    rounds at 2^22..2^17 pairs), and the timed fold (partial_evaluate(0, [r]) of the 2^24 table, evaluation_form.rs:40-80)
+    rounds at 2^22..2^16 pairs), and the timed fold (partial_evaluate(0, [r]) of the 2^24 table, evaluation_form.rs:40-80)
     equal to the oracle's on ALL 2^23 outputs."""
     field = zk_amd.BN254_FR
     _prove_vs_oracle(field, 24, 2, 2, 0x5EED0000 + 24)

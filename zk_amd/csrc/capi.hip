@@ -914,7 +914,7 @@ static std::vector<Fe> interp_weights(uint32_t D, const FieldParams &P);   // de
 static uint64_t skip1_min_pairs() {
     static const uint64_t v = [] {
         const char *e = getenv("ZK_SKIP1_MIN_PAIRS");
-        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)1 << 17;
+        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)1 << 16;
     }();
     return v;
 }
