@@ -937,7 +937,7 @@ struct DeferredTail {
 static uint64_t lead_min_pairs() {
     static const uint64_t v = [] {
         const char *e = getenv("ZK_LEAD_MIN_PAIRS");
-        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)1 << 18;
+        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)1 << 16;
     }();
     return v;
 }
