@@ -562,14 +562,18 @@ def main():
                 claimed = zk_amd.fe_from_int(field, zk_amd.fe_to_int(field, s[0]) + zk_amd.fe_to_int(field, s[1]))
                 prover = zk_amd.SumcheckProver(2)
                 prover.prove_partial(pp, claimed)   # warm
+                # the whole call under std::chrono inside the library (every launch, the transcript, the download of the
+                # proof, the one host wait) -- what a compiled host sees; the same call through this Python binding beside it
+                ms = sorted(zk_amd.bench_prove_partial(pp, 2, claimed, 11))
+                extra[f"sumcheck_prove_partial_ms_n{n}_k2_d2"] = ms[len(ms) // 2]
+                extra[f"sumcheck_prove_partial_ms_n{n}_k2_d2_min"] = ms[0]
                 ts = []
                 for _ in range(11):
                     ctx.synchronize()
                     t1 = time.perf_counter()
                     prover.prove_partial(pp, claimed)
                     ts.append(time.perf_counter() - t1)
-                extra[f"sumcheck_prove_partial_ms_n{n}_k2_d2"] = sorted(ts)[len(ts) // 2] * 1e3
-                extra[f"sumcheck_prove_partial_ms_n{n}_k2_d2_min"] = min(ts) * 1e3
+                extra[f"sumcheck_prove_partial_via_python_ms_n{n}_k2_d2"] = sorted(ts)[len(ts) // 2] * 1e3
                 ts = []
                 for _ in range(3 if n == 20 else 1):
                     ctx.synchronize()

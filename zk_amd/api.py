@@ -458,6 +458,16 @@ def ntt(ctx, vec_in, vec_out, inverse=False):
     return vec_out
 
 
+def bench_prove_partial(poly, max_var_degree, sum_, reps=10):
+    """per-call wall clock (ms) of `reps` prove_partial calls measured inside the library with std::chrono (what a compiled host
+    sees: no binding overhead)"""
+    hp, keep = _handles(poly.polynomials)
+    out = (c.c_double * reps)()
+    check(lib.zk_bench_prove_partial(poly.ctx._h, hp, len(poly.polynomials), int(max_var_degree), _p(np.ascontiguousarray(sum_, dtype=np.uint64)),
+                                     reps, out))
+    return [float(v) for v in out]
+
+
 def bench_ntt(ctx, vec_in, vec_out, inverse=False, reps=5):
     ms = c.c_double()
     check(lib.zk_bench_ntt(ctx._h, vec_in._h, int(inverse), vec_out._h, reps, c.byref(ms)))
@@ -466,6 +476,6 @@ def bench_ntt(ctx, vec_in, vec_out, inverse=False, reps=5):
 
 __all__ = [
     "BN254_FR", "BLS12_381_FR", "BLS12_377_FR", "Context", "MultiLinearPolynomial", "CoeffMultilinearPolynomial", "ProductPoly", "SumcheckProof",
-    "SubClaim", "SumcheckProver", "SumcheckVerifier", "Transcript", "ZkError", "fft", "ifft", "fft_internal", "ntt", "bench_ntt",
+    "SubClaim", "SumcheckProver", "SumcheckVerifier", "Transcript", "ZkError", "fft", "ifft", "fft_internal", "ntt", "bench_ntt", "bench_prove_partial",
     "fe_from_int", "fe_from_ints", "fe_to_int", "fe_to_ints", "keccak256", "modulus", "two_adicity", "root_of_unity",
 ]

@@ -2352,6 +2352,20 @@ extern "C" int32_t zk_bench_ntt(zk_ctx *c, const zk_mle *in, int32_t inverse, zk
     *out_ms = (double)ms / reps;
     return ZK_OK;
 }
+extern "C" int32_t zk_bench_prove_partial(zk_ctx *c, zk_mle *const *f, uint64_t k, uint32_t D, const uint64_t sum[4], int32_t reps,
+                                          double *out_ms_each) {
+    if (!c || !f || !sum || !out_ms_each || reps <= 0) return ZK_ERR_BAD_ARG;
+    ZKCHK(product_args(c, (const zk_mle *const *)f, k));
+    const uint64_t n = f[0]->n_vars;
+    std::vector<uint64_t> rp((size_t)(n ? n : 1) * (D + 1) * 4), ch((size_t)(n ? n : 1) * 4);
+    for (int i = 0; i < reps; ++i) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        ZKCHK(zk_sumcheck_prove(c, f, k, D, sum, 0, 0, rp.data(), ch.data()));
+        out_ms_each[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return ZK_OK;
+}
 extern "C" int32_t zk_bench_modmul(zk_ctx *c, int32_t variant, int32_t iters, double *out) {
     if (!c || !out || iters <= 0) return ZK_ERR_BAD_ARG;
     if (variant != 0 && variant != 1) return ZK_ERR_UNSUPPORTED;
