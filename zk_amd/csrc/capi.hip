@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <cstdio>
@@ -38,6 +39,8 @@ struct zk_ctx {
     uint64_t *d_partials;   // per-block partial sums of a round: kMaxGrid * kMaxSums elements
     uint64_t *d_sums;       // final round sums (kMaxSums elements) + lanes area
     uint64_t *h_pinned;     // pinned staging: kMaxSums*8 u64
+    uint32_t *h_flag;       // completion word in pinned memory: the last kernel of a call stores flag_seq there (host_flag_wait)
+    uint32_t flag_seq;
     uint8_t *h_results;     // pinned staging for proofs (grown on demand)
     std::map<uint32_t, uint64_t *> lagrange_w;   // interp_weights(D) in device memory, cached (a field inversion per node)
     size_t h_results_bytes;
@@ -90,14 +93,40 @@ static inline uint32_t grid_for(uint64_t items) {
     if (b > kMaxGrid) b = kMaxGrid;
     return (uint32_t)b;
 }
-// Wait for the stream: poll for a short while (a proof is ~0.3 ms of GPU time and the blocking wait's wake-up costs tens of
-// microseconds), then block.
-static inline hipError_t stream_wait(hipStream_t s) {
-    for (int i = 0; i < 20000; ++i) {
-        const hipError_t e = hipStreamQuery(s);
-        if (e != hipErrorNotReady) return e;
+// Wait for the stream.  (Until round 3 this spun on hipStreamQuery first; tools/mb/mb_flag.hip: that costs 2-4 us MORE than
+// hipStreamSynchronize for kernels of 1 us .. 1.2 ms, and a completion word in pinned memory -- host_flag_wait below -- 5 us less.)
+static inline hipError_t stream_wait(hipStream_t s) { return hipStreamSynchronize(s); }
+// ---- completion word in pinned host memory -----------------------------------------------------------------------------------
+// The last kernel of a call copies the results into pinned host memory itself and then stores a sequence number next to them
+// (system-scope fence in between); the host spins on that word instead of waiting for the stream's completion signal, which
+// arrives ~5 us later (tools/mb/mb_flag.hip: launch + wait of a 1-us kernel 11.7 us with hipStreamSynchronize, 6.9 us with the
+// word).  The stream itself is checked every few thousand spins so that a failed launch ends the wait with its error.
+__global__ __launch_bounds__(kBlock) void k_publish_host(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst_host, uint32_t n_u64,
+                                                         volatile uint32_t *flag, uint32_t seq) {
+    for (uint32_t i = 2 * threadIdx.x; i < n_u64; i += 2 * kBlock)   // n_u64 is even: elements are 4 words
+        *reinterpret_cast<uint4 *>(dst_host + i) = *reinterpret_cast<const uint4 *>(src + i);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        *flag = seq;
     }
-    return hipStreamSynchronize(s);
+}
+static int32_t host_flag_wait(zk_ctx *c, uint32_t seq) {
+    volatile uint32_t *flag = c->h_flag;
+    for (uint32_t spins = 1;; ++spins) {
+        if (*flag == seq) break;
+        if ((spins & 0x3FFF) == 0) {
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e == hipSuccess) break;                  // the stream has drained: the kernel's stores are visible
+            if (e != hipErrorNotReady) {
+                g_hip_err = std::string("stream failed while waiting for the completion word: ") + hipGetErrorString(e);
+                return ZK_ERR_HIP;
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return ZK_OK;
 }
 static inline int32_t use_device(const zk_ctx *ctx) {
     HIPCHK(hipSetDevice(ctx->device));
@@ -281,6 +310,8 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     c->fi = fi;
     c->own_stream = nullptr;
     c->d_partials = c->d_sums = c->h_pinned = nullptr;
+    c->h_flag = nullptr;
+    c->flag_seq = 0;
     c->h_results = nullptr;
     c->h_results_bytes = 0;
     c->pool_bytes = c->pool_checked = 0;
@@ -302,6 +333,8 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     HIPCHK(hipMalloc(&c->d_partials, (size_t)kMaxGrid * kMaxSums * 32));
     HIPCHK(hipMalloc(&c->d_sums, (size_t)kMaxSums * 32 * 3));
     HIPCHK(hipHostMalloc(&c->h_pinned, (size_t)kMaxSums * 32 * 3, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocDefault));
+    *c->h_flag = 0;
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
     *out = c;
@@ -324,6 +357,7 @@ extern "C" int32_t zk_ctx_destroy(zk_ctx *c) {
     (void)hipFree(c->d_partials);
     (void)hipFree(c->d_sums);
     (void)hipHostFree(c->h_pinned);
+    if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->h_results) (void)hipHostFree(c->h_results);
     for (int b = 0; b < 2; ++b) {
         if (c->h_absorb[b]) (void)hipHostFree(c->h_absorb[b]);
@@ -546,7 +580,8 @@ extern "C" int32_t zk_mle_fold_into(zk_ctx *c, const zk_mle *t, const uint64_t r
 
 // evaluate (evaluation_form.rs:83-89): MSB folds -- the first out of place into scratch, the next ones in place there,
 // and the last <= kEvalTailVars variables in one single-workgroup launch (k_evaluate_tail)
-static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point, uint64_t *d_out_elem) {
+// flag_seq != 0: d_out_elem is pinned host memory and the kernel that writes it also stores flag_seq into c->h_flag (host_flag_wait)
+static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point, uint64_t *d_out_elem, uint32_t flag_seq = 0) {
     const uint64_t n = t->n_vars;
     if (n == 0) {
         HIPCHK(hipMemcpyAsync(d_out_elem, t->d, 32, hipMemcpyDeviceToDevice, c->stream));
@@ -587,7 +622,7 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
             const Fe r = fe_from_u64limbs(point + 4 * (cur - 1 - p));   // index bit p <-> variable cur-1-p (variable 0 is the MSB)
             for (int i = 0; i < 8; ++i) pt.r[p][i] = r.v[i];
         }
-        k_eval_low<<<(uint32_t)n_out, kBlock, 0, c->stream>>>(src, dst, (uint32_t)L, pt, P);
+        k_eval_low<<<(uint32_t)n_out, kBlock, 0, c->stream>>>(src, dst, (uint32_t)L, pt, P, (flag_seq && L == cur) ? c->h_flag : nullptr, flag_seq);
         if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
         src = dst;
         cur -= L;
@@ -641,7 +676,8 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
             hipSuccess)
             rc = ZK_ERR_HIP;
         if (rc == ZK_OK) {
-            k_evaluate_tail<<<1, kEvalTailThreads, lds, c->stream>>>(src, (uint32_t)tail_vars, chs, P, d_out_elem);
+            k_evaluate_tail<<<1, kEvalTailThreads, lds, c->stream>>>(src, (uint32_t)tail_vars, chs, P, d_out_elem, flag_seq ? c->h_flag : nullptr,
+                                                                     flag_seq);
             if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
         }
     }
@@ -662,7 +698,18 @@ extern "C" int32_t zk_mle_evaluate(zk_ctx *c, const zk_mle *t, const uint64_t *p
     } else {
         // the last kernel stores the 32-byte result straight into the pinned host buffer (mapped into the device's address space):
         // a device-to-host copy of 32 bytes is a blit launch of its own (4-5 us on the stream)
-        ZKCHK(evaluate_device(c, t, point, c->h_pinned));
+        const uint32_t seq = ++c->flag_seq;
+        ZKCHK(evaluate_device(c, t, point, c->h_pinned, seq));
+        const auto t_enq0 = std::chrono::steady_clock::now();
+        ZKCHK(host_flag_wait(c, seq));   // the completion word the last kernel stores next to the result
+        if (host_dbg) {
+            const auto t_done = std::chrono::steady_clock::now();
+            fprintf(stderr, "[host] evaluate n=%llu: enqueue %.1f us, wait %.1f us\n", (unsigned long long)t->n_vars,
+                    std::chrono::duration<double, std::micro>(t_enq0 - t_enter).count(),
+                    std::chrono::duration<double, std::micro>(t_done - t_enq0).count());
+        }
+        memcpy(out, c->h_pinned, 32);
+        return ZK_OK;
     }
     const auto t_enq = std::chrono::steady_clock::now();
     HIPCHK(stream_wait(c->stream));
@@ -1668,12 +1715,15 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
     uint8_t *stage = nullptr;
     const size_t block = st.ps.rp_bytes + st.ps.ch_bytes + kMaxFactors * 32;
     if (rc == ZK_OK) rc = results_staging(c, block, &stage);
-    if (rc == ZK_OK && hipMemcpyAsync(stage, st.ps.d_rp, block, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ZK_ERR_HIP;
-    const auto t_enq = std::chrono::steady_clock::now();
-    if (stream_wait(c->stream) != hipSuccess && rc == ZK_OK) {
-        g_hip_err = "sumcheck: stream synchronize failed";
-        rc = ZK_ERR_HIP;
+    uint32_t seq = 0;
+    if (rc == ZK_OK) {   // the proof block goes to pinned memory by a kernel that also stores the completion word
+        seq = ++c->flag_seq;
+        k_publish_host<<<1, kBlock, 0, c->stream>>>(st.ps.d_rp, reinterpret_cast<uint64_t *>(stage), (uint32_t)(block / 8), c->h_flag, seq);
+        if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
     }
+    const auto t_enq = std::chrono::steady_clock::now();
+    if (rc == ZK_OK) rc = host_flag_wait(c, seq);
+    else (void)stream_wait(c->stream);
     if (host_dbg) {
         const auto t_done = std::chrono::steady_clock::now();
         fprintf(stderr, "[host] n=%llu: enqueue %.1f us (everything up to the last launch), wait %.1f us\n", (unsigned long long)n,

@@ -120,7 +120,7 @@ struct EvalLowPoint {   // r for index bit p (Montgomery form), p = 0 the least 
     uint32_t r[kEvalLowMax][8];
 };
 __global__ __launch_bounds__(kBlock) void k_eval_low(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t L,
-                                                     EvalLowPoint pt, FieldParams P) {
+                                                     EvalLowPoint pt, FieldParams P, volatile uint32_t *flag = nullptr, uint32_t seq = 0) {
     __shared__ Fe eq[3][16];
     __shared__ uint32_t red[kBlock / 64][8];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -172,6 +172,10 @@ __global__ __launch_bounds__(kBlock) void k_eval_low(const uint64_t *__restrict_
             acc = fe_add(acc, o, P);
         }
         fe_store(out, blockIdx.x, acc);
+        if (flag) {   // (single-workgroup launches only) completion word for the host, after the result
+            __threadfence_system();
+            *flag = seq;
+        }
     }
 }
 
@@ -187,7 +191,7 @@ struct EvalTailChallenges {   // the m remaining assignments in prepared form, p
 };
 __global__ __launch_bounds__(kEvalTailThreads) void k_evaluate_tail(const uint64_t *__restrict__ in, uint32_t m,
                                                                     EvalTailChallenges chs, FieldParams P,
-                                                                    uint64_t *__restrict__ out) {
+                                                                    uint64_t *__restrict__ out, volatile uint32_t *flag = nullptr, uint32_t seq = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ev_smem[];
     uint64_t *T = reinterpret_cast<uint64_t *>(ev_smem);
     const uint32_t tid = threadIdx.x;
@@ -215,7 +219,13 @@ __global__ __launch_bounds__(kEvalTailThreads) void k_evaluate_tail(const uint64
         }
         __syncthreads();
     }
-    if (tid == 0) fe_store(out, 0, fe_load(T, 0));
+    if (tid == 0) {
+        fe_store(out, 0, fe_load(T, 0));
+        if (flag) {   // completion word for the host (capi.hip host_flag_wait): after the result, system scope
+            __threadfence_system();
+            *flag = seq;
+        }
+    }
 }
 
 // ---- ProductPoly::prod_reduce (product_poly.rs:66-74) --------------------------------------------------------
