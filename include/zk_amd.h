@@ -337,6 +337,8 @@ int32_t zk_bench_ntt(zk_ctx *ctx, const zk_mle *in, int32_t inverse, zk_mle *out
    wait -- as SURVEY 8(d) prescribes for the prover; out_ms_each[reps].  What a compiled host sees: no binding overhead. */
 int32_t zk_bench_prove_partial(zk_ctx *ctx, zk_mle *const *factors, uint64_t k, uint32_t max_var_degree, const uint64_t sum[4],
                                int32_t reps, double *out_ms_each);
+/* the same for zk_mle_evaluate (the reference's own criterion bench, polynomial/benches/polynomial_evaluation.rs): per-call ms */
+int32_t zk_bench_evaluate(zk_ctx *ctx, const zk_mle *t, const uint64_t *point, uint64_t n_point, int32_t reps, double *out_ms_each);
 /* register-resident modular-multiply throughput (no memory traffic): variant 0 = fe_mul chain. Returns modmul/s */
 int32_t zk_bench_modmul(zk_ctx *ctx, int32_t variant, int32_t iters, double *out_modmul_per_s);
 /* plain 16-B/lane streaming copy of `bytes` bytes: achieved GB/s (calibrates the HBM ceiling on this device) */

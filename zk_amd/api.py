@@ -468,6 +468,14 @@ def bench_prove_partial(poly, max_var_degree, sum_, reps=10):
     return [float(v) for v in out]
 
 
+def bench_evaluate(table, point, reps=10):
+    """per-call wall clock (ms) of `reps` evaluate calls measured inside the library with std::chrono"""
+    pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+    out = (c.c_double * reps)()
+    check(lib.zk_bench_evaluate(table.ctx._h, table._h, _p(pt if pt.size else np.zeros((1, 4), dtype=np.uint64)), pt.shape[0], reps, out))
+    return [float(v) for v in out]
+
+
 def bench_ntt(ctx, vec_in, vec_out, inverse=False, reps=5):
     ms = c.c_double()
     check(lib.zk_bench_ntt(ctx._h, vec_in._h, int(inverse), vec_out._h, reps, c.byref(ms)))
@@ -476,6 +484,6 @@ def bench_ntt(ctx, vec_in, vec_out, inverse=False, reps=5):
 
 __all__ = [
     "BN254_FR", "BLS12_381_FR", "BLS12_377_FR", "Context", "MultiLinearPolynomial", "CoeffMultilinearPolynomial", "ProductPoly", "SumcheckProof",
-    "SubClaim", "SumcheckProver", "SumcheckVerifier", "Transcript", "ZkError", "fft", "ifft", "fft_internal", "ntt", "bench_ntt", "bench_prove_partial",
+    "SubClaim", "SumcheckProver", "SumcheckVerifier", "Transcript", "ZkError", "fft", "ifft", "fft_internal", "ntt", "bench_ntt", "bench_prove_partial", "bench_evaluate",
     "fe_from_int", "fe_from_ints", "fe_to_int", "fe_to_ints", "keccak256", "modulus", "two_adicity", "root_of_unity",
 ]

@@ -2416,6 +2416,17 @@ extern "C" int32_t zk_bench_prove_partial(zk_ctx *c, zk_mle *const *f, uint64_t 
     }
     return ZK_OK;
 }
+extern "C" int32_t zk_bench_evaluate(zk_ctx *c, const zk_mle *t, const uint64_t *point, uint64_t n_point, int32_t reps, double *out_ms_each) {
+    if (!c || !t || !out_ms_each || reps <= 0) return ZK_ERR_BAD_ARG;
+    uint64_t out[4];
+    for (int i = 0; i < reps; ++i) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        ZKCHK(zk_mle_evaluate(c, t, point, n_point, out));
+        out_ms_each[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return ZK_OK;
+}
 extern "C" int32_t zk_bench_modmul(zk_ctx *c, int32_t variant, int32_t iters, double *out) {
     if (!c || !out || iters <= 0) return ZK_ERR_BAD_ARG;
     if (variant != 0 && variant != 1) return ZK_ERR_UNSUPPORTED;
