@@ -101,16 +101,13 @@ static inline hipError_t stream_wait(hipStream_t s) { return hipStreamSynchroniz
 // (system-scope fence in between); the host spins on that word instead of waiting for the stream's completion signal, which
 // arrives ~5 us later (tools/mb/mb_flag.hip: launch + wait of a 1-us kernel 11.7 us with hipStreamSynchronize, 6.9 us with the
 // word).  The stream itself is checked every few thousand spins so that a failed launch ends the wait with its error.
-__global__ __launch_bounds__(kBlock) void k_publish_host(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst_host, uint32_t n_u64,
-                                                         volatile uint32_t *flag, uint32_t seq) {
-    for (uint32_t i = 2 * threadIdx.x; i < n_u64; i += 2 * kBlock)   // n_u64 is even: elements are 4 words
+__global__ __launch_bounds__(64) void k_publish_host(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst_host, uint32_t n_u64,
+                                                     volatile uint32_t *flag, uint32_t seq) {
+    // ONE wave: its lanes' stores, then one system-scope fence for the whole wave, then the word -- no workgroup barrier
+    for (uint32_t i = 2 * threadIdx.x; i < n_u64; i += 2 * 64)   // n_u64 is even: elements are 4 words
         *reinterpret_cast<uint4 *>(dst_host + i) = *reinterpret_cast<const uint4 *>(src + i);
     __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence_system();
-        *flag = seq;
-    }
+    if (threadIdx.x == 0) *flag = seq;
 }
 static int32_t host_flag_wait(zk_ctx *c, uint32_t seq) {
     volatile uint32_t *flag = c->h_flag;
@@ -1718,7 +1715,7 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
     uint32_t seq = 0;
     if (rc == ZK_OK) {   // the proof block goes to pinned memory by a kernel that also stores the completion word
         seq = ++c->flag_seq;
-        k_publish_host<<<1, kBlock, 0, c->stream>>>(st.ps.d_rp, reinterpret_cast<uint64_t *>(stage), (uint32_t)(block / 8), c->h_flag, seq);
+        k_publish_host<<<1, 64, 0, c->stream>>>(st.ps.d_rp, reinterpret_cast<uint64_t *>(stage), (uint32_t)(block / 8), c->h_flag, seq);
         if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
     }
     const auto t_enq = std::chrono::steady_clock::now();
