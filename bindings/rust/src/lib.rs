@@ -7,6 +7,7 @@
 //! Reference items mirrored (paths relative to the reference checkout):
 //!   polynomial/src/multilinear/evaluation_form.rs:4-103  MultiLinearPolynomial<F>  (Clone, Debug, PartialEq)
 //!   polynomial/src/multilinear/pairing_index.rs:2-9      index_pair
+//!   polynomial/src/multilinear/pairing_index.rs:24-26    mask
 //!   polynomial/src/product_poly.rs:6-88                  ProductPoly<F>            (Clone, Debug, PartialEq)
 //!   sumcheck/src/prover.rs:9-73                          SumcheckProver<MAX_VAR_DEGREE, F>
 //!   sumcheck/src/verifier.rs:9-41                        SumcheckVerifier<F>
@@ -153,6 +154,12 @@ fn ctx<F: GpuField>() -> Result<Rc<Ctx>, &'static str> {
         Ok(c)
     })
 }
+/// polynomial/src/multilinear/pairing_index.rs:24-26 — a bit sequence of n ones (`mask(1) -> 1`, `mask(3) -> 0b111`); public in the
+/// reference, so part of the surface a caller may use.  Overflows (a panic in debug builds) at n >= usize::BITS like the original.
+pub const fn mask(n: u8) -> usize {
+    (1 << n) - 1
+}
+
 /// `&[F]` as the limb array the C ABI expects (ark-ff stores exactly this).
 fn limbs<F: GpuField>(v: &[F]) -> *const u64 { v.as_ptr() as *const u64 }
 fn limbs_mut<F: GpuField>(v: &mut [F]) -> *mut u64 { v.as_mut_ptr() as *mut u64 }
@@ -162,7 +169,7 @@ fn limbs_mut<F: GpuField>(v: &mut [F]) -> *mut u64 { v.as_mut_ptr() as *mut u64 
 pub fn index_pair(n_vars: u8, index: u8) -> impl Iterator<Item = (usize, usize)> {
     let pos = n_vars - 1 - index;
     (0..1usize << (n_vars - 1)).map(move |j| {
-        let left = ((j >> pos) << (pos + 1)) | (j & ((1usize << pos) - 1));
+        let left = ((j >> pos) << (pos + 1)) | (j & mask(pos));
         (left, left | (1usize << pos))
     })
 }

@@ -112,6 +112,9 @@ TEST(test_index_pair_clone_eq_sample_n) {
     ASSERT_EQ(index_pair(3, 1), (PV{{0, 2}, {1, 3}, {4, 6}, {5, 7}}));
     ASSERT_EQ(index_pair(3, 2), (PV{{0, 1}, {2, 3}, {4, 5}, {6, 7}}));
     ASSERT_EQ(index_pair(1, 0), (PV{{0, 1}}));
+    ASSERT_EQ(mask(1), (size_t)1);        // pairing_index.rs:22-23 doc examples
+    ASSERT_EQ(mask(3), (size_t)0b111);
+    ASSERT_EQ(mask(0), (size_t)0);
     auto p = MultiLinearPolynomial<F>::new_(2, frs({3, 1, 2, 5})).unwrap();
     auto q = MultiLinearPolynomial<F>::new_(2, frs({3, 1, 2, 5})).unwrap();
     auto r = MultiLinearPolynomial<F>::new_(2, frs({3, 1, 2, 6})).unwrap();

@@ -169,3 +169,24 @@ def test_argument_validation_without_gpu():
     arr = (ctypes.c_void_p * 1)()
     assert _lib.lib.zk_product_check(ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p)), 0) == -3
     assert _lib.lib.zk_ctx_create(9, 0, ctypes.byref(ctypes.c_void_p())) == -21
+
+
+def test_verifier_round_count_is_never_an_allocation_size():
+    """A hostile round count must come back as a status, never as an exception across the C ABI: the uniform-degree entry
+    points used to size a std::vector by n_rounds + 1 before looking at the proof (UINT64_MAX wrapped it to 0)."""
+    field = zk_amd.BN254_FR
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    one = orc.from_int(field, 1)
+    # claimed sum 5 against a first round that sums to 2: rejected at round 0, whatever the count says
+    rps = np.ascontiguousarray(np.stack([one, one, one]))
+    claimed = np.ascontiguousarray(orc.from_int(field, 5))
+    out_sum = np.zeros(4, dtype=np.uint64)
+    out_ch = np.zeros(4, dtype=np.uint64)
+    for n_rounds in (2**64 - 1, 2**62, 2**40):
+        rc = _lib.lib.zk_sumcheck_verify_partial(field, ctypes.c_uint64(n_rounds), 2, claimed.ctypes.data_as(u64p),
+                                                 rps.ctypes.data_as(u64p), out_sum.ctypes.data_as(u64p),
+                                                 out_ch.ctypes.data_as(u64p))
+        assert rc == -9
+    # and a missing proof pointer with a non-zero count is a plain argument error
+    assert _lib.lib.zk_sumcheck_verify_partial(field, ctypes.c_uint64(2**63), 2, claimed.ctypes.data_as(u64p), None,
+                                               out_sum.ctypes.data_as(u64p), out_ch.ctypes.data_as(u64p)) == -20

@@ -7,6 +7,8 @@ context per field (a context per call breaks ProductPoly::new for k >= 2)."""
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")
 HEADER = os.path.join(ROOT, "include", "zk_amd.h")
@@ -152,6 +154,7 @@ def test_items_the_reference_tests_need_exist():
         r"pub fn sample_n_field_elements<F: GpuField>\(&mut self, n: usize\) -> Vec<F>",
         r"pub fn fft_internal<F: GpuField>\(values: Vec<F>, omega: F\) -> Vec<F>",
         r"pub fn index_pair\(n_vars: u8, index: u8\) -> impl Iterator<Item = \(usize, usize\)>",
+        r"pub const fn mask\(n: u8\) -> usize",                       # pairing_index.rs:24-26 (public in the reference)
         r"pub fn evaluation_slice\(&self\) -> &\[F\]",
         r"pub fn prove\(poly: ProductPoly<F>, sum: F\) -> Result<SumcheckProof<F>, &'static str>",
         r"pub fn prove_partial\(poly: ProductPoly<F>, sum: F\) -> Result<\(SumcheckProof<F>, Vec<F>\), &'static str>",
@@ -194,6 +197,25 @@ def test_verifier_passes_each_round_at_its_own_length():
     body = body[:body.index("pub fn fft<F: GpuField>")]
     assert "zk_sumcheck_verify_lengths(" in body and "zk_sumcheck_verify_partial_lengths(" in body
     assert "r.len() != ns" not in body and "ZK_ERR_VERIFY_SUM" not in body
+
+
+def test_mask_is_exported_with_the_reference_body():
+    """pairing_index.rs:24-26 `pub const fn mask(n: u8) -> usize { (1 << n) - 1 }`: the shim exports it with that body, index_pair
+    uses it, and the C++ / Python mirrors agree on the reference's doc examples (mask(1) -> 1, mask(3) -> 0b111)."""
+    code = re.sub(r"//[^\n]*", "", open(SHIM).read())
+    m = re.search(r"pub const fn mask\(n: u8\) -> usize \{\s*\(1 << n\) - 1\s*\}", code)
+    assert m, "mask must be `(1 << n) - 1`"
+    body = code[code.index("pub fn index_pair("):]
+    body = body[:body.index("pub struct MultiLinearPolynomial")]
+    assert "mask(pos)" in body
+    hpp = open(os.path.join(ROOT, "zk_amd", "host", "zk.hpp")).read()
+    assert re.search(r"inline size_t mask\(uint8_t n\)", hpp)
+    import zk_amd
+
+    assert [zk_amd.mask(n) for n in (0, 1, 3, 8)] == [0, 1, 0b111, 255]
+    assert zk_amd.index_pair(3, 1) == [(0, 2), (1, 3), (4, 6), (5, 7)]       # pairing_index.rs:70-77
+    with pytest.raises(zk_amd.ZkError):
+        zk_amd.index_pair(0, 0)
 
 
 def test_index_pair_formula_matches_the_reference_kats():

@@ -75,6 +75,25 @@ def fe_to_ints(field, arr):
     return [fe_to_int(field, arr[i]) for i in range(arr.shape[0])]
 
 
+def mask(n):  # polynomial/src/multilinear/pairing_index.rs:24-26
+    """a bit sequence of n ones: mask(1) -> 1, mask(3) -> 0b111"""
+    if not 0 <= n < 64:
+        raise ZkError(-5)   # the reference's usize shift overflows here
+    return (1 << n) - 1
+
+
+def index_pair(n_vars, index):  # polynomial/src/multilinear/pairing_index.rs:2-9
+    """the (left, right) table indices that partial_evaluate pairs up when it assigns variable `index` (variable 0 = index MSB)"""
+    if n_vars < 1 or not 0 <= index < n_vars:
+        raise ZkError(-5)   # u8 underflow in the reference
+    pos = n_vars - 1 - index
+    out = []
+    for j in range(1 << (n_vars - 1)):
+        left = ((j >> pos) << (pos + 1)) | (j & mask(pos))
+        out.append((left, left | (1 << pos)))
+    return out
+
+
 def keccak256(data: bytes) -> bytes:
     buf = c.create_string_buffer(32)
     check(lib.zk_keccak256(bytes(data), len(data), buf))
@@ -485,5 +504,5 @@ def bench_ntt(ctx, vec_in, vec_out, inverse=False, reps=5):
 __all__ = [
     "BN254_FR", "BLS12_381_FR", "BLS12_377_FR", "Context", "MultiLinearPolynomial", "CoeffMultilinearPolynomial", "ProductPoly", "SumcheckProof",
     "SubClaim", "SumcheckProver", "SumcheckVerifier", "Transcript", "ZkError", "fft", "ifft", "fft_internal", "ntt", "bench_ntt", "bench_prove_partial", "bench_evaluate",
-    "fe_from_int", "fe_from_ints", "fe_to_int", "fe_to_ints", "keccak256", "modulus", "two_adicity", "root_of_unity",
+    "fe_from_int", "fe_from_ints", "fe_to_int", "fe_to_ints", "keccak256", "modulus", "two_adicity", "root_of_unity", "mask", "index_pair",
 ]

@@ -109,6 +109,12 @@ __global__ __launch_bounds__(64) void k_publish_host(const uint64_t *__restrict_
     __threadfence_system();
     if (threadIdx.x == 0) *flag = seq;
 }
+static constexpr unsigned kPolledHostFlags = hipHostMallocCoherent | hipHostMallocMapped;
+// next completion sequence number; 0 is reserved ("this launch writes no word"), so it is skipped when the counter wraps
+static inline uint32_t next_flag_seq(zk_ctx *c) {
+    if (++c->flag_seq == 0) ++c->flag_seq;
+    return c->flag_seq;
+}
 static int32_t host_flag_wait(zk_ctx *c, uint32_t seq) {
     volatile uint32_t *flag = c->h_flag;
     for (uint32_t spins = 1;; ++spins) {
@@ -329,8 +335,10 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     c->stream = c->own_stream;
     HIPCHK(hipMalloc(&c->d_partials, (size_t)kMaxGrid * kMaxSums * 32));
     HIPCHK(hipMalloc(&c->d_sums, (size_t)kMaxSums * 32 * 3));
-    HIPCHK(hipHostMalloc(&c->h_pinned, (size_t)kMaxSums * 32 * 3, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocDefault));
+    // completion word + result staging are POLLED by the host while the kernel that writes them is still running: ask for
+    // coherent (fine-grained) mapped memory explicitly instead of relying on HIP_HOST_COHERENT's default
+    HIPCHK(hipHostMalloc(&c->h_pinned, (size_t)kMaxSums * 32 * 3, kPolledHostFlags));
+    HIPCHK(hipHostMalloc((void **)&c->h_flag, 64, kPolledHostFlags));
     *c->h_flag = 0;
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
@@ -695,7 +703,7 @@ extern "C" int32_t zk_mle_evaluate(zk_ctx *c, const zk_mle *t, const uint64_t *p
     } else {
         // the last kernel stores the 32-byte result straight into the pinned host buffer (mapped into the device's address space):
         // a device-to-host copy of 32 bytes is a blit launch of its own (4-5 us on the stream)
-        const uint32_t seq = ++c->flag_seq;
+        const uint32_t seq = next_flag_seq(c);
         ZKCHK(evaluate_device(c, t, point, c->h_pinned, seq));
         const auto t_enq0 = std::chrono::steady_clock::now();
         ZKCHK(host_flag_wait(c, seq));   // the completion word the last kernel stores next to the result
@@ -753,8 +761,21 @@ extern "C" int32_t zk_mle_partial_evaluate_host(zk_ctx *c, uint64_t n_vars, cons
 }
 
 // CoeffMultilinearPolynomial::to_evaluation_form (coefficient_form.rs:340-347): scatter + zeta transform on the device
+static int32_t coeff_to_evaluation_impl(zk_ctx *c, uint64_t n_vars, const uint64_t *keys, const uint64_t *coeffs, uint64_t n_terms,
+                                        zk_mle **out);
+// the term list is merged in host containers sized by the caller's n_terms: an allocation failure is a status, not an exception
 extern "C" int32_t zk_coeff_to_evaluation(zk_ctx *c, uint64_t n_vars, const uint64_t *keys, const uint64_t *coeffs, uint64_t n_terms,
                                           zk_mle **out) {
+    try {
+        return coeff_to_evaluation_impl(c, n_vars, keys, coeffs, n_terms, out);
+    } catch (const std::bad_alloc &) {
+        return ZK_ERR_ALLOC;
+    } catch (...) {
+        return ZK_ERR_BAD_ARG;
+    }
+}
+static int32_t coeff_to_evaluation_impl(zk_ctx *c, uint64_t n_vars, const uint64_t *keys, const uint64_t *coeffs, uint64_t n_terms,
+                                        zk_mle **out) {
     if (!c || !out || (n_terms && (!keys || !coeffs))) return ZK_ERR_BAD_ARG;
     if (n_vars == 0 || n_vars > kMaxVars) return ZK_ERR_EVAL_LEN;
     for (uint64_t t = 0; t < n_terms; ++t)
@@ -931,7 +952,7 @@ static int32_t results_staging(zk_ctx *c, size_t bytes, uint8_t **out) {
         c->h_results_bytes = 0;
         size_t cap = 1 << 16;
         while (cap < bytes) cap <<= 1;
-        HIPCHK(hipHostMalloc((void **)&c->h_results, cap, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&c->h_results, cap, kPolledHostFlags));
         c->h_results_bytes = cap;
     }
     *out = c->h_results;
@@ -1714,7 +1735,7 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
     if (rc == ZK_OK) rc = results_staging(c, block, &stage);
     uint32_t seq = 0;
     if (rc == ZK_OK) {   // the proof block goes to pinned memory by a kernel that also stores the completion word
-        seq = ++c->flag_seq;
+        seq = next_flag_seq(c);
         k_publish_host<<<1, 64, 0, c->stream>>>(st.ps.d_rp, reinterpret_cast<uint64_t *>(stage), (uint32_t)(block / 8), c->h_flag, seq);
         if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
     }
@@ -2026,15 +2047,17 @@ static Fe interp_eval(const std::vector<Fe> &ys, const std::vector<Fe> &w, const
 // Each round polynomial is interpolated at ITS OWN length (proof.round_polys is a Vec<Vec<F>>; verifier.rs:55-58 hands
 // whatever the round carries to UnivariatePolynomial::interpolate): lens[r] evaluations for round r, stored back to back.
 // 0 evaluations -> the zero polynomial (interpolate of no points, evaluate of no coefficients = 0), 1 -> a constant.
-static int32_t verify_internal(const FieldParams &P, Sponge &sp, uint64_t n_rounds, const uint32_t *lens, const uint64_t sum[4],
-                               const uint64_t *rps, Fe &claimed, uint64_t *out_ch) {   // verifier.rs:44-78
+// lens == nullptr: every round carries `uniform_len` evaluations (the D + 1 of verify / verify_partial) -- no per-round array is
+// built from a caller-supplied round count, so a hostile count cannot make the library allocate (or throw) before it is checked.
+static int32_t verify_internal(const FieldParams &P, Sponge &sp, uint64_t n_rounds, const uint32_t *lens, uint32_t uniform_len,
+                               const uint64_t sum[4], const uint64_t *rps, Fe &claimed, uint64_t *out_ch) {   // verifier.rs:44-78
     absorb_elements(sp, sum, 1, P);                                      // :50
     claimed = fe_from_u64limbs(sum);
     std::vector<Fe> w;
     uint32_t w_len = ~0u;
     const uint64_t *rp = rps;
     for (uint64_t r = 0; r < n_rounds; ++r) {
-        const uint32_t len = lens[r];
+        const uint32_t len = lens ? lens[r] : uniform_len;
         if (len) absorb_elements(sp, rp, len, P);                        // :56 (no bytes for an empty round polynomial)
         std::vector<Fe> ys(len);
         for (uint32_t t = 0; t < len; ++t) ys[t] = fe_from_u64limbs(rp + 4 * t);
@@ -2051,57 +2074,67 @@ static int32_t verify_internal(const FieldParams &P, Sponge &sp, uint64_t n_roun
 }
 static int32_t verify_internal(const FieldParams &P, Sponge &sp, uint64_t n_rounds, uint32_t D, const uint64_t sum[4],
                                const uint64_t *rps, Fe &claimed, uint64_t *out_ch) {   // every round D + 1 evaluations
-    const std::vector<uint32_t> lens(n_rounds + 1, D + 1);
-    return verify_internal(P, sp, n_rounds, lens.data(), sum, rps, claimed, out_ch);
+    return verify_internal(P, sp, n_rounds, nullptr, D + 1, sum, rps, claimed, out_ch);
 }
 static int32_t check_lens(uint64_t n_rounds, const uint32_t *lens) {
     for (uint64_t r = 0; r < n_rounds; ++r)
         if (lens[r] > kMaxSums) return ZK_ERR_BAD_ARG;
     return ZK_OK;
 }
-extern "C" int32_t zk_sumcheck_verify_partial_lengths(int32_t field, uint64_t n_rounds, const uint32_t *lens,
-                                                      const uint64_t sum[4], const uint64_t *rps, uint64_t out_sum[4],
-                                                      uint64_t *out_ch) {
+// shared bodies of the four verifier entry points: lens == nullptr means `uniform_len` evaluations in every round
+static int32_t verify_partial_common(int32_t field, uint64_t n_rounds, const uint32_t *lens, uint32_t uniform_len,
+                                     const uint64_t sum[4], const uint64_t *rps, uint64_t out_sum[4], uint64_t *out_ch) {
     const FieldInfo *fi = field_info(field);
     if (!fi) return ZK_ERR_BAD_FIELD;
-    if (!sum || !out_sum || (n_rounds && (!lens || !rps || !out_ch))) return ZK_ERR_BAD_ARG;
-    ZKCHK(check_lens(n_rounds, lens));
+    if (!sum || !out_sum || (n_rounds && (!rps || !out_ch))) return ZK_ERR_BAD_ARG;
+    if (lens) ZKCHK(check_lens(n_rounds, lens));
     Sponge sp;
     sp.init();
     Fe claimed;
-    ZKCHK(verify_internal(fi->P, sp, n_rounds, lens, sum, rps, claimed, out_ch));
+    ZKCHK(verify_internal(fi->P, sp, n_rounds, lens, uniform_len, sum, rps, claimed, out_ch));
     fe_to_u64limbs(claimed, out_sum);
     return ZK_OK;
+}
+static int32_t verify_common(zk_ctx *c, const zk_mle *const *f, uint64_t k, uint64_t n_rps, const uint32_t *lens,
+                             uint32_t uniform_len, const uint64_t sum[4], const uint64_t *rps, int32_t *out_ok) {
+    if (!sum || !out_ok || (n_rps && !rps)) return ZK_ERR_BAD_ARG;
+    ZKCHK(product_args(c, f, k));
+    if (n_rps != f[0]->n_vars) return ZK_ERR_VERIFY_ROUNDS;              // verifier.rs:17-19 -- BEFORE anything is sized by n_rps
+    if (lens) ZKCHK(check_lens(n_rps, lens));
+    Sponge sp;
+    sp.init();
+    ZKCHK(absorb_tables(c, sp, (zk_mle *const *)f, k));                  // :22
+    uint64_t ch[4 * (kMaxVars + 1)];                                     // n_rps == n_vars <= kMaxVars
+    Fe claimed;
+    ZKCHK(verify_internal(c->fi->P, sp, n_rps, lens, uniform_len, sum, rps, claimed, ch));
+    uint64_t ev[4];
+    ZKCHK(zk_product_evaluate(c, f, k, ch, n_rps, ev));                  // :27-29
+    *out_ok = fe_eq(fe_from_u64limbs(ev), claimed) ? 1 : 0;              // :31
+    return ZK_OK;
+}
+extern "C" int32_t zk_sumcheck_verify_partial_lengths(int32_t field, uint64_t n_rounds, const uint32_t *lens,
+                                                      const uint64_t sum[4], const uint64_t *rps, uint64_t out_sum[4],
+                                                      uint64_t *out_ch) {
+    if (n_rounds && !lens) return ZK_ERR_BAD_ARG;
+    static const uint32_t none = 0;
+    return verify_partial_common(field, n_rounds, lens ? lens : &none, 0, sum, rps, out_sum, out_ch);
 }
 extern "C" int32_t zk_sumcheck_verify_partial(int32_t field, uint64_t n_rounds, uint32_t D, const uint64_t sum[4],
                                               const uint64_t *rps, uint64_t out_sum[4], uint64_t *out_ch) {
     if (D >= kMaxSums) return ZK_ERR_BAD_ARG;
-    const std::vector<uint32_t> lens(n_rounds + 1, D + 1);
-    return zk_sumcheck_verify_partial_lengths(field, n_rounds, lens.data(), sum, rps, out_sum, out_ch);
+    return verify_partial_common(field, n_rounds, nullptr, D + 1, sum, rps, out_sum, out_ch);
 }
 extern "C" int32_t zk_sumcheck_verify_lengths(zk_ctx *c, const zk_mle *const *f, uint64_t k, uint64_t n_rps,
                                               const uint32_t *lens, const uint64_t sum[4], const uint64_t *rps,
                                               int32_t *out_ok) {
-    if (!sum || !out_ok || (n_rps && (!rps || !lens))) return ZK_ERR_BAD_ARG;
-    ZKCHK(product_args(c, f, k));
-    if (n_rps != f[0]->n_vars) return ZK_ERR_VERIFY_ROUNDS;              // verifier.rs:17-19
-    ZKCHK(check_lens(n_rps, lens));
-    Sponge sp;
-    sp.init();
-    ZKCHK(absorb_tables(c, sp, (zk_mle *const *)f, k));                  // :22
-    std::vector<uint64_t> ch(4 * (n_rps + 1));
-    Fe claimed;
-    ZKCHK(verify_internal(c->fi->P, sp, n_rps, lens, sum, rps, claimed, ch.data()));
-    uint64_t ev[4];
-    ZKCHK(zk_product_evaluate(c, f, k, ch.data(), n_rps, ev));           // :27-29
-    *out_ok = fe_eq(fe_from_u64limbs(ev), claimed) ? 1 : 0;              // :31
-    return ZK_OK;
+    if (n_rps && !lens) return ZK_ERR_BAD_ARG;
+    static const uint32_t none = 0;
+    return verify_common(c, f, k, n_rps, lens ? lens : &none, 0, sum, rps, out_ok);
 }
 extern "C" int32_t zk_sumcheck_verify(zk_ctx *c, const zk_mle *const *f, uint64_t k, uint64_t n_rps, uint32_t D,
                                       const uint64_t sum[4], const uint64_t *rps, int32_t *out_ok) {
     if (D >= kMaxSums) return ZK_ERR_BAD_ARG;
-    const std::vector<uint32_t> lens(n_rps + 1, D + 1);
-    return zk_sumcheck_verify_lengths(c, f, k, n_rps, lens.data(), sum, rps, out_ok);
+    return verify_common(c, f, k, n_rps, nullptr, D + 1, sum, rps, out_ok);
 }
 
 // ------------------------------------------------------------------------------------------------------------

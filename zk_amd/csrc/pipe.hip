@@ -36,14 +36,13 @@ uint32_t pipe_work_blocks(int k, uint32_t D, int extra, uint64_t q) {
     return (uint32_t)(g ? g : 1);
 }
 
-// ZK_PIPE_SC1_HANDOFF=1: the fence-free partial hand-off of k_round_pipe (experimental, off by default)
-static int sc1_handoff() {
-    static const int v = [] {
-        const char *e = getenv("ZK_PIPE_SC1_HANDOFF");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
-}
+// The fence-free partial hand-off of k_round_pipe (measured -1.2 % GKR / 0 % prover) is an A/B BUILD option
+// only (make CXXFLAGS+=-DZK_PIPE_SC1_HANDOFF=1): relaxed write-through stores + a relaxed counter carry no release / acquire
+// edge in the HIP memory model, so the shipped library has no run-time switch that could select it.
+#ifndef ZK_PIPE_SC1_HANDOFF
+#define ZK_PIPE_SC1_HANDOFF 0
+#endif
+static constexpr int sc1_handoff() { return ZK_PIPE_SC1_HANDOFF; }
 template <int K, int D, int EXTRA>
 static void launch_shape(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t g) {
     constexpr int kThreads = pipe_block_threads<K, D, EXTRA>();

@@ -289,7 +289,7 @@ ZK_D Fe fe_from_canonical29(const Fe &c, const FieldParams &P) {
 }
 
 // Write-through / L1-bypassing element accesses (global_store / global_load ... sc1 = relaxed agent-scope atomics, 8 bytes each):
-// the EXPERIMENTAL fence-free hand-off of the block partials (ZK_PIPE_SC1_HANDOFF=1; see k_round_pipe)
+// the EXPERIMENTAL fence-free hand-off of the block partials (A/B builds with -DZK_PIPE_SC1_HANDOFF=1 only; see k_round_pipe)
 ZK_D void fe_store_sc1(uint64_t *base, uint64_t idx, const Fe &r) {
     unsigned long long *q = reinterpret_cast<unsigned long long *>(base + 4 * idx);
 #pragma unroll
@@ -507,7 +507,7 @@ __global__ __launch_bounds__((pipe_block_threads<K, D, EXTRA>())) void k_round_p
     if (threadIdx.x < 64) dbg_stamp(wdbg, 3);
     // The block that finishes last adds the partials up (slot 0), so the NEXT launch's transcript block -- the critical path --
     // reads NE values instead of reducing nwork * NE.  Release / acquire at agent scope: the other blocks may sit on other XCDs.
-    // EXPERIMENTAL (ZK_PIPE_SC1_HANDOFF=1, off by default): the same hand-off without the two fences -- write-through (sc1)
+    // EXPERIMENTAL (A/B builds with -DZK_PIPE_SC1_HANDOFF=1 only; the shipped library always passes 0): the same hand-off without the two fences -- write-through (sc1)
     // partial stores, the storing wave's s_waitcnt vmcnt(0), ONE lane's agent-scope counter add, and sc1 loads in the block whose
     // add came last (MI355X_MICROARCH.md "Valid forms": measured valid on gfx950 / ROCm 7.2, not an architectural guarantee).
     __shared__ uint32_t is_last;
@@ -658,7 +658,10 @@ __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs f
     carve += sizeof(Fe) * 8;
     S.W = reinterpret_cast<PipeEvalLds *>(carve);          // (32-byte aligned so far: the multiplier records are read 16 bytes at a time)
     carve += (sizeof(PipeEvalLds) + 15) / 16 * 16;
-    S.r29 = reinterpret_cast<Mul29 *>(carve);              // 48-byte slots
+    // two Mul29 records each (indexed by round parity: sizeof(Mul29) = 36 bytes apart, NOT 16-byte aligned -- they are read one
+    // 32-bit limb at a time); 96 bytes are reserved per pair, 4 * 48 in kFinMiscBytes
+    static_assert(2 * sizeof(Mul29) <= 2 * 48, "the r29 / rc29 pairs overlap");
+    S.r29 = reinterpret_cast<Mul29 *>(carve);
     S.rc29 = reinterpret_cast<Mul29 *>(carve + 2 * 48);
     if (wave0) pipe_eval_consts(*S.W, pc, lane);
 

@@ -334,13 +334,19 @@ inline std::vector<Fe<F>> fft_internal(const std::vector<Fe<F>> &values, const F
     if (rc != ZK_OK) throw std::runtime_error(zk_strerror(rc));
     return out;
 }
+// polynomial/src/multilinear/pairing_index.rs:24-26: a bit sequence of n ones (mask(1) -> 1, mask(3) -> 0b111).  The reference
+// overflows (panics in debug builds) at n >= usize::BITS; here that is the index panic status.
+inline size_t mask(uint8_t n) {
+    if (n >= sizeof(size_t) * 8) throw std::runtime_error(zk_strerror(ZK_ERR_PANIC_INDEX));
+    return ((size_t)1 << n) - 1;
+}
 // polynomial/src/multilinear/pairing_index.rs:2-9 (host index arithmetic; the kernels compute the same indices inline)
 inline std::vector<std::pair<size_t, size_t>> index_pair(uint8_t n_vars, uint8_t index) {
     if (n_vars == 0 || index > n_vars - 1) throw std::runtime_error(zk_strerror(ZK_ERR_PANIC_INDEX));
     const unsigned pos = n_vars - 1 - index;
     std::vector<std::pair<size_t, size_t>> out;
     for (size_t j = 0; j < ((size_t)1 << (n_vars - 1)); ++j) {
-        const size_t left = ((j >> pos) << (pos + 1)) | (j & (((size_t)1 << pos) - 1));
+        const size_t left = ((j >> pos) << (pos + 1)) | (j & mask((uint8_t)pos));
         out.emplace_back(left, left | ((size_t)1 << pos));
     }
     return out;
