@@ -233,7 +233,7 @@ def test_index_pair_formula_matches_the_reference_kats():
     assert index_pair(1, 0) == [(0, 1)]
     src = re.sub(r"\s+", " ", open(SHIM).read())
     assert "let pos = n_vars - 1 - index;" in src
-    assert "let left = ((j >> pos) << (pos + 1)) | (j & ((1usize << pos) - 1));" in src
+    assert "let left = ((j >> pos) << (pos + 1)) | (j & mask(pos));" in src   # mask(pos) = (1 << pos) - 1
     assert "(left, left | (1usize << pos))" in src
 
 

@@ -78,14 +78,14 @@ def fe_to_ints(field, arr):
 def mask(n):  # polynomial/src/multilinear/pairing_index.rs:24-26
     """a bit sequence of n ones: mask(1) -> 1, mask(3) -> 0b111"""
     if not 0 <= n < 64:
-        raise ZkError(-5)   # the reference's usize shift overflows here
+        raise ZkError(-5, lib.zk_strerror(-5).decode())   # the reference's usize shift overflows here
     return (1 << n) - 1
 
 
 def index_pair(n_vars, index):  # polynomial/src/multilinear/pairing_index.rs:2-9
     """the (left, right) table indices that partial_evaluate pairs up when it assigns variable `index` (variable 0 = index MSB)"""
     if n_vars < 1 or not 0 <= index < n_vars:
-        raise ZkError(-5)   # u8 underflow in the reference
+        raise ZkError(-5, lib.zk_strerror(-5).decode())   # u8 underflow in the reference
     pos = n_vars - 1 - index
     out = []
     for j in range(1 << (n_vars - 1)):
