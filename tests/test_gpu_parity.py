@@ -517,6 +517,69 @@ def test_evaluate_fold_path_still_exact():
     assert r.returncode == 0 and "evaluate ok" in r.stdout, r.stdout + r.stderr
 
 
+_EVAL_STREAM_CHILD = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import zk_amd
+from oracle import binding as orc
+checked = 0
+for field in (zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR):
+    c = zk_amd.Context(field, 0)
+    p = zk_amd.modulus(field)
+    for n in (19, 20, 21, 22):          # ZK_EVAL_STREAM_MIN=19: k_eval_stream with L = 10, 11, 12, 13
+        if n > 20 and field != zk_amd.BN254_FR:
+            continue
+        tab = orc.fill_random(field, 4500 + n, 1 << n)
+        t = zk_amd.MultiLinearPolynomial.new(c, n, tab)
+        pts = [orc.fill_random(field, 4600 + n, n)]
+        edge = [0, 1, p - 1, 2]
+        pts.append(orc.from_ints(field, [edge[(i * 7 + n) %% 4] for i in range(n)]))
+        for pt in pts:
+            assert np.array_equal(t.evaluate(pt), orc.mle_evaluate(field, n, tab, pt)), (field, n)
+            checked += 1
+        t.free()
+    # worst case of the column sums: every element p - 1 (all limbs of the halves near their maxima) at a point of p - 1's
+    n = 19
+    tab = orc.from_ints(field, [p - 1] * (1 << n))
+    pt = orc.from_ints(field, [p - 1 - i for i in range(n)])
+    t = zk_amd.MultiLinearPolynomial.new(c, n, tab)
+    assert np.array_equal(t.evaluate(pt), orc.mle_evaluate(field, n, tab, pt)), (field, "max")
+    t.free()
+    checked += 1
+print("evaluate stream ok", checked)
+"""
+
+
+def test_evaluate_streaming_kernel_forced_at_small_sizes():
+    """k_eval_stream (eval_kernels.cuh: half an element per lane, carry-free 29-bit column sums, up to 15 low variables per
+    launch) normally starts at 21 variables; a child process with ZK_EVAL_STREAM_MIN=19 puts n = 19..22 (L = 10..13) through it on
+    all three fields, random and edge points plus the all-(p - 1) table, bit-exact vs the oracle (evaluation_form.rs:83-89)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _EVAL_STREAM_CHILD % root], env=dict(os.environ, ZK_EVAL_STREAM_MIN="19"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "evaluate stream ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_evaluate_n24_vs_oracle():
+    """The reference's own benchmark operation at the metric's table size: evaluate on 2^24 BN254-Fr elements (k_eval_stream with
+    L = 15, then one k_eval_low workgroup) against the oracle's n folds, at a random point and at a point with 0 / 1 / p - 1
+    coordinates (the r = 0 / r = 1 shortcuts of evaluation_form.rs:61-62)."""
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    n = 24
+    p = zk_amd.modulus(field)
+    tab = orc.fill_random(field, 0x5EED0000 + 24, 1 << n)
+    t = MLE.new(c, n, tab)
+    edge = [0, 1, p - 1, 2]
+    for pt in (orc.fill_random(field, 4724, n), F(field, [edge[(i * 5 + 1) % 4] for i in range(n)])):
+        assert np.array_equal(t.evaluate(pt), orc.mle_evaluate(field, n, tab, pt))
+    t.free()
+
+
 def test_skip1_rounds_bit_exact():
     """Big fused rounds leave out the t = 1 sums and derive S(1) from the previous round's claim (k_round_kd SKIP1,
     TailDerive).  A child process with the threshold forced to 1 pair proves the (k, D) grid that way and compares every

@@ -20,6 +20,7 @@
 #include "../../include/zk_amd.h"
 #include "host_field.hpp"
 #include "kernels.cuh"
+#include "eval_kernels.cuh"
 #include "gkr_kernels.cuh"
 #include "launch.hpp"
 #include "ntt_kernels.cuh"
@@ -602,10 +603,18 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
     const uint64_t *src = t->d;
     uint64_t cur = n;   // variables left
     static const bool bulk_low = getenv("ZK_EVAL_FOLDS") == nullptr;   // ZK_EVAL_FOLDS=1: the variable-by-variable path (A/B, tests)
+    // tables of at least this many variables take the streaming kernel (k_eval_stream: up to 15 variables per launch, half an
+    // element per lane, carry-free column sums); smaller ones are launch latency and keep k_eval_low.  ZK_EVAL_STREAM_MIN overrides.
+    static const uint64_t stream_min = [] {
+        const char *e = getenv("ZK_EVAL_STREAM_MIN");
+        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)21;
+    }();
     for (int pass = 0; bulk_low && cur >= 8 && rc == ZK_OK; ++pass) {
+        const bool stream = cur >= stream_min && cur >= (uint64_t)kEvalStreamMin + 9;   // leaves >= 9 variables: >= 512 workgroups
         uint64_t L = cur <= (uint64_t)kEvalLowMax ? cur : cur - 8;
         if (L > (uint64_t)kEvalLowMax) L = kEvalLowMax;
         if (L < (uint64_t)kEvalLowMin) L = kEvalLowMin;   // cur >= 13 here
+        if (stream) L = cur - 9 < (uint64_t)kEvalStreamMax ? cur - 9 : (uint64_t)kEvalStreamMax;
         const uint64_t n_out = 1ull << (cur - L);
         uint64_t *dst = d_out_elem;
         if (L != cur) {
@@ -621,6 +630,21 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
                 }
             }
             dst = scratch[b];
+        }
+        if (stream) {
+            EvalStreamPoint sp = {};
+            for (uint64_t p = 0; p < L; ++p) {
+                const Fe r = fe_from_u64limbs(point + 4 * (cur - 1 - p));   // index bit p <-> variable cur-1-p (variable 0 is the MSB)
+                for (int i = 0; i < 8; ++i) sp.r[p][i] = r.v[i];
+            }
+            const Fe two128 = {{0, 0, 0, 0, 1, 0, 0, 0}};
+            const Fe c128 = fe_from_canonical(two128, P);
+            for (int i = 0; i < 8; ++i) sp.c128[i] = c128.v[i];
+            k_eval_stream<<<(uint32_t)n_out, kBlock, 0, c->stream>>>(src, dst, (uint32_t)L, sp, P);
+            if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+            src = dst;
+            cur -= L;
+            continue;
         }
         EvalLowPoint pt = {};
         for (uint64_t p = 0; p < L; ++p) {
