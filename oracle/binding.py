@@ -406,3 +406,67 @@ def dft_point(field, values, k, inverse=False):
     fn.argtypes = [_c.c_int, _u64p, _c.c_uint64, _c.c_uint64, _c.c_int, _u64p]
     _check(fn(field, _p(v), v.shape[0], int(k), int(bool(inverse)), _p(out)))
     return out
+
+
+# ---------------- checker pieces for the GKR-shaped driver (no reference crate: DESIGN.md section 10, oracle/gkr_ref.py) ----------------
+def sumcheck_verify_partial_lengths_on(tr, field, claimed_sum, round_polys):
+    """verify_internal's own signature (verifier.rs:44-48): the rounds on a Transcript the caller holds and keeps"""
+    lens, flat = _ragged(round_polys)
+    n = len(lens)
+    s = _arr(claimed_sum, 1)
+    sub_ = np.zeros(4, dtype=np.uint64)
+    ch = np.zeros((max(n, 1), 4), dtype=np.uint64)
+    fn = _lib.orc_sumcheck_verify_partial_lengths_on
+    fn.argtypes = [_c.c_void_p, _c.c_int, _c.c_uint64, _c.c_void_p, _u64p, _u64p, _u64p, _u64p]
+    lens_buf = np.ascontiguousarray(np.append(lens, np.uint32(0)))
+    _check(fn(tr._t, field, n, lens_buf.ctypes.data, _p(s), _p(flat), _p(sub_), _p(ch)))
+    return sub_, ch[:n]
+
+
+def circuit_layer(field, op, left, right, w):
+    """one layer of a fan-in-2 circuit over the values w: add (op 0) / mul (op 1) gates"""
+    op = np.ascontiguousarray(op, dtype=np.uint8)
+    left = np.ascontiguousarray(left, dtype=np.uint32)
+    right = np.ascontiguousarray(right, dtype=np.uint32)
+    w = _arr(w).reshape(-1, 4)
+    assert left.max(initial=0) < w.shape[0] and right.max(initial=0) < w.shape[0]
+    out = np.zeros((op.shape[0], 4), dtype=np.uint64)
+    fn = _lib.orc_circuit_layer
+    fn.argtypes = [_c.c_int, _c.c_uint64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _u64p, _u64p]
+    _check(fn(field, op.shape[0], op.ctypes.data, left.ctypes.data, right.ctypes.data, _p(w), _p(out)))
+    return out
+
+
+def tree_digest(data) -> bytes:
+    """the driver's statement digest: Keccak-256 over 128-byte leaves, then 4-ary nodes (gkr_ref.tree_digest)"""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    out = _c.create_string_buffer(32)
+    fn = _lib.orc_tree_digest
+    fn.argtypes = [_c.c_void_p, _c.c_size_t, _c.c_char_p]
+    keep = np.ascontiguousarray(buf) if buf.size else np.zeros(1, dtype=np.uint8)
+    _check(fn(keep.ctypes.data, buf.size, out))
+    return out.raw
+
+
+def eq_table(field, point):
+    pt = _arr(point).reshape(-1, 4)
+    out = np.zeros((1 << pt.shape[0], 4), dtype=np.uint64)
+    fn = _lib.orc_eq_table
+    fn.argtypes = [_c.c_int, _u64p, _c.c_uint64, _u64p]
+    _check(fn(field, _p(pt if pt.size else np.zeros((1, 4), dtype=np.uint64)), pt.shape[0], _p(out)))
+    return out
+
+
+def gkr_wiring_sums(field, op, left, right, e1, e2, alpha, beta, eq_u, eq_v):
+    """(add_e, mul_e) = sums over the add / mul gates of (alpha e1 + beta e2)[z] eq_u[left[z]] eq_v[right[z]]; e2 may be None"""
+    op = np.ascontiguousarray(op, dtype=np.uint8)
+    left = np.ascontiguousarray(left, dtype=np.uint32)
+    right = np.ascontiguousarray(right, dtype=np.uint32)
+    e1, eq_u, eq_v = _arr(e1), _arr(eq_u), _arr(eq_v)
+    e2 = _arr(e2) if e2 is not None else None
+    a, m = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    fn = _lib.orc_gkr_wiring_sums
+    fn.argtypes = [_c.c_int, _c.c_uint64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _u64p, _c.c_void_p, _u64p, _u64p, _u64p, _u64p, _u64p, _u64p]
+    _check(fn(field, op.shape[0], op.ctypes.data, left.ctypes.data, right.ctypes.data, _p(e1), e2.ctypes.data if e2 is not None else None,
+              _p(_arr(alpha, 1)), _p(_arr(beta, 1)), _p(eq_u), _p(eq_v), _p(a), _p(m)))
+    return a, m

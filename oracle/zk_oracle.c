@@ -734,15 +734,16 @@ static void uni_evaluate(const fparams *F, const u64 *coef, unsigned n, const u6
 /* verify_internal with each round polynomial at ITS OWN length (proof.round_polys is a Vec<Vec<F>>; :55-58 interpolates
  * whatever length the round carries: 0 evaluations -> the zero polynomial, 1 -> a constant).  round_polys = the rounds'
  * evaluations back to back. */
-int orc_sumcheck_verify_partial_lengths(int field, u64 n_rounds, const uint32_t *lens, const u64 sum[4],
-                                        const u64 *round_polys, const uint8_t *table_bytes, size_t table_bytes_len,
-                                        u64 subclaim_sum[4], u64 *challenges_out) {  /* :44-78 */
+/* verify_internal itself takes `transcript: &mut Transcript` (verifier.rs:44-48): this is that signature -- the rounds are
+ * checked on a transcript the caller already holds (verify absorbs the table first, :22; a driver that chains several
+ * sumchecks on ONE transcript keeps passing the same one) */
+int orc_sumcheck_verify_partial_lengths_on(orc_transcript *tr, int field, u64 n_rounds, const uint32_t *lens, const u64 sum[4],
+                                           const u64 *round_polys, u64 subclaim_sum[4], u64 *challenges_out) {  /* :44-78 */
     const fparams *F = field_get(field);
     if (!F) return ORC_ERR_BAD_FIELD;
+    if (!tr) return ORC_ERR_ALLOC;
     for (u64 r = 0; r < n_rounds; ++r)
         if (lens[r] > ORC_MAX_DEG) return ORC_ERR_ALLOC;
-    orc_transcript *tr = orc_transcript_new();
-    if (table_bytes) orc_transcript_append(tr, table_bytes, table_bytes_len);        /* :22 */
     append_elems(tr, field, sum, 1);                                                 /* :50 */
     u64 claimed[4], zero[4] = {0, 0, 0, 0};
     memcpy(claimed, sum, 32);
@@ -767,8 +768,18 @@ int orc_sumcheck_verify_partial_lengths(int field, u64 n_rounds, const uint32_t 
         rp += (size_t)len * 4;
     }
     free(coef);
-    orc_transcript_free(tr);
     if (rc == ORC_OK) memcpy(subclaim_sum, claimed, 32);
+    return rc;
+}
+int orc_sumcheck_verify_partial_lengths(int field, u64 n_rounds, const uint32_t *lens, const u64 sum[4],
+                                        const u64 *round_polys, const uint8_t *table_bytes, size_t table_bytes_len,
+                                        u64 subclaim_sum[4], u64 *challenges_out) {  /* :38-41 / :15-23: a fresh transcript */
+    if (!field_get(field)) return ORC_ERR_BAD_FIELD;
+    orc_transcript *tr = orc_transcript_new();
+    if (!tr) return ORC_ERR_ALLOC;
+    if (table_bytes) orc_transcript_append(tr, table_bytes, table_bytes_len);        /* :22 */
+    const int rc = orc_sumcheck_verify_partial_lengths_on(tr, field, n_rounds, lens, sum, round_polys, subclaim_sum, challenges_out);
+    orc_transcript_free(tr);
     return rc;
 }
 int orc_sumcheck_verify_partial(int field, u64 n_rounds, unsigned D, const u64 sum[4],
@@ -955,5 +966,112 @@ int orc_dft_point(int field, const u64 *in, u64 n, u64 k, int inverse, u64 out[4
         f_mul(F, acc, ninv, acc);
     }
     memcpy(out, acc, 32);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Checker pieces for the GKR-shaped driver.  The reference has NO gkr crate: the circuit format, the statement
+ * digest and the wiring check are this repository's own definitions (oracle/gkr_ref.py is the big-int
+ * model of the same protocol); what follows restates those definitions in C so that a width-2^20 proof can be checked on the
+ * CPU in seconds, from the reference's primitives (field ops, MLE variable order evaluation_form.rs:40-80, Keccak-256).
+ * ---------------------------------------------------------------------------------------- */
+/* one layer of a fan-in-2 circuit: out[z] = op[z] ? w[left[z]] * w[right[z]] : w[left[z]] + w[right[z]] */
+int orc_circuit_layer(int field, u64 n_gates, const uint8_t *op, const uint32_t *left, const uint32_t *right, const u64 *w, u64 *out) {
+    const fparams *F = field_get(field);
+    if (!F) return ORC_ERR_BAD_FIELD;
+#pragma omp parallel for schedule(static)
+    for (u64 z = 0; z < n_gates; ++z) {
+        if (op[z]) f_mul(F, w + 4 * (u64)left[z], w + 4 * (u64)right[z], out + 4 * z);
+        else f_add(F, w + 4 * (u64)left[z], w + 4 * (u64)right[z], out + 4 * z);
+    }
+    return ORC_OK;
+}
+/* the driver's statement digest (gkr_ref.tree_digest): Keccak-256 over 128-byte leaves (the last may be shorter; no data = one
+ * empty leaf), then 4-ary nodes Keccak256(child digests concatenated) until one digest is left */
+int orc_tree_digest(const uint8_t *data, size_t len, uint8_t out[32]) {
+    size_t n = len ? (len + 127) / 128 : 1;
+    uint8_t *cur = (uint8_t *)malloc(n * 32);
+    if (!cur) return ORC_ERR_ALLOC;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) {
+        const size_t off = i * 128, l = len > off ? (len - off < 128 ? len - off : 128) : 0;
+        orc_keccak256(data + (l ? off : 0), l, cur + 32 * i);
+    }
+    while (n > 1) {
+        const size_t m = (n + 3) / 4;
+        uint8_t *nxt = (uint8_t *)malloc(m * 32);
+        if (!nxt) {
+            free(cur);
+            return ORC_ERR_ALLOC;
+        }
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < m; ++i) {
+            const size_t c = n - 4 * i < 4 ? n - 4 * i : 4;
+            orc_keccak256(cur + 128 * i, 32 * c, nxt + 32 * i);
+        }
+        free(cur);
+        cur = nxt;
+        n = m;
+    }
+    memcpy(out, cur, 32);
+    free(cur);
+    return ORC_OK;
+}
+/* eq(point, .) as a table, variable 0 = index MSB: out[idx] = prod_v (bit_v(idx) ? point[v] : 1 - point[v]) */
+int orc_eq_table(int field, const u64 *point, u64 n_vars, u64 *out) {
+    const fparams *F = field_get(field);
+    if (!F) return ORC_ERR_BAD_FIELD;
+    memcpy(out, F->r1, 32);
+    for (u64 v = 0; v < n_vars; ++v) {   /* after v variables: 2^v entries; variable v becomes the new LEAST significant bit */
+        const u64 cnt = 1ULL << v;
+        u64 om[4];
+        f_sub(F, F->r1, point + 4 * v, om);
+        for (u64 i = cnt; i-- > 0;) {
+            u64 e[4];
+            memcpy(e, out + 4 * i, 32);
+            f_mul(F, e, om, out + 4 * (2 * i));
+            f_mul(F, e, point + 4 * v, out + 4 * (2 * i + 1));
+        }
+    }
+    return ORC_OK;
+}
+/* the verifier's wiring predicates of one layer (gkr_ref.gkr_verify): with E = alpha * e1 + beta * e2 (e2 may be NULL),
+ * add_e = sum over add gates of E[z] eq_u[left[z]] eq_v[right[z]], mul_e likewise over the mul gates */
+int orc_gkr_wiring_sums(int field, u64 n_gates, const uint8_t *op, const uint32_t *left, const uint32_t *right, const u64 *e1,
+                        const u64 *e2, const u64 alpha[4], const u64 beta[4], const u64 *eq_u, const u64 *eq_v, u64 out_add[4],
+                        u64 out_mul[4]) {
+    const fparams *F = field_get(field);
+    if (!F) return ORC_ERR_BAD_FIELD;
+    const int nt = omp_get_max_threads();
+    u64 *part = (u64 *)calloc((size_t)nt * 8, 8);
+    if (!part) return ORC_ERR_ALLOC;
+#pragma omp parallel
+    {
+        u64 a[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0};
+#pragma omp for schedule(static)
+        for (u64 z = 0; z < n_gates; ++z) {
+            u64 E[4], t[4];
+            f_mul(F, alpha, e1 + 4 * z, E);
+            if (e2) {
+                f_mul(F, beta, e2 + 4 * z, t);
+                f_add(F, E, t, E);
+            }
+            f_mul(F, E, eq_u + 4 * (u64)left[z], t);
+            f_mul(F, t, eq_v + 4 * (u64)right[z], t);
+            if (op[z]) f_add(F, m, t, m);
+            else f_add(F, a, t, a);
+        }
+        const int id = omp_get_thread_num();
+        memcpy(part + 8 * id, a, 32);
+        memcpy(part + 8 * id + 4, m, 32);
+    }
+    u64 a[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0};
+    for (int i = 0; i < nt; ++i) {
+        f_add(F, a, part + 8 * i, a);
+        f_add(F, m, part + 8 * i + 4, m);
+    }
+    free(part);
+    memcpy(out_add, a, 32);
+    memcpy(out_mul, m, 32);
     return ORC_OK;
 }

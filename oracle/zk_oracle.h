@@ -128,6 +128,11 @@ int orc_sumcheck_verify_partial(int field, uint64_t n_rounds, unsigned max_var_d
 int orc_sumcheck_verify_partial_lengths(int field, uint64_t n_rounds, const uint32_t *lens, const uint64_t sum[4],
                                         const uint64_t *round_polys, const uint8_t *table_bytes, size_t table_bytes_len,
                                         uint64_t subclaim_sum[4], uint64_t *challenges_out);
+/* verify_internal's own signature (verifier.rs:44-48 takes `transcript: &mut Transcript`): the same rounds on a transcript the
+ * caller holds and keeps */
+int orc_sumcheck_verify_partial_lengths_on(orc_transcript *tr, int field, uint64_t n_rounds, const uint32_t *lens,
+                                           const uint64_t sum[4], const uint64_t *round_polys, uint64_t subclaim_sum[4],
+                                           uint64_t *challenges_out);
 int orc_sumcheck_verify_lengths(int field, uint64_t k, uint64_t n_vars, const uint64_t *const *tables,
                                 uint64_t n_round_polys, const uint32_t *lens, const uint64_t sum[4],
                                 const uint64_t *round_polys);
@@ -146,6 +151,17 @@ int orc_ntt_fast(int field, const uint64_t *in, uint64_t n, int inverse, uint64_
 /* ONE output of fft (inverse = 0) / ifft (inverse != 0) straight from the definition out[k] = sum_j in[j] * omega^(j*k)
  * (fft/src/lib.rs:39-45): pins single outputs of transforms too large for the recursion */
 int orc_dft_point(int field, const uint64_t *in, uint64_t n, uint64_t k, int inverse, uint64_t out[4]);
+
+/* ---- checker pieces for the GKR-shaped driver (NO reference crate; definitions: DESIGN.md section 10 and
+ * oracle/gkr_ref.py).  C forms of the model's circuit evaluation, statement digest, eq table and wiring predicates, so that a
+ * width-2^20 proof can be checked on the CPU in seconds with nothing from the library under test. ---- */
+int orc_circuit_layer(int field, uint64_t n_gates, const uint8_t *op, const uint32_t *left, const uint32_t *right,
+                      const uint64_t *w, uint64_t *out);
+int orc_tree_digest(const uint8_t *data, size_t len, uint8_t out[32]);
+int orc_eq_table(int field, const uint64_t *point, uint64_t n_vars, uint64_t *out);
+int orc_gkr_wiring_sums(int field, uint64_t n_gates, const uint8_t *op, const uint32_t *left, const uint32_t *right,
+                        const uint64_t *e1, const uint64_t *e2, const uint64_t alpha[4], const uint64_t beta[4],
+                        const uint64_t *eq_u, const uint64_t *eq_v, uint64_t out_add[4], uint64_t out_mul[4]);
 
 #ifdef __cplusplus
 }

@@ -143,3 +143,100 @@ def test_tree_digest_shape():
     leaves = [k(d[i:i + 128]) for i in range(0, 768, 128)]
     assert gkr_ref.tree_digest(d) == k(k(b"".join(leaves[:4])) + k(b"".join(leaves[4:])))
     assert gkr_ref.tree_digest(d[:129]) == k(k(d[:128]) + k(d[128:129]))
+
+
+# ---- the oracle-primitives-only checker (tests/gkr_oracle_check.py) against the big-int model -------------------------------
+def _np_layers(layers):
+    import numpy as np
+
+    return [(lo, li, np.array(op, dtype=np.uint8), np.array(left, dtype=np.uint32), np.array(right, dtype=np.uint32))
+            for lo, li, op, left, right in layers]
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_oracle_gkr_pieces_match_the_model(field):
+    """orc.tree_digest / eq_table / circuit_layer / gkr_wiring_sums / sumcheck_verify_partial_lengths_on are the C forms of
+    gkr_ref's tree_digest / eq_table / evaluate_circuit / wiring sums / _verify_partial_from: same values on small inputs."""
+    import numpy as np
+
+    from oracle import binding as orc
+    from tests.gkr_oracle_check import circuit_digest
+
+    p = pyref.modulus(field)
+    rng = random.Random(100 + field)
+    for ln in (0, 1, 31, 128, 129, 512, 513, 4096, 5000):
+        data = bytes(rng.randrange(256) for _ in range(ln))
+        assert orc.tree_digest(data) == gkr_ref.tree_digest(data), ln
+    pt = [rng.randrange(p) for _ in range(5)]
+    assert orc.to_ints(field, orc.eq_table(field, orc.from_ints(field, pt))) == gkr_ref.eq_table(field, pt)
+    layers = rand_circuit(rng, [2, 4, 3])
+    ins = [rng.randrange(p) for _ in range(8)]
+    vals = gkr_ref.evaluate_circuit(field, layers, ins)
+    w = orc.from_ints(field, ins)
+    for i in (1, 0):
+        _, _, op, left, right = layers[i]
+        w = orc.circuit_layer(field, op, left, right, w)
+        assert orc.to_ints(field, w) == vals[i]
+    assert circuit_digest(_np_layers(layers)) == gkr_ref.circuit_digest(layers)
+    # wiring sums of layer 0 at random points, with a two-point E
+    lo, li, op, left, right = layers[0]
+    g1, g2 = [rng.randrange(p) for _ in range(lo)], [rng.randrange(p) for _ in range(lo)]
+    u, v = [rng.randrange(p) for _ in range(li)], [rng.randrange(p) for _ in range(li)]
+    al, be = rng.randrange(p), rng.randrange(p)
+    E = gkr_ref._E(field, {"g1": g1, "g2": g2, "alpha": al, "beta": be}, lo)
+    equ, eqv = gkr_ref.eq_table(field, u), gkr_ref.eq_table(field, v)
+    want_add = sum(E[z] * equ[x] * eqv[y] for z, (o, x, y) in enumerate(zip(op, left, right)) if o == 0) % p
+    want_mul = sum(E[z] * equ[x] * eqv[y] for z, (o, x, y) in enumerate(zip(op, left, right)) if o == 1) % p
+    F = lambda xs: orc.from_ints(field, xs)
+    a, m = orc.gkr_wiring_sums(field, op, left, right, orc.eq_table(field, F(g1)), orc.eq_table(field, F(g2)), orc.from_int(field, al),
+                               orc.from_int(field, be), orc.eq_table(field, F(u)), orc.eq_table(field, F(v)))
+    assert orc.to_int(field, a) == want_add and orc.to_int(field, m) == want_mul
+    # verify_internal on a transcript that already holds bytes == the model's continuation
+    tabs = [[rng.randrange(p) for _ in range(8)] for _ in range(2)]
+    s = sum(x * y for x, y in zip(*tabs)) % p
+    tr_m = pyref.Transcript()
+    tr_m.append(b"prefix")
+    rp, ch, _ = gkr_ref.prove_partial_terms(field, [tabs], 2, s, tr_m)
+    tr_v = pyref.Transcript()
+    tr_v.append(b"prefix")
+    want_sub, want_ch = gkr_ref._verify_partial_from(tr_v, field, s, rp)
+    tr_o = orc.Transcript()
+    tr_o.append(b"prefix")
+    sub, chs = orc.sumcheck_verify_partial_lengths_on(tr_o, field, orc.from_int(field, s), [F(r) for r in rp])
+    assert orc.to_int(field, sub) == want_sub and orc.to_ints(field, chs) == want_ch == ch
+    assert orc.to_int(field, tr_o.sample_field_element(field)) == tr_v.sample_field_element(field)   # same state afterwards
+
+
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("logs", [[1, 3, 2], [3, 3, 3, 3], [0, 2, 4], [4, 1, 3]])
+def test_oracle_checker_accepts_model_proofs_and_rejects_corruptions(field, logs):
+    """The checker that validates the depth-8 x 2^20 GPU proof (tests/test_gpu_gkr.py) is itself checked here: it accepts the
+    big-int model's proofs and rejects every single-element corruption of proof, outputs or inputs."""
+    import numpy as np
+
+    from oracle import binding as orc
+    from tests.gkr_oracle_check import check_proof
+
+    p = pyref.modulus(field)
+    rng = random.Random(sum(logs) + 31 * field)
+    layers = rand_circuit(rng, logs)
+    ins = [rng.randrange(p) for _ in range(1 << logs[-1])]
+    seed = bytes(rng.randrange(256) for _ in range(32))
+    outs, proof = gkr_ref.gkr_prove(field, layers, ins, seed)
+    assert gkr_ref.gkr_verify(field, layers, ins, outs, seed, proof)
+    L = _np_layers(layers)
+    F = lambda xs: orc.from_ints(field, xs)
+    ok, why = check_proof(field, L, F(ins), F(outs), seed, F(proof))
+    assert ok, why
+    for idx in range(len(proof)):
+        bad = list(proof)
+        bad[idx] = (bad[idx] + 1) % p
+        ok, _ = check_proof(field, L, F(ins), F(outs), seed, F(bad))
+        assert not ok, f"corrupted proof element {idx} accepted"
+    bad_out = list(outs)
+    bad_out[0] = (bad_out[0] + 1) % p
+    assert not check_proof(field, L, F(ins), F(bad_out), seed, F(proof))[0]
+    bad_in = list(ins)
+    bad_in[-1] = (bad_in[-1] + 1) % p
+    assert not check_proof(field, L, F(bad_in), F(outs), seed, F(proof))[0]
+    assert not check_proof(field, L, F(ins), F(outs), bytes(32), F(proof))[0] or seed == bytes(32)

@@ -318,3 +318,42 @@ def test_config4_gkr_depth8_width_2p20_prove_verify_tamper():
     assert not gkr.gkr_verify(circ, MLE.new(c, w, xs), out, seed, proof)
     assert not gkr.gkr_verify(circ, x, out, bytes(32), proof)   # another seed: another transcript
     circ.free()
+
+
+def test_config4_full_size_proof_checked_with_oracle_primitives_only():
+    """BASELINE config[3] at its own size, checked by something that is NOT the library: the depth-8 x 2^20 GPU proof goes through
+    tests/gkr_oracle_check.py -- every layer's values recomputed on the CPU (OpenMP), the output table compared, the statement
+    digests and the transcript replayed on orc.Transcript, the round checks made by verify_internal on that transcript
+    (sumcheck/src/verifier.rs:44-78), the wiring predicates summed over the gate lists on the CPU, and W(u), W(v) of EVERY layer
+    compared with orc.mle_evaluate of the CPU's own layer values at the replayed points (evaluation_form.rs:83-89, the intent at
+    :45-48).  The library's verifier shares k_eq_split / k_gkr_wiring_eval with its prover; this check shares nothing with either.
+    One flipped proof element must be rejected by it as well."""
+    import time
+
+    from tests.gkr_oracle_check import check_proof
+
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    rng = np.random.default_rng(0x6B73)
+    w = 20
+    circ = gkr.Circuit(c)
+    layers = []
+    for _ in range(8):
+        op = rng.integers(0, 2, 1 << w, dtype=np.uint8)
+        left = rng.integers(0, 1 << w, 1 << w, dtype=np.uint32)
+        right = rng.integers(0, 1 << w, 1 << w, dtype=np.uint32)
+        circ.add_layer(w, w, op, left, right)
+        layers.append((w, w, op, left, right))
+    x = MLE.random(c, w, 0x6B73, 0)
+    seed = bytes(range(1, 33))
+    out, proof = gkr.gkr_prove(circ, x, seed)
+    t0 = time.time()
+    ok, why = check_proof(field, layers, x.evaluation_slice(), out.evaluation_slice(), seed, proof)
+    dt = time.time() - t0
+    assert ok, why
+    bad = proof.copy()
+    bad.reshape(-1, 4)[bad.reshape(-1, 4).shape[0] // 3] = orc.add(field, bad.reshape(-1, 4)[bad.reshape(-1, 4).shape[0] // 3],
+                                                                  zk_amd.fe_from_int(field, 1))
+    assert not check_proof(field, layers, x.evaluation_slice(), out.evaluation_slice(), seed, bad)[0]
+    print(f"oracle-only check of the depth-8 x 2^20 proof: {dt:.1f} s")
+    circ.free()
