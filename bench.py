@@ -248,6 +248,20 @@ def sharded_leg(args, ctx, field, dist, torch, rank, world, ns, tdev, rehearse, 
     lw = world.bit_length() - 1
     n = ns + lw
     comm = HostComm(ctx) if rehearse else RcclComm(ctx)
+    # what the TRANSPORT says about itself (zk_comm_info: ncclGetVersion / ncclCommCount / ncclCommUserRank), gathered from every
+    # rank: a record with n_gpus = N must show N distinct RCCL ranks of an N-rank communicator, each on its own device
+    info = comm.info()
+    it = torch.tensor([info["rccl_version"], info["ranks"], info["rank"], ctx.device],
+                      dtype=torch.int64, device=tdev)
+    infos = [torch.empty_like(it) for _ in range(world)]
+    dist.all_gather(infos, it)
+    infos = [[int(v) for v in t.cpu()] for t in infos]
+    ex["comm_transport"] = "host callbacks (rehearsal)" if rehearse else "rccl"
+    ex["rccl_version"] = infos[0][0]
+    ex["comm_reported_ranks"] = sorted({r[1] for r in infos})
+    ex["comm_rank_ids"] = sorted(r[2] for r in infos)
+    ex["rank_devices"] = [r[3] for r in infos]
+    ex["comm_confirms_n_ranks"] = ex["comm_reported_ranks"] == [world] and ex["comm_rank_ids"] == list(range(world))
     seeds = (0x5EED0100, 0x5EED0200)
     shards = [zk_amd.MultiLinearPolynomial.random(ctx, ns, sd, first_index=rank << ns) for sd in seeds]
 

@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-#define ZK_AMD_ABI_VERSION 4   /* 3: + zk_comm (RCCL / host), zk_shard_prover_run, zk_ntt_sharded, sample_n, zk_ctx_trim, zk_mle_equal
-                                  4: + zk_sumcheck_verify_lengths / _verify_partial_lengths (per-round degrees, verifier.rs:55-58) */
+#define ZK_AMD_ABI_VERSION 5   /* 3: + zk_comm (RCCL / host), zk_shard_prover_run, zk_ntt_sharded, sample_n, zk_ctx_trim, zk_mle_equal
+                                  4: + zk_sumcheck_verify_lengths / _verify_partial_lengths (per-round degrees, verifier.rs:55-58)
+                                  5: + zk_comm_info */
 
 typedef enum zk_field {
     ZK_FIELD_BN254_FR = 0,     /* north-star field (not a dependency of the reference: SURVEY D2) */
@@ -214,6 +215,9 @@ int32_t zk_comm_wrap_rccl(zk_ctx *ctx, void *nccl_comm, uint32_t world, uint32_t
 int32_t zk_comm_create_host(zk_ctx *ctx, uint32_t world, uint32_t rank, zk_host_allreduce_fn allreduce,
                             zk_host_allgather_fn allgather, zk_host_alltoall_fn alltoall, void *user, zk_comm **out);
 int32_t zk_comm_destroy(zk_comm *comm);
+/* what the transport itself reports: RCCL's version (ncclGetVersion; 0 for the host transport) and the communicator's own rank
+ * count and rank (ncclCommCount / ncclCommUserRank).  Any out pointer may be NULL. */
+int32_t zk_comm_info(zk_comm *comm, int32_t *out_rccl_version, uint32_t *out_ranks, uint32_t *out_rank);
 /* The WHOLE sharded prover (prove_partial, sumcheck/src/prover.rs:24-30,44-68) on a freshly created zk_shard_prover:
  * per local round {round_begin -> all-reduce of the (D+1)*8 lanes -> round_finish} while more than `gather_below` local
  * variables remain, then tail_ptr -> all-gather -> tail_rounds.  With an RCCL comm everything is enqueued on the context's

@@ -1,0 +1,94 @@
+"""The C ABI's threading contract (include/zk_amd.h:18-19): a zk_ctx is not thread-safe, DISTINCT contexts are
+independent -- the reference's prover / verifier hold no global state (sumcheck/src/prover.rs:15-30 builds its Transcript per
+call).  Two host threads, one context each (ctypes releases the GIL around every library call, so the calls really overlap),
+loop the prover, evaluate and the NTT for a few seconds; every result must equal the oracle's, bit for bit.  Then two contexts
+share ONE caller-owned stream (zk_ctx_set_stream) and are interleaved call by call on one thread."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import zk_amd
+from oracle import binding as orc
+from zk_amd import MultiLinearPolynomial as MLE
+from zk_amd import ProductPoly, SumcheckProver
+
+pytestmark = pytest.mark.gpu
+
+
+def _workload(field, seed):
+    """inputs + oracle answers for one thread: n = 16 prover (k = 2, D = 2), n = 18 evaluate, 2^14-point NTT"""
+    n = 16
+    tabs = [orc.fill_random(field, seed + f, 1 << n) for f in range(2)]
+    claimed = np.zeros(4, dtype=np.uint64)
+    for e in orc.prod_reduce(field, n, tabs):
+        claimed = orc.add(field, claimed, e)
+    rp, ch = orc.sumcheck_prove(field, n, tabs, 2, claimed, False)
+    ev_tab = orc.fill_random(field, seed + 7, 1 << 18)
+    ev_pt = orc.fill_random(field, seed + 8, 18)
+    vec = orc.fill_random(field, seed + 9, 1 << 14)
+    return {"field": field, "n": n, "tabs": tabs, "claimed": claimed, "rp": rp, "ch": ch, "ev_tab": ev_tab, "ev_pt": ev_pt,
+            "ev": orc.mle_evaluate(field, 18, ev_tab, ev_pt), "vec": vec, "fft": orc.ntt_fast(field, vec)}
+
+
+def _one_pass(ctx, w, state):
+    """one prover + one evaluate + one NTT on ctx; tables are uploaded once per context and kept in `state`"""
+    if "polys" not in state:
+        state["polys"] = [MLE.new(ctx, w["n"], t) for t in w["tabs"]]
+        state["ev"] = MLE.new(ctx, 18, w["ev_tab"])
+    proof, ch = SumcheckProver(2).prove_partial(ProductPoly.new(state["polys"]), w["claimed"])
+    assert np.array_equal(proof.round_polys, w["rp"]) and np.array_equal(ch, w["ch"]), "prover"
+    assert np.array_equal(state["ev"].evaluate(w["ev_pt"]), w["ev"]), "evaluate"
+    assert np.array_equal(zk_amd.fft(ctx, w["vec"]), w["fft"]), "fft"
+
+
+def test_two_threads_one_context_each():
+    loads = [_workload(zk_amd.BN254_FR, 9100), _workload(zk_amd.BLS12_381_FR, 9200)]
+    errors, counts = [], [0, 0]
+    start = threading.Barrier(2)
+
+    def run(i):
+        try:
+            ctx = zk_amd.Context(loads[i]["field"], 0)
+            state = {}
+            _one_pass(ctx, loads[i], state)   # first call allocates: keep it out of the overlapped loop's timing
+            start.wait()
+            t_end = time.time() + 4.0
+            while time.time() < t_end:
+                _one_pass(ctx, loads[i], state)
+                counts[i] += 1
+        except BaseException as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append((i, repr(e)))
+            try:
+                start.abort()
+            except Exception:
+                pass
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in ts)
+    assert min(counts) >= 20, counts   # both threads made progress side by side (a pass is ~1 ms of GPU work)
+
+
+def test_two_contexts_interleaved_on_one_caller_stream():
+    import torch
+
+    stream = torch.cuda.Stream(device=0)
+    loads = [_workload(zk_amd.BN254_FR, 9300), _workload(zk_amd.BLS12_377_FR, 9400)]
+    ctxs = [zk_amd.Context(w["field"], 0) for w in loads]
+    for c in ctxs:
+        c.set_stream(stream.cuda_stream)
+    states = [{}, {}]
+    for _ in range(10):
+        for c, w, s in zip(ctxs, loads, states):
+            _one_pass(c, w, s)
+    # and back on their own streams
+    for c in ctxs:
+        c.use_own_stream()
+    for c, w, s in zip(ctxs, loads, states):
+        _one_pass(c, w, s)

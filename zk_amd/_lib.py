@@ -129,6 +129,7 @@ _sig = {
     "zk_comm_wrap_rccl": [c.c_void_p, c.c_void_p, c.c_uint32, c.c_uint32, vpp],
     "zk_comm_create_host": [c.c_void_p, c.c_uint32, c.c_uint32, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, vpp],
     "zk_comm_destroy": [c.c_void_p],
+    "zk_comm_info": [c.c_void_p, c.POINTER(c.c_int32), c.POINTER(c.c_uint32), c.POINTER(c.c_uint32)],
     "zk_shard_prover_run": [c.c_void_p, c.c_void_p, c.c_uint32],
     "zk_shard_prover_run_phases": [c.c_void_p, c.c_void_p, c.c_uint32, c.POINTER(c.c_double)],
     "zk_ntt_sharded": [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_void_p],

@@ -75,6 +75,14 @@ class RcclComm:
         self._h = h
         del torch
 
+
+    def info(self):
+        """what the transport reports: {"rccl_version", "ranks", "rank"} (zk_comm_info: ncclGetVersion / ncclCommCount / ncclCommUserRank;
+        version 0 = host-callback transport)"""
+        v, n, r = c.c_int32(), c.c_uint32(), c.c_uint32()
+        check(lib.zk_comm_info(self._h, c.byref(v), c.byref(n), c.byref(r)))
+        return {"rccl_version": v.value, "ranks": n.value, "rank": r.value}
+
     def close(self):
         if getattr(self, "_h", None):
             lib.zk_comm_destroy(self._h)
@@ -126,6 +134,13 @@ class HostComm:
         check(lib.zk_comm_create_host(ctx._h, self.world, self.rank, c.cast(self._cbs[0], c.c_void_p), c.cast(self._cbs[1], c.c_void_p),
                                       c.cast(self._cbs[2], c.c_void_p), None, c.byref(h)))
         self._h = h
+
+    def info(self):
+        """what the transport reports: {"rccl_version", "ranks", "rank"} (zk_comm_info: ncclGetVersion / ncclCommCount / ncclCommUserRank;
+        version 0 = host-callback transport)"""
+        v, n, r = c.c_int32(), c.c_uint32(), c.c_uint32()
+        check(lib.zk_comm_info(self._h, c.byref(v), c.byref(n), c.byref(r)))
+        return {"rccl_version": v.value, "ranks": n.value, "rank": r.value}
 
     def close(self):
         if getattr(self, "_h", None):
