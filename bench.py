@@ -620,6 +620,82 @@ def main():
                     ts.append(time.perf_counter() - t1)
                 extra[f"evaluate_via_python_us_n{n}"] = sorted(ts)[5] * 1e6
                 tn.free()
+            # ... the same bench on ITS field (ark_bls12_381::Fr, polynomial_evaluation.rs:12-15) and at the metric's table size
+            ctx381 = zk_amd.Context(zk_amd.BLS12_381_FR, 0)
+            for fld, cx, tag, sizes in ((zk_amd.BLS12_381_FR, ctx381, "bls12_381", (18, 19, 20, 21)), (field, ctx, "bn254", (22, 23, 24))):
+                for n in sizes:
+                    tn = zk_amd.MultiLinearPolynomial.random(cx, n, 0x5EED0E00 + n, 0)
+                    pt = tr2.sample_n_field_elements(fld, n)
+                    tn.evaluate(pt)
+                    ms = sorted(zk_amd.bench_evaluate(tn, pt, 21))
+                    extra[f"evaluate_us_n{n}_{tag}"] = ms[10] * 1e3
+                    extra[f"evaluate_us_n{n}_{tag}_min"] = ms[0] * 1e3
+                    tn.free()
+            ctx381.close()
+            ev24 = extra["evaluate_us_n24_bn254"]
+            result["roofline_evaluate"] = {"bound": "hbm", "workload": "MultiLinearPolynomial::evaluate, 2^24 BN254-Fr elements (whole call: "
+                                           "k_eval_stream over 15 variables + one k_eval_low workgroup + host launch and completion)",
+                                           "algorithmic_bytes": 32 << 24, "achieved": (32 << 24) / (ev24 * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
+                                           "unit": "GB/s", "frac": (32 << 24) / (ev24 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                           "note": "wall clock of the call (std::chrono inside the library), not a kernel duration: the kernel "
+                                                   "alone is in profiles/r04_evaluate_kernel_stats_and_pmc.log"}
+            # the (a)-rows that had no number: prod_reduce (product_poly.rs:66-74), partial_evaluate at general positions
+            # (evaluation_form.rs:40-80), to_bytes (:97-103), to_evaluation_form (coefficient_form.rs:340-347) -- device-resident
+            # calls bracketed by a synchronise, median of 9, against their algorithmic bytes
+            rows = {}
+
+            def timed(fn, reps=9):
+                ts = []
+                for _ in range(reps):
+                    ctx.synchronize()
+                    t1 = time.perf_counter()
+                    keep = fn()
+                    ctx.synchronize()
+                    ts.append(time.perf_counter() - t1)
+                    if keep is not None:
+                        keep.free()
+                return sorted(ts)[len(ts) // 2]
+
+            def row(name, seconds, nbytes, what):
+                rows[name] = {"us": seconds * 1e6, "algorithmic_bytes": nbytes, "GBps": nbytes / seconds / 1e9,
+                              "hbm_frac": nbytes / seconds / 1e9 / HBM_PEAK_GBPS, "what": what}
+
+            n = 24
+            tabs = [zk_amd.MultiLinearPolynomial.random(ctx, n, 0x5EED0F00 + f, 0) for f in range(3)]
+            for k in (2, 3):
+                pk = zk_amd.ProductPoly.new(tabs[:k])
+                pk.prod_reduce_device().free()
+                row(f"prod_reduce_k{k}_2p24", timed(lambda: pk.prod_reduce_device()), (k + 1) * (32 << n), f"k_prod_reduce: {k} tables read, one written")
+            asg = tr2.sample_n_field_elements(field, 1)
+            for v in (1, n // 2, n - 1):
+                tabs[0].partial_evaluate(v, asg).free()
+                row(f"partial_evaluate_2p24_var{v}", timed(lambda: tabs[0].partial_evaluate(v, asg)), 48 << n,
+                    f"k_fold at initial_var = {v} (index bit {n - 1 - v}): 2^24 read, 2^23 written")
+            tabs[0].partial_evaluate(0, asg).free()
+            row("partial_evaluate_2p24_var0", timed(lambda: tabs[0].partial_evaluate(0, asg)), 48 << n, "k_fold_msb through the allocating call")
+            t1 = time.perf_counter()
+            tabs[0].to_bytes()
+            dt = time.perf_counter() - t1
+            rows["to_bytes_2p24"] = {"ms": dt * 1e3, "host_GBps": (32 << n) / dt / 1e9,
+                                     "what": "k_to_bytes in 64-MiB chunks + device-to-host copies into a fresh (unpinned) bytes object: PCIe / page-fault bound"}
+            for q in tabs:
+                q.free()
+            rng_c = np.random.default_rng(0xC0EF)
+            keys = rng_c.integers(0, 1 << n, 1 << 16, dtype=np.uint64)
+            coeffs = zk_amd.fe_from_ints(field, [int(x) for x in rng_c.integers(1, 1 << 62, 1 << 16)])
+            cf = zk_amd.CoeffMultilinearPolynomial.new_with_coefficient(field, n, {int(k_): c_ for k_, c_ in zip(keys, coeffs)})
+            cf.to_evaluation_form(ctx).free()
+            ts = []
+            for _ in range(3):
+                ctx.synchronize()
+                t1 = time.perf_counter()
+                ev_t = cf.to_evaluation_form(ctx)
+                ctx.synchronize()
+                ts.append(time.perf_counter() - t1)
+                ev_t.free()
+            row("coeff_to_evaluation_2p24_64k_terms", sorted(ts)[1], n * (64 << n),
+                "k_scatter_terms + 24 k_zeta_pass launches, each reading and writing the 2^24 table once (host-side term merge included)")
+            extra["rows_2p24"] = rows
             # config[3]: GKR-shaped load -- no gkr crate exists in the reference; what it would call is
             # prove_partial on one ProductPoly per layer: depth 8, width 2^20, product of 3 MLEs, degree 3
             layers = []

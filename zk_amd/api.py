@@ -357,11 +357,15 @@ class ProductPoly:
     def partial_evaluate(self, initial_var, assignments):  # product_poly.rs:48-63
         return ProductPoly([q.partial_evaluate(initial_var, assignments) for q in self.polynomials])
 
-    def prod_reduce(self):  # product_poly.rs:66-74
+    def prod_reduce_device(self):
+        """prod_reduce with the result left resident: a new MultiLinearPolynomial (the reference returns a Vec<F>)"""
         hp, keep = _handles(self.polynomials)
         h = c.c_void_p()
         check(lib.zk_prod_reduce(self.ctx._h, hp, len(self.polynomials), c.byref(h)))
-        return MultiLinearPolynomial(self.ctx, h).evaluation_slice()
+        return MultiLinearPolynomial(self.ctx, h)
+
+    def prod_reduce(self):  # product_poly.rs:66-74
+        return self.prod_reduce_device().evaluation_slice()
 
     def round_sums(self, max_var_degree):  # prover.rs:49-56 for one round
         hp, keep = _handles(self.polynomials)
