@@ -98,6 +98,78 @@ __global__ __launch_bounds__(256) void k_tail(Shared *sh, const unsigned long lo
     spin_ticks(reduce_ticks + transcript_ticks);
     if (threadIdx.x == 0) { sh->total[s] = wsum[0] + wsum[1] + wsum[2] + wsum[3]; sh->chal[s] = sh->total[s] * 3 + 1; }
 }
+// ---- granule form: no counter, no last-arriver reduction, no separate flags --------------------------------------------------
+// Every round-kernel workgroup publishes its partial as GR tagged 8-byte granules {epoch, value} (one sc1 store each: the data IS
+// the flag); the resident workgroup (256 threads) sweeps all G * GR granules until every tag carries the round's epoch, reduces,
+// runs the transcript step and publishes the challenge as ONE granule that the next round kernel's workgroups poll directly.
+constexpr int GR = 24;   // a (D + 1) = 3 element partial is 96 bytes = 24 granules of 4 payload bytes
+template <int DUMMY>
+__global__ __launch_bounds__(256) void k_round_granule(Shared *sh, unsigned long long *gran, int s, uint64_t work_ticks) {
+    __shared__ unsigned long long r_s;
+    __shared__ unsigned ok_s;
+    if (s > 0) {
+        if (threadIdx.x == 0) {
+            const uint64_t t0 = wall_clock64();
+            ok_s = 0;
+            for (;;) {
+                const unsigned long long g = __hip_atomic_load((gu64 *)&sh->chal[s - 1], RLX_AGENT);
+                if ((unsigned)(g >> 32) == (unsigned)s) { r_s = g & 0xffffffffu; ok_s = 1; break; }
+                if (__hip_atomic_load((gu32 *)&sh->timeout, RLX_AGENT) != 0) break;
+                if (wall_clock64() - t0 > 300000) { __hip_atomic_store((gu32 *)&sh->timeout, 300u + s, RLX_AGENT); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        if (!ok_s) return;
+    } else if (threadIdx.x == 0) {
+        r_s = 0;
+    }
+    __syncthreads();
+    spin_ticks(work_ticks);
+    if (threadIdx.x < GR)
+        __hip_atomic_store((gu64 *)&gran[((size_t)(s & 1) * gridDim.x + blockIdx.x) * GR + threadIdx.x],
+                           ((unsigned long long)(s + 1) << 32) | ((r_s + blockIdx.x + 1) & 0xffffffffu), RLX_AGENT);
+}
+__global__ __launch_bounds__(256) void k_resident_granule(Shared *sh, const unsigned long long *gran, int rounds, unsigned grid, uint64_t reduce_ticks,
+                                                           uint64_t transcript_ticks) {
+    __shared__ unsigned long long wsum[4];
+    __shared__ unsigned all_ok;
+    for (int s = 0; s < rounds; ++s) {
+        const unsigned long long *g = gran + (size_t)(s & 1) * grid * GR;
+        const unsigned n = grid * GR;
+        unsigned long long acc = 0;
+        const uint64_t t0 = wall_clock64();
+        for (;;) {   // sweep until every granule of this round has arrived
+            bool ok = true;
+            acc = 0;
+            for (unsigned i = threadIdx.x; i < n; i += 256) {
+                const unsigned long long x = __hip_atomic_load((gu64 *)&g[i], RLX_AGENT);
+                ok &= (unsigned)(x >> 32) == (unsigned)(s + 1);
+                if (i % GR == 0) acc += x & 0xffffffffu;
+            }
+            if (threadIdx.x == 0) all_ok = 1;
+            __syncthreads();
+            if (!ok) all_ok = 0;
+            __syncthreads();
+            if (all_ok) break;
+            if (__hip_atomic_load((gu32 *)&sh->timeout, RLX_AGENT) != 0) return;
+            if (wall_clock64() - t0 > 300000) { if (threadIdx.x == 0) __hip_atomic_store((gu32 *)&sh->timeout, 400u + s, RLX_AGENT); return; }
+            __syncthreads();
+        }
+        for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            spin_ticks(reduce_ticks + transcript_ticks);
+            const unsigned long long t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (threadIdx.x == 0) {
+                sh->total[s] = t;
+                __hip_atomic_store((gu64 *)&sh->chal[s], ((unsigned long long)(s + 1) << 32) | ((t * 3 + 1) & 0xffffffffu), RLX_AGENT);
+            }
+        }
+        __syncthreads();
+    }
+}
 // resident transcript workgroup (one wave)
 __global__ __launch_bounds__(64) void k_resident(Shared *sh, int rounds, uint64_t transcript_ticks) {
     for (int s = 0; s < rounds; ++s) {
@@ -157,6 +229,28 @@ int main() {
                 if (h->timeout) ++tmo;
                 else if (h->chal[R - 1] != want) ++bad;
             }
+            // granule form (values are 32-bit here: compare the last challenge's payload with the classic run's low 32 bits of the same recurrence)
+            std::vector<double> tg;
+            int tmo_g = 0;
+            unsigned long long *gran;
+            CK(hipMalloc(&gran, (size_t)2 * grid * GR * 8));
+            for (int rep = 0; rep < 24; ++rep) {
+                CK(hipMemsetAsync(sh, 0, sizeof(Shared), sa));
+                CK(hipMemsetAsync(gran, 0, (size_t)2 * grid * GR * 8, sa));
+                CK(hipStreamSynchronize(sa));
+                auto t0 = std::chrono::steady_clock::now();
+                k_resident_granule<<<1, 256, 0, sb>>>(sh, gran, R, grid, 150, 500);
+                for (int s = 0; s < R; ++s) k_round_granule<0><<<grid, 256, 0, sa>>>(sh, gran, s, work);
+                CK(hipStreamSynchronize(sb));
+                CK(hipStreamSynchronize(sa));
+                double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                if (rep >= 4) tg.push_back(us / R);
+                CK(hipMemcpy(h, sh, sizeof(Shared), hipMemcpyDeviceToHost));
+                if (h->timeout) ++tmo_g;
+            }
+            CK(hipFree(gran));
+            printf("grid %4d work %4.0f us: granules %6.2f us/round (beyond work+reduce+transcript: %5.2f) timeouts %d\n", grid, work / 100.0, med(tg),
+                   med(tg) - work / 100.0 - 6.5, tmo_g);
             printf("grid %4d work %4.0f us: classic %6.2f us/round | resident %6.2f us/round  (minus work+reduce+transcript %.1f: %5.2f vs %5.2f)  wrong %d timeouts %d\n",
                    grid, work / 100.0, med(tc), med(tr), work / 100.0 + 6.5, med(tc) - work / 100.0 - 6.5, med(tr) - work / 100.0 - 6.5, bad, tmo);
         }
