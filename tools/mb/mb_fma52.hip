@@ -68,8 +68,15 @@ __device__ __forceinline__ void split52(const uint64_t a[4], double l[5]) {
     }
 }
 // the kernels set MODE.FP_ROUND[3:2] (double precision) to round-toward-zero once, at their start; every FMA below then truncates
-__device__ __forceinline__ void set_double_rtz() { __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 3); }   // hwreg(HW_REG_MODE, 2, 2) = 3
-__device__ __forceinline__ double fma_rz(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// (through inline asm: the backend's mode-register pass otherwise notices the change and resets the mode in front of the next
+// double-precision instruction it knows about; the FMAs are asm for the same reason -- the compiler's own v_add_f64 for the exact
+// subtractions run under the same mode and do not care)
+__device__ __forceinline__ void set_double_rtz() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3"); }
+__device__ __forceinline__ double fma_rz(double a, double b, double c) {
+    double d;
+    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ void mul_fma52(const double x[5], const double y[5], uint64_t col[10]) {
     const double C1 = 20282409603651670423947251286016.0;                 // 2^104
     const double C2 = 20282409603651670423947251286016.0 + 4503599627370496.0;   // 2^104 + 2^52 (exact)
