@@ -136,6 +136,27 @@ def test_fold_every_position_and_length(field, n_vars):
 
 
 @pytest.mark.parametrize("field", FIELDS)
+def test_fold_general_positions_through_the_run_kernel(field):
+    """partial_evaluate at every initial_var of a 2^14 table (index bits 13..0): bits >= 6 take k_fold_run (wave-coalesced runs,
+    block by block), the low six bits k_fold; single and multiple assignments (each later assignment folds the SAME variable index
+    of the shrunken table, evaluation_form.rs:54-72), edge challenges included.  Bit-exact vs the oracle."""
+    c = ctx_for(field)
+    p = zk_amd.modulus(field)
+    n = 14
+    tab = orc.fill_random(field, 1400 + field, 1 << n)
+    t = MLE.new(c, n, tab)
+    rng = random.Random(14 + field)
+    for initial_var in range(n):
+        for n_assign in (1, 2, 3, n - initial_var):
+            if n_assign > n - initial_var:
+                continue
+            asg = F(field, [rng.choice([0, 1, p - 1, rng.randrange(p), rng.randrange(p)]) for _ in range(n_assign)])
+            got = t.partial_evaluate(initial_var, asg).evaluation_slice()
+            assert np.array_equal(got, orc.mle_partial_evaluate(field, n, tab, initial_var, asg)), (initial_var, n_assign)
+    assert np.array_equal(t.evaluation_slice(), tab)
+
+
+@pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("n_vars", [12, 16])
 def test_msb_fold_evaluate_to_bytes_random(field, n_vars):
     c = ctx_for(field)
@@ -194,7 +215,7 @@ def test_ref_to_evaluation_form_kat_and_random(field):
                                                            (zk_amd.fe_from_int(field, 5), [True, False])])
     assert ints(field, dup.to_evaluation_form(c).evaluation_slice()) == [0, 0, 7, 7]
     rng = random.Random(field)
-    for n_vars, n_terms in [(1, 2), (4, 9), (9, 300), (13, 2000), (16, 65536)]:
+    for n_vars, n_terms in [(1, 2), (2, 3), (4, 9), (5, 20), (8, 100), (9, 300), (11, 700), (13, 2000), (16, 65536)]:   # n mod 3 = 0, 1, 2
         keys = sorted(rng.sample(range(1 << n_vars), min(n_terms, 1 << n_vars)))
         coeffs = orc.fill_random(field, 2600 + n_vars, len(keys))
         poly = zk_amd.CoeffMultilinearPolynomial.new_with_coefficient(field, n_vars, {k: coeffs[i] for i, k in enumerate(keys)})
@@ -225,10 +246,10 @@ def test_ref_to_evaluation_form_kat_and_random(field):
 @pytest.mark.parametrize("k", [1, 2, 3, 5])
 def test_prod_reduce_random(field, k):
     c = ctx_for(field)
-    n_vars = 10
-    tabs = [orc.fill_random(field, 300 + f, 1 << n_vars) for f in range(k)]
-    pp = ProductPoly.new([MLE.new(c, n_vars, t) for t in tabs])
-    assert np.array_equal(pp.prod_reduce(), orc.prod_reduce(field, n_vars, tabs))
+    for n_vars in (0, 3, 5, 6, 10, 13):   # below 64 elements: k_prod_reduce; from 64: the wave-coalesced k_prod_reduce_run
+        tabs = [orc.fill_random(field, 300 + f + 10 * n_vars, 1 << n_vars) for f in range(k)]
+        pp = ProductPoly.new([MLE.new(c, n_vars, t) for t in tabs])
+        assert np.array_equal(pp.prod_reduce(), orc.prod_reduce(field, n_vars, tabs)), n_vars
 
 
 def oracle_round_sums(field, n_vars, tabs, D):

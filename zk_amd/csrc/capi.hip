@@ -532,6 +532,13 @@ static int32_t launch_fold(zk_ctx *c, const uint64_t *in, uint64_t *out, uint64_
         HIPCHK(hipGetLastError());
         return ZK_OK;
     }
+    if (pos >= 6 && in != out) {   // any other variable whose pair partner is >= 64 elements away: the same run access, block by block
+        uint64_t g = pairs / kBlock;
+        if (g > 2 * kMaxGridStream) g = 2 * kMaxGridStream;
+        k_fold_run<<<(uint32_t)(g ? g : 1), kBlock, 0, c->stream>>>(in, out, pairs, pos, c->fi->P, mul29_prepare(r, c->fi->P));
+        HIPCHK(hipGetLastError());
+        return ZK_OK;
+    }
     uint64_t g = (pairs + kBlock - 1) / kBlock;
     if (g > kMaxGridStream) g = kMaxGridStream;
     k_fold<<<(uint32_t)(g ? g : 1), kBlock, 0, c->stream>>>(in, out, pairs, pos, c->fi->P, mul29_prepare(r, c->fi->P));
@@ -837,12 +844,16 @@ static int32_t coeff_to_evaluation_impl(zk_ctx *c, uint64_t n_vars, const uint64
             if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
         }
     }
-    for (uint32_t b = 0; b < n_vars && rc == ZK_OK; ++b) {
-        const uint64_t pairs = 1ull << (n_vars - 1);
-        uint64_t g = (pairs + kBlock - 1) / kBlock;
+    for (uint32_t b = 0; b < n_vars && rc == ZK_OK;) {   // the subset-sum butterfly over every index bit, three bits per pass
+        const uint32_t v = n_vars - b >= 3 ? 3u : (uint32_t)(n_vars - b);
+        const uint64_t groups = 1ull << (n_vars - v);
+        uint64_t g = (groups + kBlock - 1) / kBlock;
         if (g > kMaxGridStream) g = kMaxGridStream;
-        k_zeta_pass<<<(uint32_t)g, kBlock, 0, c->stream>>>(t->d, pairs, b, c->fi->P);
+        if (v == 3) k_zeta_multi<3><<<(uint32_t)g, kBlock, 0, c->stream>>>(t->d, groups, b, c->fi->P);
+        else if (v == 2) k_zeta_multi<2><<<(uint32_t)g, kBlock, 0, c->stream>>>(t->d, groups, b, c->fi->P);
+        else k_zeta_pass<<<(uint32_t)g, kBlock, 0, c->stream>>>(t->d, groups, b, c->fi->P);
         if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+        b += v;
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == ZK_OK) rc = ZK_ERR_HIP;   // host staging vectors go out of scope
     if (d_keys) pool_free(c, d_keys, m * 8);
@@ -884,7 +895,13 @@ extern "C" int32_t zk_prod_reduce(zk_ctx *c, const zk_mle *const *f, uint64_t k,
     FactorPtrs fp = {};
     for (uint64_t i = 0; i < k; ++i) fp.in[i] = f[i]->d;
     const uint64_t n = 1ull << f[0]->n_vars;
-    k_prod_reduce<<<grid_for(n), kBlock, 0, c->stream>>>(fp, (int)k, n, o->d, c->fi->P);
+    if (n >= 64) {
+        uint64_t g = n / kBlock;   // one 64-element run per wave and pass
+        if (g > 2 * kMaxGridStream) g = 2 * kMaxGridStream;
+        k_prod_reduce_run<<<(uint32_t)(g ? g : 1), kBlock, 0, c->stream>>>(fp, (int)k, n, o->d, c->fi->P);
+    } else {
+        k_prod_reduce<<<grid_for(n), kBlock, 0, c->stream>>>(fp, (int)k, n, o->d, c->fi->P);
+    }
     HIPCHK(hipGetLastError());
     *out = o;
     return ZK_OK;

@@ -65,6 +65,33 @@ __global__ __launch_bounds__(kBlock) void k_fold_msb(const uint64_t *in, uint64_
     }
 }
 
+// The same data movement for ANY fold position pos >= 6 (partial_evaluate with initial_var > 0, evaluation_form.rs:55-70): the pair
+// partner of an element sits 2^pos >= 64 elements away, so 64 consecutive outputs still read two contiguous 64-element runs --
+// block b = e / 2^pos of the output reads in[b * 2^(pos+1) + off] and in[b * 2^(pos+1) + 2^pos + off].  k_fold_msb is the case
+// of one block.  Out of place only (a later block's inputs are an earlier block's output positions).  Measured (bench rows_2p24):
+// the 32-byte-per-lane k_fold reaches 0.62-0.66 of the HBM peak at 2^24, this form the MSB fold's 0.79.
+__global__ __launch_bounds__(kBlock) void k_fold_run(const uint64_t *in, uint64_t *out, uint64_t pairs, uint32_t pos, FieldParams P, Mul29 r) {
+    const uint32_t lane = threadIdx.x & 63;
+    const bool odd = lane & 1;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * kBlock) >> 6;
+    const uint4 *in4 = reinterpret_cast<const uint4 *>(in);
+    uint4 *out4 = reinterpret_cast<uint4 *>(out);
+    const uint64_t span = 1ull << pos;
+    for (uint64_t e0 = wave * 64; e0 < pairs; e0 += nwaves * 64) {
+        const uint64_t lo0 = ((e0 >> pos) << (pos + 1)) | (e0 & (span - 1));   // insert_zero_bit(e0, pos): first element of the lo run
+        const uint64_t cl = 2 * lo0 + lane, co = 2 * e0 + lane;                // element e occupies uint4 slots 2e, 2e+1
+        const uint4 la = nt_load16(in4 + cl), lb = nt_load16(in4 + cl + 64);
+        const uint4 ha = nt_load16(in4 + cl + 2 * span), hb = nt_load16(in4 + cl + 2 * span + 64);
+        const Fe lo = pair_gather(la, lb, odd), hi = pair_gather(ha, hb, odd);
+        const Fe o = fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P);
+        uint4 oa, ob;
+        pair_scatter(o, odd, oa, ob);
+        nt_store16(oa, out4 + co);
+        nt_store16(ob, out4 + co + 64);
+    }
+}
+
 // same fold with the challenge read from device memory (produced by the on-device transcript); m = variables of `in`,
 // always the MSB fold.  `pairs` = 2^(m-1).
 __global__ __launch_bounds__(kBlock) void k_fold_dev(const uint64_t *in, uint64_t *out, uint64_t pairs, uint32_t m,
@@ -229,6 +256,31 @@ __global__ __launch_bounds__(kEvalTailThreads) void k_evaluate_tail(const uint64
 }
 
 // ---- ProductPoly::prod_reduce (product_poly.rs:66-74) --------------------------------------------------------
+// n >= 64: the fold's wave-coalesced run access (two 1-KiB dwordx4 accesses per 64 elements and table + a DPP half swap, nontemporal:
+// every table is streamed once).  Measured at 2^24: 0.62 (k = 2) / 0.57 (k = 3) of the HBM peak with 32 bytes per lane.
+__global__ __launch_bounds__(kBlock) void k_prod_reduce_run(FactorPtrs fp, int k, uint64_t n, uint64_t *__restrict__ out, FieldParams P) {
+    const uint32_t lane = threadIdx.x & 63;
+    const bool odd = lane & 1;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * kBlock) >> 6;
+    uint4 *out4 = reinterpret_cast<uint4 *>(out);
+    for (uint64_t e0 = wave * 64; e0 < n; e0 += nwaves * 64) {
+        const uint64_t c0 = 2 * e0 + lane;
+        Fe acc;
+        {
+            const uint4 *q = reinterpret_cast<const uint4 *>(fp.in[0]);
+            acc = pair_gather(nt_load16(q + c0), nt_load16(q + c0 + 64), odd);
+        }
+        for (int f = 1; f < k; ++f) {
+            const uint4 *q = reinterpret_cast<const uint4 *>(fp.in[f]);
+            acc = fe_mul(acc, pair_gather(nt_load16(q + c0), nt_load16(q + c0 + 64), odd), P);
+        }
+        uint4 oa, ob;
+        pair_scatter(acc, odd, oa, ob);
+        nt_store16(oa, out4 + c0);
+        nt_store16(ob, out4 + c0 + 64);
+    }
+}
 __global__ __launch_bounds__(kBlock) void k_prod_reduce(FactorPtrs fp, int k, uint64_t n, uint64_t *__restrict__ out,
                                                         FieldParams P) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
@@ -730,6 +782,28 @@ __global__ __launch_bounds__(kBlock) void k_zeta_pass(uint64_t *table, uint64_t 
     for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < pairs; j += stride) {
         const uint64_t lo = insert_zero_bit(j, pos), hi = lo | (1ull << pos);
         fe_store(table, hi, fe_add(fe_load(table, hi), fe_load(table, lo), P));
+    }
+}
+
+// V consecutive bit positions pos .. pos+V-1 in one pass: a thread owns the 2^V elements that differ in those bits, applies the V
+// levels of the subset-sum butterfly (hi += lo: additions only) in registers and writes the 2^V - 1 elements that changed --
+// a third of the launches and 0.4 of the traffic of three single passes at V = 3.
+template <int V>
+__global__ __launch_bounds__(kBlock) void k_zeta_multi(uint64_t *table, uint64_t groups, uint32_t pos, FieldParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t low_mask = (1ull << pos) - 1;
+    for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
+        const uint64_t base = ((g >> pos) << (pos + V)) | (g & low_mask);
+        Fe x[1 << V];
+#pragma unroll
+        for (int c = 0; c < (1 << V); ++c) x[c] = fe_load(table, base | ((uint64_t)c << pos));
+#pragma unroll
+        for (int b = 0; b < V; ++b)
+#pragma unroll
+            for (int c = 0; c < (1 << V); ++c)
+                if (c & (1 << b)) x[c] = fe_add(x[c], x[c ^ (1 << b)], P);
+#pragma unroll
+        for (int c = 1; c < (1 << V); ++c) fe_store(table, base | ((uint64_t)c << pos), x[c]);
     }
 }
 
