@@ -14,6 +14,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -759,23 +760,46 @@ extern "C" int32_t zk_mle_evaluate(zk_ctx *c, const zk_mle *t, const uint64_t *p
     return ZK_OK;
 }
 
+static int32_t absorb_tables(zk_ctx *c, Sponge &sp, zk_mle *const *f, uint64_t k);
+template <class Consume>
+static int32_t stream_table_bytes(zk_ctx *c, const zk_mle *const *f, uint64_t k, Consume &&consume);
+// chunk -> caller's buffer on a few host threads: a fresh destination (a new Vec<u8>) is page-fault bound, and faults parallelise
+static void copy_out_parallel(uint8_t *dst, const uint8_t *src, size_t bytes) {
+    constexpr size_t kMinPerThread = (size_t)2 << 20;
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 4) nt = 4;
+    if (nt < 2 || bytes < 2 * kMinPerThread) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t per = (bytes / nt + 4095) & ~(size_t)4095;
+    std::thread th[3];
+    unsigned started = 0;
+    for (unsigned i = 1; i < nt; ++i) {
+        const size_t off = per * i;
+        if (off >= bytes) break;
+        const size_t len = bytes - off < per ? bytes - off : per;
+        try {
+            th[started] = std::thread([=] { memcpy(dst + off, src + off, len); });
+            ++started;
+        } catch (...) {
+            memcpy(dst + off, src + off, len);   // no thread to be had: copy it here
+        }
+    }
+    memcpy(dst, src, per < bytes ? per : bytes);
+    for (unsigned i = 0; i < started; ++i) th[i].join();
+}
 extern "C" int32_t zk_mle_to_bytes(zk_ctx *c, const zk_mle *t, uint8_t *out) {
     if (!c || !t || !out) return ZK_ERR_BAD_ARG;
     if (t->ctx != c) return ZK_ERR_CONTEXT_MISMATCH;
     ZKCHK(use_device(c));
-    const uint64_t n = 1ull << t->n_vars;
-    const uint64_t chunk = n < (1ull << 21) ? n : (1ull << 21);   // 64 MiB of bytes per chunk
-    uint8_t *d_bytes = nullptr;
-    ZKCHK(raw_alloc(c, (size_t)chunk * 32, (void **)&d_bytes));
-    int32_t rc = ZK_OK;
-    for (uint64_t off = 0; off < n && rc == ZK_OK; off += chunk) {
-        k_to_bytes<<<grid_for(chunk), kBlock, 0, c->stream>>>(t->d + 4 * off, d_bytes, chunk, c->fi->P);
-        if (hipMemcpyAsync(out + 32 * off, d_bytes, (size_t)chunk * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess)
-            rc = ZK_ERR_HIP;
-    }
-    (void)hipFree(d_bytes);
-    return rc;
+    // device serialiser -> pinned staging (two buffers, the copy of chunk i + 1 under the host's copy-out of chunk i) -> caller
+    size_t off = 0;
+    const zk_mle *one[1] = {t};
+    return stream_table_bytes(c, one, 1, [&](const uint8_t *p, size_t bytes) {
+        copy_out_parallel(out + off, p, bytes);
+        off += bytes;
+    });
 }
 
 extern "C" int32_t zk_mle_partial_evaluate_host(zk_ctx *c, uint64_t n_vars, const uint64_t *evals, uint64_t len,
@@ -1210,7 +1234,9 @@ static Fe squeeze_field_element(Sponge &sp, const FieldParams &P) {   // transcr
 // serial by construction and runs on the host (one GPU wave permutes 136 bytes in ~3 us = 45 MB/s; a host core does
 // 0.4-0.75 GB/s with keccak_host::rounds), so it bounds `prove`; the serialiser kernel and the copy of chunk i+1 run while the host absorbs
 // chunk i (two device + two pinned buffers, one event each; the pinned buffers stay with the context).
-static int32_t absorb_tables(zk_ctx *c, Sponge &sp, zk_mle *const *f, uint64_t k) {
+// consume(host_ptr, bytes) is called once per 16-MiB chunk, in order, on the calling thread, while the next chunk is serialised and copied
+template <class Consume>
+static int32_t stream_table_bytes(zk_ctx *c, const zk_mle *const *f, uint64_t k, Consume &&consume) {
     const uint64_t n = 1ull << f[0]->n_vars;
     const uint64_t chunk = n < (1ull << 19) ? n : (1ull << 19);   // 16 MiB of bytes per chunk
     const size_t cb = (size_t)chunk * 32;
@@ -1240,14 +1266,17 @@ static int32_t absorb_tables(zk_ctx *c, Sponge &sp, zk_mle *const *f, uint64_t k
     };
     if (rc == ZK_OK) rc = enqueue(0);
     for (uint64_t i = 0; i < total && rc == ZK_OK; ++i) {
-        if (i + 1 < total) rc = enqueue(i + 1);   // its buffers were released when chunk i-1 was absorbed
+        if (i + 1 < total) rc = enqueue(i + 1);   // its buffers were released when chunk i-1 was consumed
         if (rc == ZK_OK && hipEventSynchronize(c->ev_absorb[i & 1]) != hipSuccess) rc = ZK_ERR_HIP;
-        if (rc == ZK_OK) sp.update(c->h_absorb[i & 1], cb);
+        if (rc == ZK_OK) consume(c->h_absorb[i & 1], cb);
     }
     if (rc != ZK_OK) (void)hipStreamSynchronize(c->stream);
     pool_free(c, d_bytes[0], cb);
     if (d_bytes[1]) pool_free(c, d_bytes[1], cb);
     return rc;
+}
+static int32_t absorb_tables(zk_ctx *c, Sponge &sp, zk_mle *const *f, uint64_t k) {
+    return stream_table_bytes(c, (const zk_mle *const *)f, k, [&](const uint8_t *p, size_t bytes) { sp.update(p, bytes); });
 }
 
 // ------------------------------------------------------------------------------------------------------------
