@@ -274,10 +274,16 @@ class MultiLinearPolynomial:
         return out
 
     # to_bytes (evaluation_form.rs:97-103)
-    def to_bytes(self):
-        out = np.zeros(32 << self.n_vars(), dtype=np.uint8)
+    def to_bytes_array(self, out=None):
+        """to_bytes (evaluation_form.rs:97-103) into a numpy uint8 array (a fresh one, or `out`): no second host copy"""
+        if out is None:
+            out = np.empty(32 << self.n_vars(), dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.size == 32 << self.n_vars() and out.flags["C_CONTIGUOUS"]
         check(lib.zk_mle_to_bytes(self.ctx._h, self._h, out.ctypes.data_as(u8p)))
-        return out.tobytes()
+        return out
+
+    def to_bytes(self):
+        return self.to_bytes_array().tobytes()
 
     def __eq__(self, other):  # #[derive(PartialEq)] (evaluation_form.rs:4)
         if not isinstance(other, MultiLinearPolynomial):
