@@ -22,7 +22,7 @@ while time.time() < t_end:
     f = rng.randrange(3)
     c = ctxs[f]
     p = zk_amd.modulus(f)
-    kind = rng.choice(["prove", "prove", "terms", "evaluate", "fold", "gkr", "gkr_wide"])
+    kind = rng.choice(["prove", "prove", "terms", "evaluate", "fold", "gkr", "gkr_wide", "evaluate_big", "prod_reduce", "to_bytes", "coeff"])
     if kind == "prove":
         k = rng.choice([1, 2, 2, 3, 3, 4, 5, 8])
         D = rng.choice([max(1, k), k, k + 1, rng.randrange(1, 7)])
@@ -97,6 +97,35 @@ while time.time() < t_end:
         bad[rng.randrange(len(want_proof))] = zk_amd.fe_from_int(f, rng.randrange(p))
         assert not gkr.gkr_verify(circ, x, out, seed, bad) or zk_amd.fe_to_ints(f, bad) == want_proof, ("gkr_wide tamper", f, logs)
         circ.free()
+    elif kind == "evaluate_big":   # k_eval_stream from 21 variables (L = 12, 13), k_eval_low below
+        if rng.random() < 0.7:
+            n_cases -= 1           # (rare: a 2^21-2^22 table costs seconds of host generation)
+        else:
+            n = rng.choice([20, 21, 21, 22])
+            t = orc.fill_random(f, rng.randrange(1 << 30), 1 << n)
+            pt = orc.fill_random(f, rng.randrange(1 << 30), n)
+            if rng.random() < 0.3:
+                pt[rng.randrange(n)] = orc.from_int(f, rng.choice([0, 1, p - 1]))
+            m = MLE.new(c, n, t)
+            assert np.array_equal(m.evaluate(pt), orc.mle_evaluate(f, n, t, pt)), ("evaluate_big", f, n)
+            m.free()
+    elif kind == "prod_reduce":
+        k, n = rng.choice([1, 2, 2, 3, 5]), rng.randrange(0, 15)
+        tabs = [orc.fill_random(f, rng.randrange(1 << 30), 1 << n) for _ in range(k)]
+        got = ProductPoly.new([MLE.new(c, n, t) for t in tabs]).prod_reduce()
+        assert np.array_equal(got, orc.prod_reduce(f, n, tabs)), ("prod_reduce", f, k, n)
+    elif kind == "to_bytes":
+        n = rng.randrange(0, 21)
+        t = orc.fill_random(f, rng.randrange(1 << 30), 1 << n)
+        assert MLE.new(c, n, t).to_bytes() == orc.mle_to_bytes(f, n, t), ("to_bytes", f, n)
+    elif kind == "coeff":
+        n = rng.randrange(1, 12)
+        nt = rng.randrange(1, min(1 << n, 400) + 1)
+        keys = sorted(rng.sample(range(1 << n), nt))
+        coeffs = orc.fill_random(f, rng.randrange(1 << 30), nt)
+        poly = zk_amd.CoeffMultilinearPolynomial.new_with_coefficient(f, n, {kk: coeffs[i] for i, kk in enumerate(keys)})
+        got = poly.to_evaluation_form(c).evaluation_slice()
+        assert np.array_equal(got, orc.coeff_to_evaluation(f, n, keys, coeffs)), ("coeff", f, n, nt)
     elif kind == "evaluate":
         n = rng.randrange(0, 19)
         t = orc.fill_random(f, rng.randrange(1 << 30), 1 << n)
