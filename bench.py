@@ -633,12 +633,20 @@ def main():
                     tn.free()
             ctx381.close()
             ev24 = extra["evaluate_us_n24_bn254"]
-            result["roofline_evaluate"] = {"bound": "hbm", "workload": "MultiLinearPolynomial::evaluate, 2^24 BN254-Fr elements (whole call: "
-                                           "k_eval_stream over 15 variables + one k_eval_low workgroup + host launch and completion)",
-                                           "algorithmic_bytes": 32 << 24, "achieved": (32 << 24) / (ev24 * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
-                                           "unit": "GB/s", "frac": (32 << 24) / (ev24 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                                           "note": "wall clock of the call (std::chrono inside the library), not a kernel duration: the kernel "
-                                                   "alone is in profiles/r04_evaluate_kernel_stats_and_pmc.log"}
+            t24 = zk_amd.MultiLinearPolynomial.random(ctx, 24, 0x5EED0E00 + 24, 0)
+            pt24 = tr2.sample_n_field_elements(field, 24)
+            dev24 = zk_amd.bench_evaluate_device(t24, pt24, 40) * 1e3    # us: HIP events around 40 back-to-back evaluates, no host wait
+            t24.free()
+            extra["evaluate_device_us_n24_bn254"] = dev24
+            result["roofline_evaluate"] = {"bound": "hbm", "workload": "MultiLinearPolynomial::evaluate, 2^24 BN254-Fr elements: k_eval_stream over the low "
+                                           "15 variables + one k_eval_low workgroup for the other 9",
+                                           "algorithmic_bytes": 32 << 24, "achieved": (32 << 24) / (dev24 * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
+                                           "unit": "GB/s", "frac": (32 << 24) / (dev24 * 1e-6) / 1e9 / HBM_PEAK_GBPS, "device_us": dev24,
+                                           "call_us": ev24, "frac_of_the_whole_call": (32 << 24) / (ev24 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                           "timing": "device_us: HIP events on the launch stream around 40 back-to-back evaluates (both launches of each, "
+                                                     "zk_bench_evaluate_device); call_us: std::chrono around one zk_mle_evaluate incl. launch and completion",
+                                           "profile": "profiles/r04_evaluate_kernel_stats_and_pmc.log (rocprofv3: the streaming kernel alone, VALU and "
+                                                      "FETCH_SIZE counters)"}
             # the (a)-rows that had no number: prod_reduce (product_poly.rs:66-74), partial_evaluate at general positions
             # (evaluation_form.rs:40-80), to_bytes (:97-103), to_evaluation_form (coefficient_form.rs:340-347) -- device-resident
             # calls bracketed by a synchronise, median of 9, against their algorithmic bytes

@@ -31,7 +31,7 @@ extern "C" {
 
 #define ZK_AMD_ABI_VERSION 5   /* 3: + zk_comm (RCCL / host), zk_shard_prover_run, zk_ntt_sharded, sample_n, zk_ctx_trim, zk_mle_equal
                                   4: + zk_sumcheck_verify_lengths / _verify_partial_lengths (per-round degrees, verifier.rs:55-58)
-                                  5: + zk_comm_info */
+                                  5: + zk_comm_info, zk_bench_evaluate_device */
 
 typedef enum zk_field {
     ZK_FIELD_BN254_FR = 0,     /* north-star field (not a dependency of the reference: SURVEY D2) */
@@ -343,6 +343,9 @@ int32_t zk_bench_prove_partial(zk_ctx *ctx, zk_mle *const *factors, uint64_t k, 
                                int32_t reps, double *out_ms_each);
 /* the same for zk_mle_evaluate (the reference's own criterion bench, polynomial/benches/polynomial_evaluation.rs): per-call ms */
 int32_t zk_bench_evaluate(zk_ctx *ctx, const zk_mle *t, const uint64_t *point, uint64_t n_point, int32_t reps, double *out_ms_each);
+/* device time of the same call: `reps` back-to-back enqueues of evaluate's launches between two HIP events on the context's stream,
+   no host wait in between; average ms per evaluate (bench.py roofline_evaluate) */
+int32_t zk_bench_evaluate_device(zk_ctx *ctx, const zk_mle *t, const uint64_t *point, uint64_t n_point, int32_t reps, double *out_ms);
 /* register-resident modular-multiply throughput (no memory traffic): variant 0 = fe_mul chain. Returns modmul/s */
 int32_t zk_bench_modmul(zk_ctx *ctx, int32_t variant, int32_t iters, double *out_modmul_per_s);
 /* plain 16-B/lane streaming copy of `bytes` bytes: achieved GB/s (calibrates the HBM ceiling on this device) */

@@ -164,6 +164,7 @@ _sig = {
     "zk_bench_ntt": [c.c_void_p, c.c_void_p, c.c_int32, c.c_void_p, c.c_int32, c.POINTER(c.c_double)],
     "zk_bench_prove_partial": [c.c_void_p, c.POINTER(c.c_void_p), c.c_uint64, c.c_uint32, u64p, c.c_int32, c.POINTER(c.c_double)],
     "zk_bench_evaluate": [c.c_void_p, c.c_void_p, u64p, c.c_uint64, c.c_int32, c.POINTER(c.c_double)],
+    "zk_bench_evaluate_device": [c.c_void_p, c.c_void_p, u64p, c.c_uint64, c.c_int32, c.POINTER(c.c_double)],
     "zk_bench_modmul": [c.c_void_p, c.c_int32, c.c_int32, c.POINTER(c.c_double)],
     "zk_bench_copy": [c.c_void_p, c.c_uint64, c.c_int32, c.POINTER(c.c_double)],
 }

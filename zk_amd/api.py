@@ -505,6 +505,14 @@ def bench_evaluate(table, point, reps=10):
     return [float(v) for v in out]
 
 
+def bench_evaluate_device(table, point, reps=20):
+    """average device time (ms) of one evaluate: `reps` back-to-back enqueues between two HIP events, no host wait in between"""
+    pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+    out = c.c_double()
+    check(lib.zk_bench_evaluate_device(table.ctx._h, table._h, _p(pt if pt.size else np.zeros((1, 4), dtype=np.uint64)), pt.shape[0], reps, c.byref(out)))
+    return out.value
+
+
 def bench_ntt(ctx, vec_in, vec_out, inverse=False, reps=5):
     ms = c.c_double()
     check(lib.zk_bench_ntt(ctx._h, vec_in._h, int(inverse), vec_out._h, reps, c.byref(ms)))
@@ -513,6 +521,6 @@ def bench_ntt(ctx, vec_in, vec_out, inverse=False, reps=5):
 
 __all__ = [
     "BN254_FR", "BLS12_381_FR", "BLS12_377_FR", "Context", "MultiLinearPolynomial", "CoeffMultilinearPolynomial", "ProductPoly", "SumcheckProof",
-    "SubClaim", "SumcheckProver", "SumcheckVerifier", "Transcript", "ZkError", "fft", "ifft", "fft_internal", "ntt", "bench_ntt", "bench_prove_partial", "bench_evaluate",
+    "SubClaim", "SumcheckProver", "SumcheckVerifier", "Transcript", "ZkError", "fft", "ifft", "fft_internal", "ntt", "bench_ntt", "bench_prove_partial", "bench_evaluate", "bench_evaluate_device",
     "fe_from_int", "fe_from_ints", "fe_to_int", "fe_to_ints", "keccak256", "modulus", "two_adicity", "root_of_unity", "mask", "index_pair",
 ]

@@ -2527,6 +2527,24 @@ extern "C" int32_t zk_bench_evaluate(zk_ctx *c, const zk_mle *t, const uint64_t 
     }
     return ZK_OK;
 }
+// device time of evaluate: `reps` back-to-back enqueues of its launches (no host wait in between) between two HIP events on the
+// context's stream -> average ms per evaluate.  What the roofline of the streaming kernel is priced on (bench.py roofline_evaluate).
+extern "C" int32_t zk_bench_evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point, uint64_t n_point, int32_t reps, double *out_ms) {
+    if (!c || !t || !out_ms || reps <= 0 || (!point && n_point)) return ZK_ERR_BAD_ARG;
+    if (t->ctx != c) return ZK_ERR_CONTEXT_MISMATCH;
+    if (n_point != t->n_vars) return ZK_ERR_EVAL_ARITY;
+    ZKCHK(use_device(c));
+    ZKCHK(evaluate_device(c, t, point, c->d_sums));   // warm: scratch from the pool
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < reps; ++i) ZKCHK(evaluate_device(c, t, point, c->d_sums));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *out_ms = (double)ms / reps;
+    return ZK_OK;
+}
 extern "C" int32_t zk_bench_modmul(zk_ctx *c, int32_t variant, int32_t iters, double *out) {
     if (!c || !out || iters <= 0) return ZK_ERR_BAD_ARG;
     if (variant != 0 && variant != 1) return ZK_ERR_UNSUPPORTED;
