@@ -12,7 +12,7 @@ titles = {"sumcheck_n24": "`python3 tools/prof_sumcheck.py 24 5` (6 prove_partia
           "ntt": "2^24-point NTT (6 forward + 6 inverse)",
           "gkr": "`python3 tools/prof_gkr.py 20 8` (4 zk_gkr_prove + 3 zk_gkr_verify, depth 8, width 2^20, random add/mul wiring)",
           "sumcheck_k3_n20": "`python3 tools/prof_k3.py 20` (6 prove_partial calls on a product of 3 MLEs, D = 3, n = 20: one GKR-shaped layer)",
-          "evaluate": "`python3 tools/prof_evaluate.py` (21 evaluate calls each at n = 18, 19, 20, 21, 24: k_eval_low takes the low 8-12 variables per launch)",
+          "evaluate": "`python3 tools/prof_evaluate.py` (21 evaluate calls each at n = 18, 19, 20, 21, 24: k_eval_stream takes the low 12 / 15 variables at n = 21 / 24, k_eval_low the rest and everything below 21)",
           "fold": "`python3 tools/pmc_fold.py 24 200` (200 launches of the headline kernel k_fold_msb, 2^24 -> 2^23 BN254 Fr)"}
 lines = [f"# rocprofv3 kernel stats `{tag}`: prover, NTT, GKR driver", "",
          "Each section: `rocprofv3 --kernel-trace --stats --output-format csv -- <command>` on one MI355X.", ""]
