@@ -639,6 +639,17 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
             }
             dst = scratch[b];
         }
+        // when at most kEvalHighMax variables remain after this launch its workgroups weight their outputs with eq(point_high, g)
+        // (common.cuh eval_high_weight) and what is left is a plain sum of the 2^H outputs (k_eval_sum) instead of another bulk launch
+        const uint64_t H = cur - L;
+        EvalHighPoint ph = {};
+        if (H >= 1 && H <= (uint64_t)kEvalHighMax) {
+            ph.n = (uint32_t)H;
+            for (uint64_t p = 0; p < H; ++p) {
+                const Fe r = fe_from_u64limbs(point + 4 * (H - 1 - p));   // bit p of the output index <-> variable H-1-p of the point
+                for (int i = 0; i < 8; ++i) ph.r[p][i] = r.v[i];
+            }
+        }
         if (stream) {
             EvalStreamPoint sp = {};
             for (uint64_t p = 0; p < L; ++p) {
@@ -648,21 +659,24 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
             const Fe two128 = {{0, 0, 0, 0, 1, 0, 0, 0}};
             const Fe c128 = fe_from_canonical(two128, P);
             for (int i = 0; i < 8; ++i) sp.c128[i] = c128.v[i];
-            k_eval_stream<<<(uint32_t)n_out, kBlock, 0, c->stream>>>(src, dst, (uint32_t)L, sp, P);
-            if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
-            src = dst;
-            cur -= L;
-            continue;
+            k_eval_stream<<<(uint32_t)n_out, kEvalStreamThreads, 0, c->stream>>>(src, dst, (uint32_t)L, sp, P, ph);
+        } else {
+            EvalLowPoint pt = {};
+            for (uint64_t p = 0; p < L; ++p) {
+                const Fe r = fe_from_u64limbs(point + 4 * (cur - 1 - p));   // index bit p <-> variable cur-1-p (variable 0 is the MSB)
+                for (int i = 0; i < 8; ++i) pt.r[p][i] = r.v[i];
+            }
+            k_eval_low<<<(uint32_t)n_out, kBlock, 0, c->stream>>>(src, dst, (uint32_t)L, pt, P, (flag_seq && L == cur) ? c->h_flag : nullptr, flag_seq, ph);
         }
-        EvalLowPoint pt = {};
-        for (uint64_t p = 0; p < L; ++p) {
-            const Fe r = fe_from_u64limbs(point + 4 * (cur - 1 - p));   // index bit p <-> variable cur-1-p (variable 0 is the MSB)
-            for (int i = 0; i < 8; ++i) pt.r[p][i] = r.v[i];
-        }
-        k_eval_low<<<(uint32_t)n_out, kBlock, 0, c->stream>>>(src, dst, (uint32_t)L, pt, P, (flag_seq && L == cur) ? c->h_flag : nullptr, flag_seq);
         if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
         src = dst;
         cur -= L;
+        if (ph.n && rc == ZK_OK) {   // the outputs carry their weights: the result is their sum
+            k_eval_sum<<<1, kBlock, 0, c->stream>>>(src, (uint32_t)n_out, P, d_out_elem, flag_seq ? c->h_flag : nullptr, flag_seq);
+            if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+            cur = 0;
+            break;
+        }
     }
     auto release = [&]() {
         for (int b = 0; b < 2; ++b)

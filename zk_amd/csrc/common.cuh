@@ -153,6 +153,36 @@ ZK_D Fe fe_wave_sum(Fe s, const FieldParams &P, uint32_t width = 64) {
     if (width > 1) s = fe_add(s, fe_dpp<0x12F>(s), P);
     return s;
 }
+
+// ---- the variables a bulk launch leaves over, applied as a weight on its outputs (round 4) ------------------------------------
+// A bulk launch (k_eval_low, k_eval_stream) writes out[g] = the table restricted in its LOW L variables; when H <= 12 variables
+// remain, workgroup g also multiplies its output by eq(point_high, g) -- H selected factors, multiplied up by ONE otherwise idle wave
+// as a four-level butterfly over a 16-lane row while the other waves build their tables -- so that what is left of evaluate is the
+// plain SUM of the 2^H outputs (k_eval_sum: ~3 us) instead of a second bulk launch with its own tables, products and reduction
+// (10-12 us).  Exact field arithmetic: sum_g eq(hi, g) * out[g] is the same canonical element.
+constexpr int kEvalHighMax = 12;
+struct EvalHighPoint {   // r for bit p of the OUTPUT index g (Montgomery form); n = 0: the outputs are not weighted
+    uint32_t n;
+    uint32_t r[kEvalHighMax][8];
+};
+ZK_D Fe eval_high_weight(const EvalHighPoint &ph, uint64_t g, uint32_t lane, const FieldParams &P) {
+    Fe one;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
+    Fe f = one;
+    for (uint32_t k = 0; k < ph.n; ++k) {   // uniform k: scalar loads from the argument segment, no per-lane indexing of it
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.v[i] = ph.r[k][i];
+        const Fe sel = (g >> k) & 1 ? r : fe_sub(one, r, P);
+        if ((lane & 15) == k) f = sel;
+    }
+    f = fe_mul(f, fe_dpp<0x128>(f), P);   // row_ror 8, 4, 2, 1: every lane of the row ends with the product of all sixteen
+    f = fe_mul(f, fe_dpp<0x124>(f), P);
+    f = fe_mul(f, fe_dpp<0x122>(f), P);
+    f = fe_mul(f, fe_dpp<0x121>(f), P);
+    return f;
+}
 #endif
 
 }  // namespace zk

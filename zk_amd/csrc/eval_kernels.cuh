@@ -119,14 +119,29 @@ ZK_D void eval_normalise(EvalCols &a) {
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_eval_stream(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t L,
-                                                           EvalStreamPoint pt, FieldParams P) {
+// 320 threads: waves 0-3 are the workers described above; wave 4 only multiplies up eq(point_high, blockIdx.x) when the outputs
+// are weighted (ph.n > 0, kernels.cuh eval_high_weight) -- all four worker waves have a table to build -- and then just keeps the
+// barriers company.
+constexpr int kEvalStreamThreads = kBlock + 64;
+__global__ __launch_bounds__(kEvalStreamThreads) void k_eval_stream(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t L,
+                                                                      EvalStreamPoint pt, FieldParams P, EvalHighPoint ph) {
     __shared__ Fe eq[4][16];                       // bits 0-3, 4-6, 7-10, 11-14
+    __shared__ Fe wg;
     __shared__ __attribute__((aligned(16))) uint32_t A[256][12];   // row weights as 9 limbs (+ padding to 48 bytes)
     __shared__ uint32_t red[kBlock / 64][8];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t MB = L - 7, rows = 1u << MB;
+    if (wave == 4) {   // the weight wave: no loads, no rows
+        if (ph.n) {
+            const Fe f = eval_high_weight(ph, blockIdx.x, lane, P);
+            if (lane == 0) wg = f;
+        }
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        return;
+    }
     const uint4 *src = reinterpret_cast<const uint4 *>(in) + (((uint64_t)blockIdx.x << L) << 1) + tid;   // row m: + 256 * m
     constexpr int PF = kEvalStreamPrefetch;
     uint4 x[PF];
@@ -235,6 +250,7 @@ __global__ __launch_bounds__(kBlock) void k_eval_stream(const uint64_t *__restri
             for (int i = 0; i < 8; ++i) o.v[i] = red[wv][i];
             tot = fe_add(tot, o, P);
         }
+        if (ph.n) tot = fe_mul(tot, wg, P);
         fe_store(out, blockIdx.x, tot);
     }
 }

@@ -142,13 +142,49 @@ __global__ __launch_bounds__(kBlock) void k_fold_multi(const uint64_t *in, uint6
 // 0-3, 4-7, 8-L-1; chains of <= 3 multiplications, hidden under the loads); then each thread adds its <= 16 products
 // in[.] * eq_m[xm] UNREDUCED (wide_mac), reduces once, multiplies by its own eq_l[t] = eq_47[t >> 4] * eq_03[t & 15] and the
 // workgroup sums.  Per element: one 512-bit product and 32 bytes read; the remaining n - L variables are a 2^L times smaller table.
+// what is left after a weighted bulk launch: the sum of its n <= 4096 outputs, one workgroup; result (and the completion word)
+// straight into pinned host memory when the caller asks for it
+__global__ __launch_bounds__(kBlock) void k_eval_sum(const uint64_t *__restrict__ in, uint32_t n, FieldParams P, uint64_t *__restrict__ out,
+                                                     volatile uint32_t *flag, uint32_t seq) {
+    __shared__ uint32_t red[kBlock / 64][8];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    Fe acc = fe_zero();
+    Fe x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (tid + 256u * i < n) x[i] = fe_load(in, tid + 256u * i);   // all loads first: one memory round trip
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (tid + 256u * i < n) acc = fe_add(acc, x[i], P);
+    acc = fe_wave_sum(acc, P);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[tid >> 6][i] = acc.v[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int wv = 1; wv < kBlock / 64; ++wv) {
+            Fe o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] = red[wv][i];
+            acc = fe_add(acc, o, P);
+        }
+        fe_store(out, 0, acc);
+        if (flag) {
+            __threadfence_system();
+            *flag = seq;
+        }
+    }
+}
+
 constexpr int kEvalLowMax = 12, kEvalLowMin = 8;   // L = 8: one element per thread
 struct EvalLowPoint {   // r for index bit p (Montgomery form), p = 0 the least significant bit = the LAST variable
     uint32_t r[kEvalLowMax][8];
 };
 __global__ __launch_bounds__(kBlock) void k_eval_low(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t L,
-                                                     EvalLowPoint pt, FieldParams P, volatile uint32_t *flag = nullptr, uint32_t seq = 0) {
+                                                     EvalLowPoint pt, FieldParams P, volatile uint32_t *flag, uint32_t seq, EvalHighPoint ph) {
     __shared__ Fe eq[3][16];
+    __shared__ Fe wg;   // eq(point_high, blockIdx.x) when the outputs are weighted (ph.n > 0): wave 3, which has no table to build
     __shared__ uint32_t red[kBlock / 64][8];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -172,6 +208,9 @@ __global__ __launch_bounds__(kBlock) void k_eval_low(const uint64_t *__restrict_
             acc = k == 0 ? sel : fe_mul(acc, sel, P);
         }
         if (lane < 16) eq[wave][lane] = acc;
+    } else if (ph.n) {
+        const Fe f = eval_high_weight(ph, blockIdx.x, lane, P);
+        if (lane == 0) wg = f;
     }
     __syncthreads();
     WideAcc w;
@@ -198,6 +237,7 @@ __global__ __launch_bounds__(kBlock) void k_eval_low(const uint64_t *__restrict_
             for (int i = 0; i < 8; ++i) o.v[i] = red[wv][i];
             acc = fe_add(acc, o, P);
         }
+        if (ph.n) acc = fe_mul(acc, wg, P);
         fe_store(out, blockIdx.x, acc);
         if (flag) {   // (single-workgroup launches only) completion word for the host, after the result
             __threadfence_system();
