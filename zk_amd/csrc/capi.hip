@@ -643,7 +643,8 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
         // (common.cuh eval_high_weight) and what is left is a plain sum of the 2^H outputs (k_eval_sum) instead of another bulk launch
         const uint64_t H = cur - L;
         EvalHighPoint ph = {};
-        if (H >= 1 && H <= (uint64_t)kEvalHighMax) {
+        static const int weight_mode = getenv("ZK_EVAL_WEIGHT") ? atoi(getenv("ZK_EVAL_WEIGHT")) : 3;   // A/B: bit 0 = k_eval_low, bit 1 = k_eval_stream
+        if (H >= 1 && H <= (uint64_t)kEvalHighMax && (weight_mode & (stream ? 2 : 1))) {
             ph.n = (uint32_t)H;
             for (uint64_t p = 0; p < H; ++p) {
                 const Fe r = fe_from_u64limbs(point + 4 * (H - 1 - p));   // bit p of the output index <-> variable H-1-p of the point
