@@ -585,6 +585,21 @@ def test_evaluate_streaming_kernel_forced_at_small_sizes():
     assert r.returncode == 0 and "evaluate stream ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_evaluate_unweighted_second_stage_still_exact():
+    """ZK_EVAL_WEIGHT=0 switches off the eq(point_high, g) weights of the bulk launches (the shape tables of more than 27 variables
+    take, where more than 12 variables are left after a launch): the second stage is then a bulk launch of its own, as in round 3.
+    Same results, through k_eval_low (n <= 20) and k_eval_stream (n = 21)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = _EVAL_CHILD.replace("(1, 8, 9, 12, 13, 17, 20)", "(1, 8, 9, 12, 13, 17, 20, 21)")
+    r = subprocess.run([sys.executable, "-c", child % root], env=dict(os.environ, ZK_EVAL_WEIGHT="0"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "evaluate ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_evaluate_n24_vs_oracle():
     """The reference's own benchmark operation at the metric's table size: evaluate on 2^24 BN254-Fr elements (k_eval_stream with
     L = 15, then one k_eval_low workgroup) against the oracle's n folds, at a random point and at a point with 0 / 1 / p - 1
