@@ -245,6 +245,223 @@ __global__ __launch_bounds__(kBlock, ZK_KD_MIN_BLOCKS(K, EXTRA, FUSED, SKIP1)) v
     block_reduce_store<NS, SKIP1>(R.sum, partials, P);
 }
 
+// ---- round 0 (sums only) of the two-table degree-2 shapes on carry-free 29-bit columns (round 4) ---------------------------------
+// The first round of a proof has no fold: per pair index it is three products of table values (LEAD form: S(0) = sum lo0 lo1,
+// S(1) = sum hi0 hi1, L = sum (hi0 - lo0)(hi1 - lo1)) and nothing else, i.e. the kernel IS its multiplier.  wide_mac spends 80
+// v_mad_u64_u32 + 80 v_addc + shifts (~195 instructions) on a 256 x 256-bit product; with both operands split into nine 29-bit
+// limbs (2 x ~20 instructions) the 81 limb products go straight into seventeen 64-bit column sums with no carry instruction at
+// all (dot29_mac, the form k_eval_stream uses): ~130 per product.  A column takes 7 pair indices (63 products < 2^58) between
+// carry normalisations; the three sums are converted to 512-bit integers and Montgomery-reduced once per thread, exactly as
+// before, so the partials are the same canonical elements (exact integer sums of the same products).
+// c (17 columns of weight 2^(29 k)) += x * y, both nine 29-bit limbs: 81 v_mad_u64_u32 and nothing else.  Two asm statements (an asm
+// statement takes at most 30 operands): limbs 0-4 of x (columns 0..12), then limbs 5-8 (columns 5..16); i-major, so consecutive
+// instructions write different columns.
+ZK_D void dot29_mac(uint64_t (&c)[17], const uint32_t (&x)[9], const uint32_t (&y)[9]) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM)
+    asm("v_mad_u64_u32 %0, vcc, %13, %18, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %13, %19, %1\n\t"
+        "v_mad_u64_u32 %2, vcc, %13, %20, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %13, %21, %3\n\t"
+        "v_mad_u64_u32 %4, vcc, %13, %22, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %13, %23, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %13, %24, %6\n\t"
+        "v_mad_u64_u32 %7, vcc, %13, %25, %7\n\t"
+        "v_mad_u64_u32 %8, vcc, %13, %26, %8\n\t"
+        "v_mad_u64_u32 %1, vcc, %14, %18, %1\n\t"
+        "v_mad_u64_u32 %2, vcc, %14, %19, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %14, %20, %3\n\t"
+        "v_mad_u64_u32 %4, vcc, %14, %21, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %14, %22, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %14, %23, %6\n\t"
+        "v_mad_u64_u32 %7, vcc, %14, %24, %7\n\t"
+        "v_mad_u64_u32 %8, vcc, %14, %25, %8\n\t"
+        "v_mad_u64_u32 %9, vcc, %14, %26, %9\n\t"
+        "v_mad_u64_u32 %2, vcc, %15, %18, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %15, %19, %3\n\t"
+        "v_mad_u64_u32 %4, vcc, %15, %20, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %15, %21, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %15, %22, %6\n\t"
+        "v_mad_u64_u32 %7, vcc, %15, %23, %7\n\t"
+        "v_mad_u64_u32 %8, vcc, %15, %24, %8\n\t"
+        "v_mad_u64_u32 %9, vcc, %15, %25, %9\n\t"
+        "v_mad_u64_u32 %10, vcc, %15, %26, %10\n\t"
+        "v_mad_u64_u32 %3, vcc, %16, %18, %3\n\t"
+        "v_mad_u64_u32 %4, vcc, %16, %19, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %16, %20, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %16, %21, %6\n\t"
+        "v_mad_u64_u32 %7, vcc, %16, %22, %7\n\t"
+        "v_mad_u64_u32 %8, vcc, %16, %23, %8\n\t"
+        "v_mad_u64_u32 %9, vcc, %16, %24, %9\n\t"
+        "v_mad_u64_u32 %10, vcc, %16, %25, %10\n\t"
+        "v_mad_u64_u32 %11, vcc, %16, %26, %11\n\t"
+        "v_mad_u64_u32 %4, vcc, %17, %18, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %17, %19, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %17, %20, %6\n\t"
+        "v_mad_u64_u32 %7, vcc, %17, %21, %7\n\t"
+        "v_mad_u64_u32 %8, vcc, %17, %22, %8\n\t"
+        "v_mad_u64_u32 %9, vcc, %17, %23, %9\n\t"
+        "v_mad_u64_u32 %10, vcc, %17, %24, %10\n\t"
+        "v_mad_u64_u32 %11, vcc, %17, %25, %11\n\t"
+        "v_mad_u64_u32 %12, vcc, %17, %26, %12"
+        : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(y[8])
+        : "vcc");
+    asm("v_mad_u64_u32 %0, vcc, %12, %16, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %12, %17, %1\n\t"
+        "v_mad_u64_u32 %2, vcc, %12, %18, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %12, %19, %3\n\t"
+        "v_mad_u64_u32 %4, vcc, %12, %20, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %12, %21, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %12, %22, %6\n\t"
+        "v_mad_u64_u32 %7, vcc, %12, %23, %7\n\t"
+        "v_mad_u64_u32 %8, vcc, %12, %24, %8\n\t"
+        "v_mad_u64_u32 %1, vcc, %13, %16, %1\n\t"
+        "v_mad_u64_u32 %2, vcc, %13, %17, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %13, %18, %3\n\t"
+        "v_mad_u64_u32 %4, vcc, %13, %19, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %13, %20, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %13, %21, %6\n\t"
+        "v_mad_u64_u32 %7, vcc, %13, %22, %7\n\t"
+        "v_mad_u64_u32 %8, vcc, %13, %23, %8\n\t"
+        "v_mad_u64_u32 %9, vcc, %13, %24, %9\n\t"
+        "v_mad_u64_u32 %2, vcc, %14, %16, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %14, %17, %3\n\t"
+        "v_mad_u64_u32 %4, vcc, %14, %18, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %14, %19, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %14, %20, %6\n\t"
+        "v_mad_u64_u32 %7, vcc, %14, %21, %7\n\t"
+        "v_mad_u64_u32 %8, vcc, %14, %22, %8\n\t"
+        "v_mad_u64_u32 %9, vcc, %14, %23, %9\n\t"
+        "v_mad_u64_u32 %10, vcc, %14, %24, %10\n\t"
+        "v_mad_u64_u32 %3, vcc, %15, %16, %3\n\t"
+        "v_mad_u64_u32 %4, vcc, %15, %17, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %15, %18, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %15, %19, %6\n\t"
+        "v_mad_u64_u32 %7, vcc, %15, %20, %7\n\t"
+        "v_mad_u64_u32 %8, vcc, %15, %21, %8\n\t"
+        "v_mad_u64_u32 %9, vcc, %15, %22, %9\n\t"
+        "v_mad_u64_u32 %10, vcc, %15, %23, %10\n\t"
+        "v_mad_u64_u32 %11, vcc, %15, %24, %11"
+        : "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]), "+v"(c[16])
+        : "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(y[8])
+        : "vcc");
+#else
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) c[i + j] += (uint64_t)x[i] * y[j];
+#endif
+}
+
+ZK_D void dot29_normalise(uint64_t (&c)[17]) {
+    constexpr uint64_t M = (1ull << 29) - 1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        c[k + 1] += c[k] >> 29;
+        c[k] &= M;
+    }
+}
+// normalised columns (the top one unbounded) -> the 17-word integer redc_wide takes
+ZK_D void dot29_to_wide(const uint64_t (&c)[17], WideAcc &w) {
+    constexpr uint64_t M = (1ull << 29) - 1;
+    uint64_t window = 0;
+    int have = 0, wi = 0;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+        const uint64_t limb = k < 16 ? c[k] : (k == 16 ? (c[16] & M) : (c[16] >> 29));   // 18 limbs below 2^29 (the last: what is left)
+        window |= limb << have;
+        have += 29;
+        if (have >= 32) {
+            if (wi < 17) w.v[wi] = (uint32_t)window;
+            ++wi;
+            window >>= 32;
+            have -= 32;
+        }
+    }
+    if (wi < 17) w.v[wi++] = (uint32_t)window;
+#pragma unroll
+    for (int i = 0; i < 17; ++i)
+        if (i >= wi) w.v[i] = 0;
+}
+template <int EXTRA>
+__global__ __launch_bounds__(kBlock, 2) void k_round0_dot29(FactorPtrs fp, uint64_t q, FieldParams P, uint64_t *__restrict__ partials) {
+    constexpr int NT = 2 + EXTRA;
+    uint64_t c0[17], c1[17], cL[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) c0[k] = c1[k] = cL[k] = 0;
+    Fe sb0 = fe_zero(), sb1 = fe_zero();   // the single-factor term (EXTRA): linear, so it only feeds S(0) and S(1)
+    constexpr bool DEEP = EXTRA == 0;   // two tables: loads two pair indices ahead (as k_round_kd); three: one ahead, or the registers run out
+    Fe cur[NT][2], nxt[DEEP ? NT : 1][2];
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j < q) {
+#pragma unroll
+        for (int f = 0; f < NT; ++f) cur[f][0] = fe_load(fp.in[f], j), cur[f][1] = fe_load(fp.in[f], j + q);
+    }
+    if (DEEP && j + stride < q) {
+#pragma unroll
+        for (int f = 0; f < NT; ++f) nxt[f][0] = fe_load(fp.in[f], j + stride), nxt[f][1] = fe_load(fp.in[f], j + stride + q);
+    }
+    int since = 0;
+    while (j < q) {
+        const uint64_t jn = j + stride, jnn = jn + stride;
+        Fe v[NT][2];
+#pragma unroll
+        for (int f = 0; f < NT; ++f) v[f][0] = cur[f][0], v[f][1] = cur[f][1];
+        if (DEEP) {
+#pragma unroll
+            for (int f = 0; f < NT; ++f) cur[f][0] = nxt[f][0], cur[f][1] = nxt[f][1];
+            if (jnn < q) {
+#pragma unroll
+                for (int f = 0; f < NT; ++f) nxt[f][0] = fe_load(fp.in[f], jnn), nxt[f][1] = fe_load(fp.in[f], jnn + q);
+            }
+        } else if (jn < q) {
+#pragma unroll
+            for (int f = 0; f < NT; ++f) cur[f][0] = fe_load(fp.in[f], jn), cur[f][1] = fe_load(fp.in[f], jn + q);
+        }
+        uint32_t a[9], b[9];
+        split29(v[0][0].v, a);
+        split29(v[1][0].v, b);
+        dot29_mac(c0, a, b);                                  // S(0): lo0 * lo1
+        split29(v[0][1].v, a);
+        split29(v[1][1].v, b);
+        dot29_mac(c1, a, b);                                  // S(1): hi0 * hi1
+        const Fe d0 = fe_sub(v[0][1], v[0][0], P), d1 = fe_sub(v[1][1], v[1][0], P);
+        split29(d0.v, a);
+        split29(d1.v, b);
+        dot29_mac(cL, a, b);                                  // leading coefficient: (hi0 - lo0)(hi1 - lo1)
+        if (EXTRA) {
+            sb0 = fe_add(sb0, v[NT - 1][0], P);
+            sb1 = fe_add(sb1, v[NT - 1][1], P);
+        }
+        if (++since == 7) {
+            dot29_normalise(c0);
+            dot29_normalise(c1);
+            dot29_normalise(cL);
+            since = 0;
+        }
+        j = jn;
+    }
+    dot29_normalise(c0);
+    dot29_normalise(c1);
+    dot29_normalise(cL);
+    Fe sum[3];
+    {
+        WideAcc w;
+        dot29_to_wide(c0, w);
+        sum[0] = redc_wide(w, P);
+        dot29_to_wide(c1, w);
+        sum[1] = redc_wide(w, P);
+        dot29_to_wide(cL, w);
+        sum[2] = redc_wide(w, P);
+    }
+    if (EXTRA) {
+        sum[0] = fe_add(sum[0], sb0, P);
+        sum[1] = fe_add(sum[1], sb1, P);
+    }
+    block_reduce_store<3>(sum, partials, P);
+}
+
 // ---- small fused rounds: one FACTOR per lane, one EVALUATION POINT per lane, four lanes per pair index -----------------
 // Between ~2^10 and ~2^15 pairs a round is pure latency: k_round_kd gives a lane the whole pair index (7 dependent-ish
 // multiplies for k = 2, 14 for k = 3: 4-8 us of a single wave's issue time) while most of the machine idles.  Here the four

@@ -21,6 +21,17 @@ static uint32_t min_blocks() {
 }
 // fused rounds with at most this many pairs (and at least 16) use the four-lanes-per-pair-index kernel (ZK_QUAD_MAX_PAIRS;
 // 0 switches it off)
+// ZK_ROUND0_DOT29: 1 (default) = round 0 of the two-table (2, 2) product on the carry-free kernel; 0 = the wide-accumulator kernel
+// everywhere; 2 = the carry-free kernel for the product-plus-term shape as well (A/B)
+static int round0_dot29_mode() {
+    static const int v = [] {
+        const char *e = getenv("ZK_ROUND0_DOT29");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
+static bool round0_dot29() { return round0_dot29_mode() != 0; }
+static bool round0_dot29_extra() { return round0_dot29_mode() == 2; }
 static uint64_t quad_max_pairs() {
     static const uint64_t v = [] {
         const char *e = getenv("ZK_QUAD_MAX_PAIRS");
@@ -73,7 +84,8 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
         const int shl = k * 10 + (int)D;
         bool done = true;
         if (!fused) {
-            if (shl == 22) k_round_kd<2, 2, false, 0, false, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+            if (shl == 22 && round0_dot29()) k_round0_dot29<0><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, lc.d_partials);
+            else if (shl == 22) k_round_kd<2, 2, false, 0, false, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
             else k_round_kd<3, 3, false, 0, false, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
             if (skip1) *skip1 = false;
         } else if (skip1 && *skip1) {
@@ -149,7 +161,10 @@ int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, ui
     if (!lead) lead = &no_lead;
     if (*lead && shape == 22 && (!fused || (skip1 && *skip1))) {   // the GKR layer polynomial W*H + B: sums-only or fused + SKIP1
         if (!fused) {
-            k_round_kd<2, 2, false, 1, false, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+            // (the carry-free round-0 kernel with a third table has no registers left for the second prefetch buffer and measures
+            // 0.1-0.4 % SLOWER on the GKR driver: profiles/r04_round0_dot29_ab.log; ZK_ROUND0_DOT29=2 selects it for A/B runs)
+            if (round0_dot29_extra()) k_round0_dot29<1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, lc.d_partials);
+            else k_round_kd<2, 2, false, 1, false, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
             if (skip1) *skip1 = false;
         } else {
             k_round_kd<2, 2, true, 1, true, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
