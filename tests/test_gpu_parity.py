@@ -626,7 +626,7 @@ def test_skip1_rounds_bit_exact():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = {k: v for k, v in os.environ.items()
-            if k not in ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES", "ZK_LEAD_MIN_PAIRS")}
+            if k not in ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES", "ZK_LEAD_MIN_PAIRS", "ZK_ROUND0_DOT29")}
     runs = [
         # SKIP1 kernels everywhere (no quad kernel, no pipeline: they would take the small rounds)
         dict(ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0"),
@@ -644,6 +644,10 @@ def test_skip1_rounds_bit_exact():
         dict(ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="11,12,13,15"),
         # LEAD in round 0 only (sums-only kernel), everything else default
         dict(ZK_LEAD_MIN_PAIRS="1", ZK_CHECK_SIZES="3,9,14,16"),
+        # round 0 on the wide-accumulator kernel (k_round_kd<2,2,sums only,LEAD>: the A/B fallback of k_round0_dot29) ...
+        dict(ZK_ROUND0_DOT29="0", ZK_LEAD_MIN_PAIRS="1", ZK_CHECK_SIZES="3,9,14"),
+        # ... and the carry-free round-0 kernel for the product-plus-term shape as well (k_round0_dot29<1>, not selected by default)
+        dict(ZK_ROUND0_DOT29="2", ZK_LEAD_MIN_PAIRS="1", ZK_CHECK_SIZES="3,9,13,14"),
     ]
     for extra in runs:
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "skip1_check.py")], env=dict(base, **extra), capture_output=True,
