@@ -282,6 +282,53 @@ def test_round_sums_lazy_reduction_worst_case():
         assert np.array_equal(pp.round_sums(2), oracle_round_sums(field, n_vars, tabs, 2))
 
 
+_LAZY_CHILD = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import zk_amd
+from oracle import binding as orc
+checked = 0
+for field in (zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR):
+    c = zk_amd.Context(field, 0)
+    p = zk_amd.modulus(field)
+    for k, D, n in ((2, 2, 15), (2, 2, 16), (3, 3, 15), (2, 1, 15), (2, 3, 15)):
+        tabs = [orc.from_ints(field, [p - 1]).repeat(1 << n, axis=0) for _ in range(k)]
+        want = []
+        for t in range(D + 1):
+            a = orc.from_int(field, t)[None, :]
+            folded = [orc.mle_partial_evaluate(field, n, tb, 0, a) for tb in tabs]
+            acc = np.zeros(4, dtype=np.uint64)
+            for e in orc.prod_reduce(field, n - 1, folded):
+                acc = orc.add(field, acc, e)
+            want.append(acc)
+        pp = zk_amd.ProductPoly.new([zk_amd.MultiLinearPolynomial.new(c, n, t) for t in tabs])
+        assert np.array_equal(pp.round_sums(D), np.stack(want)), (field, k, D, n)
+        # and a whole proof: the fused rounds accumulate as many products per lane
+        claimed = orc.add(field, want[0], want[1])
+        rp, ch = orc.sumcheck_prove(field, n, tabs, D, claimed, False)
+        proof, got_ch = zk_amd.SumcheckProver(D).prove_partial(pp, claimed)
+        assert np.array_equal(proof.round_polys, rp) and np.array_equal(got_ch, ch), (field, k, D, n)
+        checked += 1
+print("lazy ok", checked)
+"""
+
+
+def test_unreduced_accumulators_at_their_product_limit():
+    """kMaxLazy products of (p - 1)^2 per lane before the one Montgomery reduction: a child process with ZK_ROUND_MIN_BLOCKS=1 makes
+    the round kernels run with as FEW workgroups as the limit allows (2^14-2^15 pairs on 2-4 workgroups: every thread at the limit),
+    all tables p - 1 -- the largest possible unreduced sums, the top limb of the wide accumulator at its maximum -- on all three
+    fields, round sums and whole proofs against the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _LAZY_CHILD % root], env=dict(os.environ, ZK_ROUND_MIN_BLOCKS="1", ZK_QUAD_MAX_PAIRS="0",
+                                                                           ZK_PIPE_MAX_PAIRS="0", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "lazy ok" in r.stdout, r.stdout + r.stderr
+
+
 # ------------------------------------------------------------------ prover vs oracle (bit-exact transcript)
 @pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k,D,n_vars", [(1, 1, 12), (2, 2, 12), (3, 3, 10), (2, 1, 7), (1, 3, 6), (4, 4, 8), (2, 2, 1),
