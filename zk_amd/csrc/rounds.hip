@@ -48,10 +48,20 @@ static uint32_t launch_quad(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint
     k_round_quad<K, D, EXTRA><<<(uint32_t)g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
     return (uint32_t)g;
 }
-static inline uint32_t round_grid(uint64_t q) {
+// the product-plus-term shape (a GKR layer: three tables, 2300-2700 instructions per pair index) is better off with ONE wave per SIMD
+// and twice the pairs per thread below 2^17 pairs: 7.57 -> 7.50 ms on the depth-8 x 2^20 driver (profiles/r04_round_min_blocks_ab.log);
+// ZK_ROUND_MIN_BLOCKS overrides both
+static uint32_t min_blocks_plus1() {
+    static const uint32_t v = [] {
+        const char *e = getenv("ZK_ROUND_MIN_BLOCKS");
+        return e ? (uint32_t)atoi(e) : 256u;
+    }();
+    return v;
+}
+static inline uint32_t round_grid(uint64_t q, uint32_t min_b = min_blocks()) {
     uint64_t b = (q + (uint64_t)kBlock * kMaxLazy - 1) / ((uint64_t)kBlock * kMaxLazy);   // kMaxLazy pairs per thread
     const uint64_t one_pair = (q + kBlock - 1) / kBlock;                                    // one pair per thread
-    const uint64_t floor_b = one_pair < min_blocks() ? one_pair : min_blocks();
+    const uint64_t floor_b = one_pair < min_b ? one_pair : min_b;
     if (b < floor_b) b = floor_b;
     return (uint32_t)(b ? b : 1);
 }
@@ -154,7 +164,7 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
 // Terms {k, 1}: the k-factor product plus one single-factor term in one pass (fp lists the k factors, then the extra one).
 int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused,
                        const uint64_t *d_r, uint32_t *out_grid, bool *skip1, bool *lead) {
-    const uint32_t g = round_grid(q);
+    const uint32_t g = round_grid(q, min_blocks_plus1());
     if ((uint64_t)g * (D + 1) > lc.capacity_elems) return kLaunchUnsupported;
     const int shape = k * 10 + (int)D;
     bool no_lead = false;
