@@ -618,11 +618,20 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
         return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)21;
     }();
     for (int pass = 0; bulk_low && cur >= 8 && rc == ZK_OK; ++pass) {
-        const bool stream = cur >= stream_min && cur >= (uint64_t)kEvalStreamMin + 9;   // leaves >= 9 variables: >= 512 workgroups
+        // the streaming launch leaves 9 variables (512 workgroups), 8 at 21 variables: every workgroup spends ~2600 instructions per
+        // wave on its weight tables before the first product, so at 2^21 elements half as many workgroups with twice the rows win
+        // (device time 31.2 -> 29.1 us; 10 left: 54 us -- profiles/r04_evaluate_stream_grid_ab.log).  ZK_EVAL_STREAM_LEAVE overrides.
+        static const uint64_t leave_env = [] {
+            const char *e = getenv("ZK_EVAL_STREAM_LEAVE");
+            const uint64_t v = e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)0;
+            return v == 0 ? (uint64_t)0 : (v < 7 ? (uint64_t)7 : (v > (uint64_t)kEvalHighMax ? (uint64_t)kEvalHighMax : v));
+        }();
+        const uint64_t stream_leave = leave_env ? leave_env : (cur <= 21 ? (uint64_t)8 : (uint64_t)9);
+        const bool stream = cur >= stream_min && cur >= (uint64_t)kEvalStreamMin + stream_leave;
         uint64_t L = cur <= (uint64_t)kEvalLowMax ? cur : cur - 8;
         if (L > (uint64_t)kEvalLowMax) L = kEvalLowMax;
         if (L < (uint64_t)kEvalLowMin) L = kEvalLowMin;   // cur >= 13 here
-        if (stream) L = cur - 9 < (uint64_t)kEvalStreamMax ? cur - 9 : (uint64_t)kEvalStreamMax;
+        if (stream) L = cur - stream_leave < (uint64_t)kEvalStreamMax ? cur - stream_leave : (uint64_t)kEvalStreamMax;
         const uint64_t n_out = 1ull << (cur - L);
         uint64_t *dst = d_out_elem;
         if (L != cur) {
