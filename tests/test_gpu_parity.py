@@ -627,9 +627,12 @@ def test_evaluate_streaming_kernel_forced_at_small_sizes():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", _EVAL_STREAM_CHILD % root], env=dict(os.environ, ZK_EVAL_STREAM_MIN="19"),
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "evaluate stream ok" in r.stdout, r.stdout + r.stderr
+    # 9 variables left (512 workgroups: L = 10, 11, 12, 13) and the shipped choice (8 left up to 21 variables: L = 11, 12, 13, 13)
+    for extra in (dict(ZK_EVAL_STREAM_LEAVE="9"), dict()):
+        env = {k: v for k, v in os.environ.items() if k != "ZK_EVAL_STREAM_LEAVE"}
+        r = subprocess.run([sys.executable, "-c", _EVAL_STREAM_CHILD % root], env=dict(env, ZK_EVAL_STREAM_MIN="19", **extra),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "evaluate stream ok" in r.stdout, str(extra) + r.stdout + r.stderr
 
 
 def test_evaluate_unweighted_second_stage_still_exact():
