@@ -165,6 +165,7 @@ struct EvalHighPoint {   // r for bit p of the OUTPUT index g (Montgomery form);
     uint32_t n;
     uint32_t r[kEvalHighMax][8];
 };
+ZK_D uint32_t eval_high_lane(uint32_t n) { return n > 8 ? 15u : n > 4 ? 7u : n > 2 ? 3u : n > 1 ? 1u : 0u; }
 ZK_D Fe eval_high_weight(const EvalHighPoint &ph, uint64_t g, uint32_t lane, const FieldParams &P) {
     Fe one;
 #pragma unroll
@@ -177,11 +178,13 @@ ZK_D Fe eval_high_weight(const EvalHighPoint &ph, uint64_t g, uint32_t lane, con
         const Fe sel = (g >> k) & 1 ? r : fe_sub(one, r, P);
         if ((lane & 15) == k) f = sel;
     }
-    f = fe_mul(f, fe_dpp<0x128>(f), P);   // row_ror 8, 4, 2, 1: every lane of the row ends with the product of all sixteen
-    f = fe_mul(f, fe_dpp<0x124>(f), P);
-    f = fe_mul(f, fe_dpp<0x122>(f), P);
-    f = fe_mul(f, fe_dpp<0x121>(f), P);
-    return f;
+    // row_ror 8, 4, 2, 1: every lane of the row ends with the product of all sixteen.  A level whose partner lanes all hold `one`
+    // is skipped (ph.n is uniform): 8 factors -- every table of up to 20 variables -- take three dependent multiplications, not four
+    if (ph.n > 8) f = fe_mul(f, fe_dpp<0x128>(f), P);
+    if (ph.n > 4) f = fe_mul(f, fe_dpp<0x124>(f), P);
+    if (ph.n > 2) f = fe_mul(f, fe_dpp<0x122>(f), P);
+    if (ph.n > 1) f = fe_mul(f, fe_dpp<0x121>(f), P);
+    return f;   // complete in lane eval_high_lane(ph.n) (row_ror:m makes lane i take lane i - m: the last lane of the factors' power-of-two block has them all)
 }
 #endif
 

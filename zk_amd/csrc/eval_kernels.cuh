@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kEvalStreamThreads) void k_eval_stream(const uint64
     if (wave == 4) {   // the weight wave: no loads, no rows
         if (ph.n) {
             const Fe f = eval_high_weight(ph, blockIdx.x, lane, P);
-            if (lane == 0) wg = f;
+            if (lane == eval_high_lane(ph.n)) wg = f;
         }
         __syncthreads();
         __syncthreads();

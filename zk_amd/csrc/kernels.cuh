@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void k_eval_low(const uint64_t *__restrict_
         if (lane < 16) eq[wave][lane] = acc;
     } else if (ph.n) {
         const Fe f = eval_high_weight(ph, blockIdx.x, lane, P);
-        if (lane == 0) wg = f;
+        if (lane == eval_high_lane(ph.n)) wg = f;
     }
     __syncthreads();
     WideAcc w;
