@@ -13,8 +13,11 @@ step, so there is no data-path collective -- and the sumcheck prover on the same
 RCCL all-reduce of (D+1)*8 lanes per round, inside zk_shard_prover_run) is timed next to it, with the per-round collective
 latency.  The sumcheck prover wall-clock (second half of the metric) is `sumcheck_prover_wall_clock_ms`.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; N > 1 is launched by torch.distributed.run, one rank per
-GPU.  Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.  N > 1 runs one rank per GPU over RCCL:
+either the caller launches it (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`,
+WORLD_SIZE set: rank 0 prints the line), or the plain command is given and bench.py starts that same launcher itself as a
+child job (self_launch: the parent makes no GPU call, relays rank 0's line and the job's exit code, enforces
+--launch-timeout).
 """
 import argparse
 import json
@@ -421,6 +424,52 @@ def sharded_leg(args, ctx, field, dist, torch, rank, world, ns, tdev, rehearse, 
     return 0 if ok else 5
 
 
+def self_launch(n, argv, limit_s):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: run the SAME command under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` (one fresh child process per GPU, RCCL between them) and
+    relay rank 0's JSON line.  Called before torch / zk_amd are imported: this parent never initialises the GPU, never
+    os.exec*s; it waits for the child job, ends its whole process group when the wall-clock limit passes, and returns the
+    job's exit code (124 on the limit, 1 when the job printed no line)."""
+    import signal
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=limit_s)
+        rc = proc.returncode
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)
+            out, _ = proc.communicate(timeout=20)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            out, _ = proc.communicate()
+        except ProcessLookupError:
+            out = ""
+        sys.stderr.write(f"bench.py: the {n}-rank job passed its {limit_s:.0f} s limit and was ended\n")
+        rc = 124
+    lines = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
+    for ln in (out or "").splitlines():
+        if not ln.startswith("{"):
+            sys.stderr.write(ln + "\n")
+    if os.environ.get("ZK_BENCH_TRACE_PARENT_IMPORTS") == "1":
+        sys.stderr.write(f"bench.py: parent_imported_torch={'torch' in sys.modules} parent_imported_zk_amd={'zk_amd' in sys.modules}\n")
+    if lines:
+        print(lines[-1], flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the child job ended without a JSON line\n")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -437,7 +486,16 @@ def main():
     ap.add_argument("--prewarm-ms", type=float, default=250.0,
                     help="untimed folds before the W warm-up steps so that the shader clock has ramped (the parity gate leaves the "
                          "GPU idle for seconds); reported in the line")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="plain `bench.py --gpus N` (N > 1, no torchrun): wall-clock limit of the N-rank child job, seconds")
     args = ap.parse_args()
+
+    if args.gpus < 1 or args.gpus & (args.gpus - 1):
+        raise SystemExit("the table shards by index mod N: --gpus must be a power of two")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process has made no HIP call and imported neither torch nor zk_amd; it only
+        # starts the N ranks as FRESH children and relays their line
+        sys.exit(self_launch(args.gpus, sys.argv[1:], args.launch_timeout))
 
     import numpy as np
     import torch
@@ -445,12 +503,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    if world & (world - 1):
-        raise SystemExit("the table shards by index mod N: N must be a power of two")
 
     import zk_amd
 

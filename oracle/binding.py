@@ -96,6 +96,16 @@ def two_adicity(field):
     return _check(_lib.orc_field_two_adicity(field))
 
 
+def field_constants(field):
+    """(-p^-1 mod 2^64, R mod p, R^2 mod p, TWO_ADIC_ROOT_OF_UNITY as a canonical integer) as the C oracle derived them"""
+    inv = _c.c_uint64(0)
+    r1, r2, root = (np.zeros(4, dtype=np.uint64) for _ in range(3))
+    _lib.orc_field_constants.argtypes = [_c.c_int, _c.POINTER(_c.c_uint64), _u64p, _u64p, _u64p]
+    _check(_lib.orc_field_constants(field, _c.byref(inv), _p(r1), _p(r2), _p(root)))
+    as_int = lambda a: sum(int(v) << (64 * i) for i, v in enumerate(a))
+    return int(inv.value), as_int(r1), as_int(r2), to_int(field, root)
+
+
 def _binop(fn):
     def f(field, a, b):
         a, b = _arr(a, 1), _arr(b, 1)

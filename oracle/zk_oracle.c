@@ -179,6 +179,18 @@ int orc_field_modulus(int field, u64 out[4]) {
     memcpy(out, F->p, 32);
     return ORC_OK;
 }
+/* the Montgomery constants and the two-adic root exactly as this file derived them (tests pin them to the literals the
+ * arkworks / zkcrypto / halo2curves field definitions publish): -p^-1 mod 2^64, R mod p, R^2 mod p as plain integers,
+ * TWO_ADIC_ROOT_OF_UNITY in Montgomery form */
+int orc_field_constants(int field, u64 *inv, u64 r1[4], u64 r2[4], u64 root[4]) {
+    const fparams *F = field_get(field);
+    if (!F) return ORC_ERR_BAD_FIELD;
+    if (inv) *inv = F->inv;
+    if (r1) memcpy(r1, F->r1, 32);
+    if (r2) memcpy(r2, F->r2, 32);
+    if (root) memcpy(root, F->root, 32);
+    return ORC_OK;
+}
 int orc_field_two_adicity(int field) {
     const fparams *F = field_get(field);
     return F ? (int)F->two_adicity : ORC_ERR_BAD_FIELD;

@@ -52,6 +52,9 @@ enum {
 /* ---- field (ark-ff 0.5.0 PrimeField semantics) ---- */
 int orc_field_modulus(int field, uint64_t out[4]);
 int orc_field_two_adicity(int field);
+/* -p^-1 mod 2^64, R mod p, R^2 mod p (plain integers, 4 LE limbs) and TWO_ADIC_ROOT_OF_UNITY (Montgomery form) as derived at
+ * first use from (p, generator, two-adicity); any pointer may be NULL */
+int orc_field_constants(int field, uint64_t *inv, uint64_t r1[4], uint64_t r2[4], uint64_t root[4]);
 void orc_add(int field, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 void orc_sub(int field, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 void orc_mul(int field, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);

@@ -21,20 +21,28 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, extra_env=None):
-    env = dict(os.environ, ZK_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1", **(extra_env or {}))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "40", "--warmup", "5",
-           "--prewarm-ms", "20"]
+def _run(world, extra_env=None, plain=False):
+    """plain = the command exactly as the driver gives it at N = 1, with N = world: `python3 bench.py --gpus N --steps K --warmup W`
+    and no launcher environment (bench.py self_launch starts the ranks); otherwise the driver's documented N > 1 launch line"""
+    env = dict(os.environ, ZK_BENCH_REHEARSE="1", **(extra_env or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "40", "--warmup", "5", "--prewarm-ms", "20"]
+    if plain:
+        cmd = [sys.executable] + tail
+    else:
+        env["MASTER_ADDR"] = "127.0.0.1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port())] + tail
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     return r, lines
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
-def test_bench_ranks_on_one_gpu(world):
-    r, lines = _run(world)
+@pytest.mark.parametrize("world,plain", [(2, True), (4, True), (2, False)])
+def test_bench_ranks_on_one_gpu(world, plain):
+    r, lines = _run(world, plain=plain)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
@@ -44,6 +52,7 @@ def test_bench_ranks_on_one_gpu(world):
     assert d["value"] > 0 and d["roofline"]["algorithmic_bytes"] == 48 << lv
     ex = d["extra"]
     assert "sharded_error" not in ex and "sharded_ntt_error" not in ex, ex
+    assert ex["comm_confirms_n_ranks"] is True and ex["comm_rank_ids"] == list(range(world))
     assert ex["sharded_proof_verified"] is True
     assert ex["sharded_proof_identical_on_all_ranks"] is True
     assert ex["sharded_proof_equals_unsharded_proof"] is True
@@ -69,3 +78,29 @@ def test_bench_world1_under_torchrun_matches_the_plain_line_shape():
     assert "sharded_error" not in ex, ex
     assert ex["sharded_proof_verified"] is True and ex["sharded_proof_equals_unsharded_proof"] is True
     assert 0.3 < d["roofline"]["frac"] < 1.0
+
+
+def test_plain_multi_gpu_command_launches_children_and_never_hangs():
+    """CPU box (no GPU): `python bench.py --gpus 2` must start the two ranks as child processes, relay their failure (no device
+    here) as a non-zero exit with no JSON line, and the parent itself must not import torch (it must never touch the GPU)."""
+    env = dict(os.environ, ZK_BENCH_TRACE_PARENT_IMPORTS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            pytest.skip("GPU box: the plain command is covered by test_bench_ranks_on_one_gpu")
+    except ImportError:
+        pass
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--launch-timeout", "240"], env=env, capture_output=True, text=True, timeout=400, cwd=ROOT)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "parent_imported_torch=False" in r.stderr, r.stderr[-1500:]
+
+
+def test_gpus_must_be_a_power_of_two():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], capture_output=True, text=True, timeout=60,
+                       cwd=ROOT)
+    assert r.returncode != 0 and "power of two" in r.stderr

@@ -225,3 +225,83 @@ def test_bench_fused_parallel_prover_equals_the_restatement(field, n, k, D):
     for threads in (1, 3):
         rp, ch, used = orc.sumcheck_prove_fused_parallel(field, n, tabs, D, s, threads)
         assert used >= 1 and np.array_equal(rp, want_rp) and np.array_equal(ch, want_ch)
+
+
+# ---- published third-party constants (the only external pin this image allows: no Rust toolchain, ark-ff is not vendored) ----
+# Literals as the field definitions publish them -- ark-bn254 / ark-bls12-381 / ark-bls12-377 `FrConfig` (MODULUS, GENERATOR,
+# TWO_ADICITY, TWO_ADIC_ROOT_OF_UNITY as decimal strings), zkcrypto `bls12_381::Scalar` (INV, R, R2, ROOT_OF_UNITY) and
+# halo2curves / `bn` `Fr` (INV, R, R2) -- typed here, NOT computed: the oracle derives every one of them at run time from
+# (p, generator, two-adicity) alone (oracle/zk_oracle.c field_get), so agreement is a check of that derivation and of the
+# Montgomery core against numbers the libraries the reference links carry.  Used by fft/src/lib.rs:6,14 (get_root_of_unity),
+# transcript/src/lib.rs:27-30 (from_be_bytes_mod_order) and every field op of the path.
+PUBLISHED = {
+    orc.BN254_FR: dict(
+        p=21888242871839275222246405745257275088548364400416034343698204186575808495617, generator=5, two_adicity=28,
+        root=19103219067921713944291392827692070036145651957329286315305642004821462161904,
+        inv=0xc2e1f593efffffff,
+        R=0x0e0a77c19a07df2f666ea36f7879462e36fc76959f60cd29ac96341c4ffffffb,
+        R2=0x0216d0b17f4e44a58c49833d53bb808553fe3ab1e35c59e31bb8e645ae216da7),
+    orc.BLS12_381_FR: dict(
+        p=52435875175126190479447740508185965837690552500527637822603658699938581184513, generator=7, two_adicity=32,
+        root=10238227357739495823651030575849232062558860180284477541189508159991286009131,
+        inv=0xfffffffeffffffff,
+        R=0x1824b159acc5056f998c4fefecbc4ff55884b7fa0003480200000001fffffffe,
+        R2=0x0748d9d99f59ff1105d314967254398f2b6cedcb87925c23c999e990f3f29c6d),
+    orc.BLS12_377_FR: dict(
+        p=8444461749428370424248824938781546531375899335154063827935233455917409239041, generator=22, two_adicity=47,
+        root=8065159656716812877374967518403273466521432693661810619979959746626482506078,
+        inv=0x0a117fffffffffff,
+        R=0x0d4bda322bbb9a9d16d81575512c0fee7257f50f6ffffff27d1c7ffffffffff3,
+        R2=0x011fdae7eff1c939a7cc008fe5dc8593cc2c27b58860591f25d577bab861857b),
+}
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_published_field_constants(field):
+    c = PUBLISHED[field]
+    assert orc.modulus(field) == c["p"] and orc.two_adicity(field) == c["two_adicity"]
+    inv, r1, r2, root = orc.field_constants(field)
+    assert inv == c["inv"] and r1 == c["R"] and r2 == c["R2"] and root == c["root"]
+    # F::one() in memory is R mod p (the layout that crosses the C ABI), and the independent big-int model agrees
+    assert sum(int(v) << (64 * i) for i, v in enumerate(orc.from_int(field, 1))) == c["R"]
+    assert pow(c["generator"], (c["p"] - 1) >> c["two_adicity"], c["p"]) == c["root"]
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_root_of_unity_is_the_published_root_squared_down(field):
+    """F::get_root_of_unity(2^k) = TWO_ADIC_ROOT_OF_UNITY^(2^(s-k)) for every k <= s, None above (fft/src/lib.rs:6,14)"""
+    c = PUBLISHED[field]
+    p, s = c["p"], c["two_adicity"]
+    for k in range(s + 1):
+        w = orc.to_int(field, orc.root_of_unity(field, 1 << k))
+        assert w == pow(c["root"], 1 << (s - k), p), k
+        assert pow(w, 1 << k, p) == 1 and (k == 0 or pow(w, 1 << (k - 1), p) == p - 1)
+    with pytest.raises(orc.OracleError):
+        orc.root_of_unity(field, 1 << (s + 1))
+
+
+def test_bn254_root_of_unity_2p24_literal():
+    """the omega the 2^24-point NTT of config 5 uses: published root squared four times"""
+    p = PUBLISHED[orc.BN254_FR]["p"]
+    w24 = pow(PUBLISHED[orc.BN254_FR]["root"], 16, p)
+    assert orc.to_int(orc.BN254_FR, orc.root_of_unity(orc.BN254_FR, 1 << 24)) == w24
+    assert pow(w24, 1 << 23, p) == p - 1
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_from_be_bytes_mod_order_reduces_values_at_and_above_p(field):
+    """transcript/src/lib.rs:27-30: a 32-byte digest is an integer below 2^256 that may exceed p (up to 5.2 p on BN254): the
+    challenge is that integer mod p; to_bytes_be gives the canonical integer back"""
+    p = PUBLISHED[field]["p"]
+    cases = [p, p + 1, 2 * p - 1, 2 * p, (1 << 256) - 1, (1 << 255) + 12345, p - 1, 0, 1, ((1 << 256) - 1) // p * p, ((1 << 256) - 1) // p * p - 1]
+    for v in cases:
+        got = orc.from_be_bytes_mod_order(field, v.to_bytes(32, "big"))
+        assert orc.to_int(field, got) == v % p, hex(v)
+        assert orc.to_bytes_be(field, got) == (v % p).to_bytes(32, "big")
+    # a Keccak-256 digest of a public vector as the challenge source (sha3 KAT above)
+    d = orc.keccak256(b"abc")
+    assert d.hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+    assert orc.to_int(field, orc.from_be_bytes_mod_order(field, d)) == int.from_bytes(d, "big") % p
+    # longer and shorter inputs (ark's from_be_bytes_mod_order takes any length)
+    for b in (b"\x01", bytes(range(1, 41)), b"\xff" * 64):
+        assert orc.to_int(field, orc.from_be_bytes_mod_order(field, b)) == int.from_bytes(b, "big") % p
