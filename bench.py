@@ -727,12 +727,12 @@ def main():
             for k in (2, 3):
                 pk = zk_amd.ProductPoly.new(tabs[:k])
                 pk.prod_reduce_device().free()
-                row(f"prod_reduce_k{k}_2p24", timed(lambda: pk.prod_reduce_device()), (k + 1) * (32 << n), f"k_prod_reduce_run: {k} tables read, one written ({k - 1} saturated multiplications per element: VALU-bound from k = 3)")
+                row(f"prod_reduce_k{k}_2p24", timed(lambda: pk.prod_reduce_device()), (k + 1) * (32 << n), f"k_prod_reduce_run: {k} tables read, one written ({k - 1} carry-free table x table multiplications per element, fe_mul_tt)")
             asg = tr2.sample_n_field_elements(field, 1)
             for v in (1, n // 2, n - 1):
                 tabs[0].partial_evaluate(v, asg).free()
                 row(f"partial_evaluate_2p24_var{v}", timed(lambda: tabs[0].partial_evaluate(v, asg)), 48 << n,
-                    f"{'k_fold_run' if n - 1 - v >= 6 else 'k_fold'} at initial_var = {v} (index bit {n - 1 - v}), through the allocating call: 2^24 read, 2^23 written")
+                    f"{'k_fold_run' if n - 1 - v >= 6 else 'k_fold_low'} at initial_var = {v} (index bit {n - 1 - v}), through the allocating call: 2^24 read, 2^23 written")
             tabs[0].partial_evaluate(0, asg).free()
             row("partial_evaluate_2p24_var0", timed(lambda: tabs[0].partial_evaluate(0, asg)), 48 << n, "k_fold_msb through the allocating call")
             t1 = time.perf_counter()
@@ -761,9 +761,10 @@ def main():
                 ctx.synchronize()
                 ts.append(time.perf_counter() - t1)
                 ev_t.free()
-            row("coeff_to_evaluation_2p24_1k_terms", sorted(ts)[1], (512 << 20) + ((n + 2) // 3) * (60 << n),
-                "zeroing the table + k_scatter_terms + 8 k_zeta_multi<3> launches (three index bits each: 2^24 elements read, 7/8 of them written); "
-                "bytes = what those passes move")
+            row("coeff_to_evaluation_2p24_1k_terms", sorted(ts)[1], 32 << n,
+                "k_zeta_first (11 index bits per 2^11-entry LDS tile, built from the sorted term list: the table is written, never read) + "
+                "k_zeta_tile x 2 (7 and 6 index bits, one read and one write each); algorithmic bytes = the table written once (32 * 2^24); "
+                "the three passes move 5 x that (PMC: profiles/r05_zeta_ab_and_pmc.log)")
             extra["rows_2p24"] = rows
             # config[3]: GKR-shaped load -- no gkr crate exists in the reference; what it would call is
             # prove_partial on one ProductPoly per layer: depth 8, width 2^20, product of 3 MLEs, degree 3

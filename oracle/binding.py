@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libzk_oracle.so")
+# ZK_ORACLE_LIB: another build of the same source (the sanitizer build of `make -C oracle asan`, tools/run_sanitized.sh)
+_LIB_PATH = os.environ.get("ZK_ORACLE_LIB") or os.path.join(_HERE, "libzk_oracle.so")
 
 BN254_FR, BLS12_381_FR, BLS12_377_FR = 0, 1, 2
 

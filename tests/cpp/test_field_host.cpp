@@ -1,6 +1,7 @@
 // Host-side check of the product's field arithmetic (zk_amd/csrc/field.cuh compiled for the CPU, no GPU needed):
 // the carry-free 9x29-bit multiplier fe_mul29(a, prepare(c)) must equal the saturated Montgomery product fe_mul(a, c)
 // bit for bit -- 200k random pairs plus edge values (0, 1, 2, p-1) per field, all three fields -- and the two-product form
+// fe_mul_tt(a, c) (left operand split five bits lower, nothing prepared: prod_reduce) must equal it too, and
 // fe_dot2_29(a, prepare(c), a2, prepare(c2)) must equal fe_mul(a, c) + fe_mul(a2, c2) (one reduction for both products).  (fe_mul itself is pinned
 // against the oracle through the C ABI host helpers and every GPU parity test.)  Built with clang++ (field.cuh uses
 // __builtin_addc).  Driven by tests/test_gpu_cpp_host.py.
@@ -17,6 +18,7 @@ int main(){
     Fe edge[4]={fe_zero(), fe_one(P), pm1, fe_from_u32(2,P)};
     for(int it=0;it<200000;++it){ Fe a = it<16? edge[it&3] : rnd(); Fe c = it<16? edge[(it>>2)&3] : rnd();
       Fe want=fe_mul(a,c,P); Fe got=fe_mul29(a,mul29_prepare(c,P),P); if(!fe_eq(want,got)){ if(bad<5) printf("MISMATCH field %d it %d\n",f,it); ++bad; }
+      Fe gtt=fe_mul_tt(a,c,P); if(!fe_eq(want,gtt)){ if(bad<5) printf("MUL_TT MISMATCH field %d it %d\n",f,it); ++bad; }   // table x table product (prod_reduce)
       Fe a2 = it<64? edge[(it>>4)&3] : rnd(); Fe c2 = it<64? edge[(it>>2)&3] : rnd();
       Fe want2=fe_add(want,fe_mul(a2,c2,P),P); Fe got2=fe_dot2_29(a,mul29_prepare(c,P),a2,mul29_prepare(c2,P),P); if(!fe_eq(want2,got2)){ if(bad<5) printf("DOT2 MISMATCH field %d it %d\n",f,it); ++bad; } }
     printf("field %d inv29=%08x ok\n",f,P.inv29);

@@ -4,7 +4,10 @@ Layout follows the reference's own tests (evaluation_form.rs:106-203, product_po
 sumcheck/src/lib.rs:31-123, fft/src/lib.rs:63-83) and then widens to random tables, every fold position, edge
 values, all three fields and the (k, D) grid.  Run with -m gpu on the MI355X box.
 """
+import os
 import random
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -15,6 +18,7 @@ from zk_amd import MultiLinearPolynomial as MLE
 from zk_amd import ProductPoly, SumcheckProof, SumcheckProver, SumcheckVerifier, ZkError
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 FIELDS = [zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR]
 _ctx = {}
@@ -120,7 +124,7 @@ def test_ref_fft_roundtrip_kat(field):
 
 # ------------------------------------------------------------------ fold vs oracle
 @pytest.mark.parametrize("field", FIELDS)
-@pytest.mark.parametrize("n_vars", [1, 2, 3, 6, 9])
+@pytest.mark.parametrize("n_vars", [1, 2, 3, 6, 7, 8, 9])   # 7: the first size with 64 pairs (k_fold_low / k_fold_run / k_fold_msb take over from k_fold)
 def test_fold_every_position_and_length(field, n_vars):
     c = ctx_for(field)
     p = zk_amd.modulus(field)
@@ -138,7 +142,7 @@ def test_fold_every_position_and_length(field, n_vars):
 @pytest.mark.parametrize("field", FIELDS)
 def test_fold_general_positions_through_the_run_kernel(field):
     """partial_evaluate at every initial_var of a 2^14 table (index bits 13..0): bits >= 6 take k_fold_run (wave-coalesced runs,
-    block by block), the low six bits k_fold; single and multiple assignments (each later assignment folds the SAME variable index
+    block by block), the low six bits k_fold_low (one in-wave exchange); single and multiple assignments (each later assignment folds the SAME variable index
     of the shrunken table, evaluation_form.rs:54-72), edge challenges included.  Bit-exact vs the oracle."""
     c = ctx_for(field)
     p = zk_amd.modulus(field)
@@ -239,6 +243,66 @@ def test_ref_to_evaluation_form_kat_and_random(field):
                     v += 1
                 acc = (acc + t) % pm
             assert zk_amd.fe_to_int(field, ev) == acc
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_to_evaluation_form_every_arity_and_term_class(field):
+    """coefficient_form.rs:340-347 on the LDS-tiled passes (zeta_kernels.cuh): every n = 1..24 -- one partial tile below 11
+    variables, the 11-bit first pass alone at 11, then 1..8-bit strided passes in every split up to 11 + 7 + 6 -- against the
+    oracle's direct definition, with the term classes that exercise the first pass's tile logic: no term at all, the constant
+    term only, the all-variables term only, all terms inside one 2^11 tile, terms in every tile, random."""
+    c = ctx_for(field)
+    rng = random.Random(1000 + field)
+    for n_vars in range(1, 25):
+        full = (1 << n_vars) - 1
+        budget = max(2, min(300, (1 << 27) >> n_vars))   # oracle cost = 2^n * terms
+        classes = {
+            "none": [],
+            "constant": [0],
+            "all_variables": [full],
+            "random": sorted(rng.sample(range(1 << n_vars), min(budget, 1 << n_vars))),
+        }
+        if n_vars >= 12:
+            # table index = bit-reversed key: keys whose LOW n - 11 bits are fixed share the index's high bits, i.e. one tile
+            hi_bits = rng.randrange(1 << (n_vars - 11))
+            classes["one_tile"] = sorted({(rng.randrange(1 << 11) << (n_vars - 11)) | hi_bits for _ in range(min(budget, 40))})
+            # ... and keys that only use the low n - 11 bits put one term at the START of many different tiles
+            classes["tile_heads"] = sorted({rng.randrange(1 << (n_vars - 11)) for _ in range(min(budget, 40))})
+        if n_vars <= 10:
+            classes["dense"] = list(range(1 << n_vars))
+        for name, keys in classes.items():
+            if n_vars > 20 and name not in ("random", "one_tile"):
+                continue   # (big tables: two classes keep the test in seconds)
+            coeffs = orc.fill_random(field, 2700 + 31 * n_vars + len(keys), max(len(keys), 1))[:len(keys)]
+            poly = zk_amd.CoeffMultilinearPolynomial.new_with_coefficient(field, n_vars, {k: coeffs[i] for i, k in enumerate(keys)})
+            t = poly.to_evaluation_form(c)
+            got = t.evaluation_slice()
+            t.free()
+            want = orc.coeff_to_evaluation(field, n_vars, keys, coeffs)
+            assert np.array_equal(got, want), (n_vars, name)
+
+
+def test_to_evaluation_form_tiled_equals_global_passes():
+    """the round-4 form (memset + scatter + three index bits per launch, ZK_ZETA_GLOBAL=1) and the LDS-tiled passes give the
+    same table on a dense-ish term list at 2^22 (child process: the switch is read once per process)"""
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import zk_amd\n"
+        "f = zk_amd.BN254_FR; c = zk_amd.Context(f, 0)\n"
+        "rng = np.random.default_rng(77); n = 22\n"
+        "keys = np.unique(rng.integers(0, 1 << n, 1 << 15, dtype=np.uint64))\n"
+        "co = zk_amd.MultiLinearPolynomial.random(c, 15, 99, 0).evaluation_slice()[:len(keys)]\n"
+        "p = zk_amd.CoeffMultilinearPolynomial.new_with_coefficient(f, n, {int(k): co[i] for i, k in enumerate(keys)})\n"
+        "t = p.to_evaluation_form(c)\n"
+        "import hashlib; print('DIGEST', hashlib.sha256(t.evaluation_slice().tobytes()).hexdigest())\n"
+    ) % ROOT
+    outs = []
+    for env in ({}, {"ZK_ZETA_GLOBAL": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert outs[0] == outs[1]
 
 
 # ------------------------------------------------------------------ product / round sums vs oracle

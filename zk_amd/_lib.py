@@ -9,7 +9,9 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzk_amd.so")
+# ZK_AMD_LIB: another build of the SAME sources (the host-sanitizer build of `make -C zk_amd/csrc asan`, tools/run_sanitized.sh; the
+# A/B scripts under tools/); never a different implementation -- there is no fallback path
+LIB_PATH = os.environ.get("ZK_AMD_LIB") or os.path.join(_HERE, "libzk_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "zk_amd.h")
 
 c = ctypes

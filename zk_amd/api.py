@@ -327,9 +327,11 @@ class CoeffMultilinearPolynomial:
         return self._n_vars
 
     def to_evaluation_form(self, ctx):
-        keys = np.array(sorted(self.coefficients), dtype=np.uint64)
-        coeffs = (np.stack([self.coefficients[int(k)] for k in keys]) if len(keys) else np.zeros((0, 4), dtype=np.uint64))
-        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        if getattr(self, "_flat", None) is None or self._flat[2] != len(self.coefficients):   # the term list as two arrays, built once
+            keys = np.array(sorted(self.coefficients), dtype=np.uint64)
+            coeffs = (np.stack([self.coefficients[int(k)] for k in keys]) if len(keys) else np.zeros((0, 4), dtype=np.uint64))
+            self._flat = (keys, np.ascontiguousarray(coeffs, dtype=np.uint64), len(self.coefficients))
+        keys, coeffs, _ = self._flat
         h = c.c_void_p()
         check(lib.zk_coeff_to_evaluation(ctx._h, self._n_vars, _p(keys), _p(coeffs), len(keys), c.byref(h)))
         return MultiLinearPolynomial(ctx, h)

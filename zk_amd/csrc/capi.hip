@@ -6,6 +6,7 @@
 //   fft/src/lib.rs:4-19.  There is no CPU compute fallback: every table operation is a gfx950 kernel.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <array>
 #include <atomic>
 #include <chrono>
@@ -13,6 +14,7 @@
 #include <cstdio>
 #include <map>
 #include <new>
+#include <set>
 #include <string>
 #include <thread>
 #include <utility>
@@ -20,8 +22,10 @@
 
 #include "../../include/zk_amd.h"
 #include "host_field.hpp"
+#include "env.hpp"
 #include "kernels.cuh"
 #include "eval_kernels.cuh"
+#include "zeta_kernels.cuh"
 #include "gkr_kernels.cuh"
 #include "launch.hpp"
 #include "ntt_kernels.cuh"
@@ -540,6 +544,13 @@ static int32_t launch_fold(zk_ctx *c, const uint64_t *in, uint64_t *out, uint64_
         HIPCHK(hipGetLastError());
         return ZK_OK;
     }
+    if (pos < 6 && pairs >= 64 && in != out) {   // partner inside the wave's 128-element run: one in-wave exchange (k_fold_low)
+        uint64_t g = pairs / kBlock;
+        if (g > 2 * kMaxGridStream) g = 2 * kMaxGridStream;
+        k_fold_low<<<(uint32_t)(g ? g : 1), kBlock, 0, c->stream>>>(in, out, pairs, pos, c->fi->P, mul29_prepare(r, c->fi->P));
+        HIPCHK(hipGetLastError());
+        return ZK_OK;
+    }
     uint64_t g = (pairs + kBlock - 1) / kBlock;
     if (g > kMaxGridStream) g = kMaxGridStream;
     k_fold<<<(uint32_t)(g ? g : 1), kBlock, 0, c->stream>>>(in, out, pairs, pos, c->fi->P, mul29_prepare(r, c->fi->P));
@@ -610,22 +621,15 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
     int32_t rc = ZK_OK;
     const uint64_t *src = t->d;
     uint64_t cur = n;   // variables left
-    static const bool bulk_low = getenv("ZK_EVAL_FOLDS") == nullptr;   // ZK_EVAL_FOLDS=1: the variable-by-variable path (A/B, tests)
+    static const bool bulk_low = !env_flag("ZK_EVAL_FOLDS");   // ZK_EVAL_FOLDS=1: the variable-by-variable path (A/B, tests)
     // tables of at least this many variables take the streaming kernel (k_eval_stream: up to 15 variables per launch, half an
     // element per lane, carry-free column sums); smaller ones are launch latency and keep k_eval_low.  ZK_EVAL_STREAM_MIN overrides.
-    static const uint64_t stream_min = [] {
-        const char *e = getenv("ZK_EVAL_STREAM_MIN");
-        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)21;
-    }();
+    static const uint64_t stream_min = env_u64("ZK_EVAL_STREAM_MIN", 21, 0, 1000);   // above kMaxVars: never
     for (int pass = 0; bulk_low && cur >= 8 && rc == ZK_OK; ++pass) {
         // the streaming launch leaves 9 variables (512 workgroups), 8 at 21 variables: every workgroup spends ~2600 instructions per
         // wave on its weight tables before the first product, so at 2^21 elements half as many workgroups with twice the rows win
         // (device time 31.2 -> 29.1 us; 10 left: 54 us -- profiles/r04_evaluate_stream_grid_ab.log).  ZK_EVAL_STREAM_LEAVE overrides.
-        static const uint64_t leave_env = [] {
-            const char *e = getenv("ZK_EVAL_STREAM_LEAVE");
-            const uint64_t v = e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)0;
-            return v == 0 ? (uint64_t)0 : (v < 7 ? (uint64_t)7 : (v > (uint64_t)kEvalHighMax ? (uint64_t)kEvalHighMax : v));
-        }();
+        static const uint64_t leave_env = env_u64("ZK_EVAL_STREAM_LEAVE", 0, 7, kEvalHighMax);   // 0 = not set
         const uint64_t stream_leave = leave_env ? leave_env : (cur <= 21 ? (uint64_t)8 : (uint64_t)9);
         const bool stream = cur >= stream_min && cur >= (uint64_t)kEvalStreamMin + stream_leave;
         uint64_t L = cur <= (uint64_t)kEvalLowMax ? cur : cur - 8;
@@ -652,7 +656,7 @@ static int32_t evaluate_device(zk_ctx *c, const zk_mle *t, const uint64_t *point
         // (common.cuh eval_high_weight) and what is left is a plain sum of the 2^H outputs (k_eval_sum) instead of another bulk launch
         const uint64_t H = cur - L;
         EvalHighPoint ph = {};
-        static const int weight_mode = getenv("ZK_EVAL_WEIGHT") ? atoi(getenv("ZK_EVAL_WEIGHT")) : 3;   // A/B: bit 0 = k_eval_low, bit 1 = k_eval_stream
+        static const int weight_mode = (int)env_u64("ZK_EVAL_WEIGHT", 3, 0, 3);   // A/B: bit 0 = k_eval_low, bit 1 = k_eval_stream
         if (H >= 1 && H <= (uint64_t)kEvalHighMax && (weight_mode & (stream ? 2 : 1))) {
             ph.n = (uint32_t)H;
             for (uint64_t p = 0; p < H; ++p) {
@@ -751,7 +755,7 @@ extern "C" int32_t zk_mle_evaluate(zk_ctx *c, const zk_mle *t, const uint64_t *p
     if (t->ctx != c) return ZK_ERR_CONTEXT_MISMATCH;
     if (n_point != t->n_vars) return ZK_ERR_EVAL_ARITY;   // evaluation_form.rs:84-86
     ZKCHK(use_device(c));
-    static const bool host_dbg = getenv("ZK_HOST_DEBUG") != nullptr;
+    static const bool host_dbg = env_flag("ZK_HOST_DEBUG");
     const auto t_enter = std::chrono::steady_clock::now();
     if (t->n_vars == 0) {
         ZKCHK(evaluate_device(c, t, point, c->d_sums));
@@ -839,6 +843,24 @@ extern "C" int32_t zk_mle_partial_evaluate_host(zk_ctx *c, uint64_t n_vars, cons
     return rc;
 }
 
+static int32_t results_staging(zk_ctx *c, size_t bytes, uint8_t **out);
+static uint64_t bit_reverse64(uint64_t x) {
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0f0f0f0f0f0f0f0full) | ((x & 0x0f0f0f0f0f0f0f0full) << 4);
+    return __builtin_bswap64(x);
+}
+// the zeta tile kernels use 64 KiB + 128 B of dynamic LDS (two per CU): above the 64-KiB default, so opt in once per device
+static int32_t zeta_lds_opt_in(zk_ctx *c) {
+    static std::mutex mu;
+    static std::set<int> done;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count(c->device)) return ZK_OK;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_zeta_first), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kZetaLdsBytes));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_zeta_tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kZetaLdsBytes));
+    done.insert(c->device);
+    return ZK_OK;
+}
 // CoeffMultilinearPolynomial::to_evaluation_form (coefficient_form.rs:340-347): scatter + zeta transform on the device
 static int32_t coeff_to_evaluation_impl(zk_ctx *c, uint64_t n_vars, const uint64_t *keys, const uint64_t *coeffs, uint64_t n_terms,
                                         zk_mle **out);
@@ -860,52 +882,88 @@ static int32_t coeff_to_evaluation_impl(zk_ctx *c, uint64_t n_vars, const uint64
     for (uint64_t t = 0; t < n_terms; ++t)
         if (keys[t] >> n_vars) return ZK_ERR_COEFF_RANGE;                            // coefficient_form.rs:183-186
     ZKCHK(use_device(c));
-    // BTreeMap semantics: one entry per key, duplicate terms summed (coefficient_form.rs:164-171)
-    std::map<uint64_t, Fe> merged;
-    for (uint64_t t = 0; t < n_terms; ++t) {
-        const Fe v = fe_from_u64limbs(coeffs + 4 * t);
-        auto it = merged.find(keys[t]);
-        if (it == merged.end()) merged.emplace(keys[t], v);
-        else it->second = fe_add(it->second, v, c->fi->P);
+    // BTreeMap semantics: one entry per key, duplicate terms summed (coefficient_form.rs:164-171).  Keyed by the TABLE INDEX of the
+    // term (key bit v <-> variable v <-> index bit n-1-v: the bit-reversed key), so the list comes out sorted by index, which is
+    // what k_zeta_first's per-tile binary search needs.
+    std::vector<std::pair<uint64_t, uint64_t>> order(n_terms);   // (table index, position in the caller's list)
+    for (uint64_t t = 0; t < n_terms; ++t) order[t] = {bit_reverse64(keys[t]) >> (64 - n_vars), t};
+    std::sort(order.begin(), order.end());
+    // one staging block: m indices, then m coefficients (4 words each); pinned (the context's results block) while it is small
+    const size_t stage_bytes = (size_t)n_terms * 40;
+    std::vector<uint64_t> pageable;
+    uint64_t *hs = nullptr;
+    if (stage_bytes <= ((size_t)1 << 20)) {
+        uint8_t *blk = nullptr;
+        ZKCHK(results_staging(c, stage_bytes ? stage_bytes : 8, &blk));
+        hs = reinterpret_cast<uint64_t *>(blk);
+    } else {
+        pageable.resize((size_t)n_terms * 5);
+        hs = pageable.data();
     }
-    std::vector<uint64_t> hk, hc;
-    for (auto &kv : merged) {
-        hk.push_back(kv.first);
-        uint64_t l[4];
-        fe_to_u64limbs(kv.second, l);
-        hc.insert(hc.end(), l, l + 4);
-    }
-    const uint64_t m = hk.size();
-    zk_mle *t = nullptr;
-    ZKCHK(mle_alloc(c, n_vars, &t));
-    uint64_t *d_keys = nullptr, *d_coeffs = nullptr;
-    int32_t rc = ZK_OK;
-    if (hipMemsetAsync(t->d, 0, (size_t)32 << n_vars, c->stream) != hipSuccess) rc = ZK_ERR_HIP;
-    if (rc == ZK_OK && m) {
-        rc = pool_alloc(c, m * 8, (void **)&d_keys);
-        if (rc == ZK_OK) rc = pool_alloc(c, m * 32, (void **)&d_coeffs);
-        if (rc == ZK_OK && (hipMemcpyAsync(d_keys, hk.data(), m * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-                            hipMemcpyAsync(d_coeffs, hc.data(), m * 32, hipMemcpyHostToDevice, c->stream) != hipSuccess))
-            rc = ZK_ERR_HIP;
-        if (rc == ZK_OK) {
-            k_scatter_terms<<<grid_for(m), kBlock, 0, c->stream>>>(d_keys, d_coeffs, m, t->d, (uint32_t)n_vars);
-            if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+    uint64_t m = 0;
+    {
+        uint64_t *hk = hs, *hc = hs + n_terms;   // indices packed at the front; coefficients start at word n_terms (>= m)
+        for (uint64_t i = 0; i < n_terms;) {
+            Fe acc = fe_from_u64limbs(coeffs + 4 * order[i].second);
+            uint64_t j = i + 1;
+            for (; j < n_terms && order[j].first == order[i].first; ++j)
+                acc = fe_add(acc, fe_from_u64limbs(coeffs + 4 * order[j].second), c->fi->P);
+            hk[m] = order[i].first;
+            fe_to_u64limbs(acc, hc + 4 * m);
+            ++m;
+            i = j;
         }
     }
-    for (uint32_t b = 0; b < n_vars && rc == ZK_OK;) {   // the subset-sum butterfly over every index bit, three bits per pass
-        const uint32_t v = n_vars - b >= 3 ? 3u : (uint32_t)(n_vars - b);
-        const uint64_t groups = 1ull << (n_vars - v);
-        uint64_t g = (groups + kBlock - 1) / kBlock;
-        if (g > kMaxGridStream) g = kMaxGridStream;
-        if (v == 3) k_zeta_multi<3><<<(uint32_t)g, kBlock, 0, c->stream>>>(t->d, groups, b, c->fi->P);
-        else if (v == 2) k_zeta_multi<2><<<(uint32_t)g, kBlock, 0, c->stream>>>(t->d, groups, b, c->fi->P);
-        else k_zeta_pass<<<(uint32_t)g, kBlock, 0, c->stream>>>(t->d, groups, b, c->fi->P);
-        if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
-        b += v;
+    zk_mle *t = nullptr;
+    ZKCHK(mle_alloc(c, n_vars, &t));
+    uint64_t *d_terms = nullptr, *d_keys = nullptr, *d_coeffs = nullptr;
+    int32_t rc = ZK_OK;
+    if (m) {
+        rc = pool_alloc(c, (size_t)n_terms * 40, (void **)&d_terms);
+        if (rc == ZK_OK && hipMemcpyAsync(d_terms, hs, (size_t)(n_terms + 4 * m) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+            rc = ZK_ERR_HIP;
+        d_keys = d_terms;
+        d_coeffs = d_terms + n_terms;
+    }
+    static const bool global_passes = env_flag("ZK_ZETA_GLOBAL");   // round 4's path (memset + scatter + three bits per launch): A/B only
+    if (rc == ZK_OK && !global_passes) {
+        // LDS-tiled passes (zeta_kernels.cuh): the low min(n, 11) index bits from the term list without reading the table, then
+        // the remaining bits in passes of at most 8, evenly split
+        rc = zeta_lds_opt_in(c);
+        const uint32_t tile_log = n_vars < kZetaTileLog ? (uint32_t)n_vars : kZetaTileLog;
+        if (rc == ZK_OK) {
+            k_zeta_first<<<(uint32_t)(1ull << (n_vars - tile_log)), kBlock, kZetaLdsBytes, c->stream>>>(t->d, d_keys, d_coeffs, m, tile_log,
+                                                                                                      c->fi->P);
+            if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+        }
+        const uint32_t rem = (uint32_t)n_vars - tile_log, n_pass = (rem + 7) / 8;
+        uint32_t pos = tile_log;
+        for (uint32_t p = 0; p < n_pass && rc == ZK_OK; ++p) {
+            const uint32_t L = rem / n_pass + (p < rem % n_pass ? 1u : 0u);
+            k_zeta_tile<<<(uint32_t)(1ull << (n_vars - kZetaTileLog)), kBlock, kZetaLdsBytes, c->stream>>>(t->d, pos, L, c->fi->P);
+            if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+            pos += L;
+        }
+    } else if (rc == ZK_OK) {
+        if (hipMemsetAsync(t->d, 0, (size_t)32 << n_vars, c->stream) != hipSuccess) rc = ZK_ERR_HIP;
+        if (rc == ZK_OK && m) {
+            k_scatter_terms<<<grid_for(m), kBlock, 0, c->stream>>>(d_keys, d_coeffs, m, t->d);
+            if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+        }
+        for (uint32_t b = 0; b < n_vars && rc == ZK_OK;) {   // the subset-sum butterfly over every index bit, three bits per pass
+            const uint32_t v = n_vars - b >= 3 ? 3u : (uint32_t)(n_vars - b);
+            const uint64_t groups = 1ull << (n_vars - v);
+            uint64_t g = (groups + kBlock - 1) / kBlock;
+            if (g > kMaxGridStream) g = kMaxGridStream;
+            if (v == 3) k_zeta_multi<3><<<(uint32_t)g, kBlock, 0, c->stream>>>(t->d, groups, b, c->fi->P);
+            else if (v == 2) k_zeta_multi<2><<<(uint32_t)g, kBlock, 0, c->stream>>>(t->d, groups, b, c->fi->P);
+            else k_zeta_pass<<<(uint32_t)g, kBlock, 0, c->stream>>>(t->d, groups, b, c->fi->P);
+            if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
+            b += v;
+        }
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == ZK_OK) rc = ZK_ERR_HIP;   // host staging vectors go out of scope
-    if (d_keys) pool_free(c, d_keys, m * 8);
-    if (d_coeffs) pool_free(c, d_coeffs, m * 32);
+    if (d_terms) pool_free(c, d_terms, (size_t)n_terms * 40);
     if (rc != ZK_OK) {
         mle_release(t);
         return rc;
@@ -1066,10 +1124,7 @@ static std::vector<Fe> interp_weights(uint32_t D, const FieldParams &P);   // de
 // Rounds with at least this many pairs leave out the t = 1 sums (k_round_kd SKIP1 + TailDerive): below it the extra
 // D + 1 dependent multiplies in the tail cost more than the products they save.  ZK_SKIP1_MIN_PAIRS overrides (tests).
 static uint64_t skip1_min_pairs() {
-    static const uint64_t v = [] {
-        const char *e = getenv("ZK_SKIP1_MIN_PAIRS");
-        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)1 << 16;
-    }();
+    static const uint64_t v = env_u64("ZK_SKIP1_MIN_PAIRS", (uint64_t)1 << 16, 1, (uint64_t)1 << 40);
     return v;
 }
 static inline TermSpec single_term(int k) {
@@ -1089,10 +1144,7 @@ struct DeferredTail {
 // Rounds with at least this many pairs accumulate the leading coefficient instead of S(D) (k_round_kd LEAD): one modular
 // addition per factor and pair index fewer against three to six more in the tail.  ZK_LEAD_MIN_PAIRS overrides (tests).
 static uint64_t lead_min_pairs() {
-    static const uint64_t v = [] {
-        const char *e = getenv("ZK_LEAD_MIN_PAIRS");
-        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)1 << 16;
-    }();
+    static const uint64_t v = env_u64("ZK_LEAD_MIN_PAIRS", (uint64_t)1 << 16, 1, (uint64_t)1 << 40);
     return v;
 }
 static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, uint64_t q, uint32_t D, bool fused,
@@ -1439,8 +1491,7 @@ static int32_t round_enqueue(RoundState &st, uint64_t *lanes, DeferredTail *defe
 // off; ZK_PIPE_MAX_PAIRS overrides; the accumulators hold at most kMaxLazy products per lane, hence the cap).
 static uint64_t pipe_max_pairs() {
     static const uint64_t v = [] {
-        const char *e = getenv("ZK_PIPE_MAX_PAIRS");
-        uint64_t x = e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)1 << 12;
+        uint64_t x = env_u64("ZK_PIPE_MAX_PAIRS", (uint64_t)1 << 12, 0, (uint64_t)1 << 40);   // 0 = no pipelined rounds; capped below
         const uint64_t cap = (uint64_t)kPipeMaxWorkBlocks * 16 * kMaxLazy;   // products a lane may accumulate unreduced (16 rows per block)
         return x > cap ? cap : x;
     }();
@@ -1460,7 +1511,7 @@ static bool pipe_shape(const RoundState &st, int *k, int *extra) {
 }
 static constexpr size_t kDbgWords = 64 * 32 + 64 * 16;
 static uint64_t *pipe_dbg_slot(zk_ctx *c, bool finisher) {
-    static const bool on = getenv("ZK_PIPE_DEBUG") != nullptr;
+    static const bool on = env_flag("ZK_PIPE_DEBUG");
     if (!on) return nullptr;
     if (!c->d_dbg) {
         if (hipMalloc(&c->d_dbg, kDbgWords * 8) != hipSuccess) return nullptr;
@@ -1494,10 +1545,7 @@ static void pipe_dbg_dump(zk_ctx *c) {
 }
 // the pipelined finisher takes over from every state when the tables it would hold fit LDS (ZK_FINISH_PIPE=0: classic one)
 static bool finish_pipe_on() {
-    static const bool v = [] {
-        const char *e = getenv("ZK_FINISH_PIPE");
-        return !(e && e[0] == '0');
-    }();
+    static const bool v = env_u64("ZK_FINISH_PIPE", 1, 0, 1) != 0;
     return v;
 }
 static bool finish_pipe_applies(const RoundState &st) {
@@ -1799,7 +1847,7 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
     // the reference takes the polynomial by value and clones per fold, so a table may appear twice (A * A): in-place folds
     // would then fold the shared buffer once per listing -- such a product is proved out of place (own scratch per factor)
     if (has_duplicate_handles(f, k)) consume = 0;
-    static const bool host_dbg = getenv("ZK_HOST_DEBUG") != nullptr;
+    static const bool host_dbg = env_flag("ZK_HOST_DEBUG");
     const auto t_enter = std::chrono::steady_clock::now();
     RoundState st;
     ZKCHK(round_state_init(st, c, f, k, D, consume != 0, n));

@@ -91,6 +91,19 @@ ZK_D void run_store(uint64_t *run, uint32_t lane, const Fe &e) {
     p[64] = B;
 }
 
+// nontemporal forms (tables streamed once)
+ZK_D Fe run_load_nt(const uint64_t *run, uint32_t lane) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(run) + lane;
+    return pair_gather(nt_load16(p), nt_load16(p + 64), lane & 1);
+}
+ZK_D void run_store_nt(uint64_t *run, uint32_t lane, const Fe &e) {
+    uint4 A, B;
+    pair_scatter(e, lane & 1, A, B);
+    uint4 *p = reinterpret_cast<uint4 *>(run) + lane;
+    nt_store16(A, p);
+    nt_store16(B, p + 64);
+}
+
 // Big fused rounds leave out the t = 1 sums; the tail derives S_i(1) = S_{i-1}(r_{i-1}) - S_i(0) (k_round_kd, SKIP1).
 // prev_rp: the previous round polynomial (D + 1 elements, device); w[t] = 1 / prod_{u != t} (t - u), the Lagrange weights
 // on the nodes 0..D (Montgomery form, computed by the host once per context and degree, kept in device memory).

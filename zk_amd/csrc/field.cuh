@@ -474,12 +474,11 @@ ZK_HD Mul29 mul29_prepare(const Fe &c, const FieldParams &P) {
 // TWO = true adds a second product before the ONE reduction: a*c + a2*c2 (a dot product of length two for the price of one and
 // a half multiplications).  The columns stay carry-free: at most 18 products of two 29-bit limbs plus 9 of the reduction,
 // 27 * 2^58 < 2^63; the value bound doubles to 2^251 + p, still below 2p.
+// (the core works on the left operands' limbs: fe_mul29_t splits an element, fe_mul_tt splits it shifted by five bits)
 template <bool LAZY = false, bool TWO = false>
-ZK_HD Fe fe_mul29_t(const Fe &a, const Mul29 &c, const FieldParams &P, const Fe *a2 = nullptr, const Mul29 *c2 = nullptr) {
+ZK_HD Fe mul29_core(const uint32_t (&x)[9], const uint32_t (&y)[9], const Mul29 &c, const FieldParams &P, const Mul29 *c2 = nullptr) {
     constexpr uint32_t M = (1u << 29) - 1;
-    uint32_t x[9], y[9], m[9], r[9];
-    split29(a.v, x);
-    if constexpr (TWO) split29(a2->v, y);
+    uint32_t m[9], r[9];
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -525,6 +524,37 @@ ZK_HD Fe fe_mul29_t(const Fe &a, const Mul29 &c, const FieldParams &P, const Fe 
 #pragma unroll
     for (int i = 0; i < 8; ++i) o.v[i] = borrow ? s.v[i] : d.v[i];
     return o;
+}
+template <bool LAZY = false, bool TWO = false>
+ZK_HD Fe fe_mul29_t(const Fe &a, const Mul29 &c, const FieldParams &P, const Fe *a2 = nullptr, const Mul29 *c2 = nullptr) {
+    uint32_t x[9], y[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    split29(a.v, x);
+    if constexpr (TWO) split29(a2->v, y);
+    return mul29_core<LAZY, TWO>(x, y, c, P, c2);
+}
+// Product of two TABLE values on the carry-free core (ProductPoly::prod_reduce, product_poly.rs:66-74: neither operand is
+// uniform, so nothing can be prepared ahead).  The core divides by 2^261; the missing factor 2^5 goes into the left operand's
+// SPLIT: a < p < 2^255, so a * 2^5 < 2^260 still fits nine 29-bit limbs -- the limbs are cut five bits lower, no doublings:
+//   fe_mul_tt(a, b) = (a * 2^5) * b * 2^-261 = a * b * 2^-256 mod p = fe_mul(a, b), bit for bit
+// (value bound (2^260 * 2^255) / 2^261 + p < 2p, one conditional subtraction; column sums as in fe_mul29).  About 290
+// instructions against ~420 for the saturated product.
+ZK_HD void split29_shl5(const uint32_t a[8], uint32_t out[9]) {
+    constexpr uint32_t M = (1u << 29) - 1;
+    out[0] = (a[0] << 5) & M;
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const int bit = 29 * i - 5, w = bit >> 5, sh = bit & 31;
+        uint32_t v = a[w] >> sh;
+        if (sh > 3 && w + 1 < 8) v |= a[w + 1] << (32 - sh);
+        out[i] = v & M;   // limb 8 = bits 227..255 of a (29 bits)
+    }
+}
+ZK_HD Fe fe_mul_tt(const Fe &a, const Fe &b, const FieldParams &P) {
+    uint32_t x[9], y[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Mul29 c;
+    split29_shl5(a.v, x);
+    split29(b.v, c.l);
+    return mul29_core<false, false>(x, y, c, P);
 }
 // a*c + a2*c2 (both right operands prepared), one reduction
 ZK_HD Fe fe_dot2_29(const Fe &a, const Mul29 &c, const Fe &a2, const Mul29 &c2, const FieldParams &P) {

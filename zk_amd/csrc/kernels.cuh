@@ -92,6 +92,42 @@ __global__ __launch_bounds__(kBlock) void k_fold_run(const uint64_t *in, uint64_
     }
 }
 
+// The same data movement for the LOW six fold positions (pos < 6: the pair partner is 1..32 elements away, inside the wave's
+// run).  A wave reads 128 consecutive elements as two coalesced 64-element runs A and B (run_load: lane l owns element
+// own(l) = (l >> 1) + 32 (l & 1) of each), so a lane holds one element of a pair of A and one of a pair of B; bit pos of own(l)
+// says which side.  ONE exchange with the partner lane (own index differing in bit pos) hands the "low" lane the whole A pair
+// and the "high" lane the whole B pair (the low lane sends its B element and receives the partner's A element, the high lane
+// the other way round), every lane folds one pair, and a second lane permutation puts output own(l) of the wave's 64 outputs
+// on lane l for the coalesced store.  Both permutations are ds_bpermute pulls (8 words each): a few LDS-crossbar cycles per
+// 6 KiB of HBM traffic.  Out of place only; pairs a multiple of 64.  Until round 5 these positions ran on k_fold (32 bytes
+// per lane: 0.63 of the HBM peak at 2^24 against 0.72-0.73 for the run forms).
+ZK_D Fe lane_pull(const Fe &v, uint32_t src_lane) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v.v[i]);
+    return r;
+}
+__global__ __launch_bounds__(kBlock) void k_fold_low(const uint64_t *in, uint64_t *out, uint64_t pairs, uint32_t pos, FieldParams P, Mul29 r) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * kBlock) >> 6;
+    const uint32_t own = pair_owned(lane);
+    const bool high = (own >> pos) & 1u;
+    const uint32_t partner_own = own ^ (1u << pos);
+    const uint32_t partner = ((partner_own & 31u) << 1) | (partner_own >> 5);          // the lane that owns partner_own
+    // this lane computes output q = 32 * high + (own without bit pos); the store wants output own(l) on lane l
+    const uint32_t want = own, want_half = want >> 5, want_low = want & 31u;
+    const uint32_t src_own = (((want_low >> pos) << (pos + 1)) | (want_low & ((1u << pos) - 1u))) | (want_half << pos);
+    const uint32_t src = ((src_own & 31u) << 1) | (src_own >> 5);
+    for (uint64_t e0 = wave * 64; e0 < pairs; e0 += nwaves * 64) {
+        const Fe a = run_load_nt(in + 4 * (2 * e0), lane), b = run_load_nt(in + 4 * (2 * e0 + 64), lane);
+        const Fe got = lane_pull(high ? a : b, partner);
+        const Fe lo = high ? got : a, hi = high ? b : got;
+        const Fe o = fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), r, P), P);
+        run_store_nt(out + 4 * e0, lane, lane_pull(o, src));
+    }
+}
+
 // same fold with the challenge read from device memory (produced by the on-device transcript); m = variables of `in`,
 // always the MSB fold.  `pairs` = 2^(m-1).
 __global__ __launch_bounds__(kBlock) void k_fold_dev(const uint64_t *in, uint64_t *out, uint64_t pairs, uint32_t m,
@@ -313,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void k_prod_reduce_run(FactorPtrs fp, int k
         }
         for (int f = 1; f < k; ++f) {
             const uint4 *q = reinterpret_cast<const uint4 *>(fp.in[f]);
-            acc = fe_mul(acc, pair_gather(nt_load16(q + c0), nt_load16(q + c0 + 64), odd), P);
+            acc = fe_mul_tt(acc, pair_gather(nt_load16(q + c0), nt_load16(q + c0 + 64), odd), P);   // carry-free table x table product
         }
         uint4 oa, ob;
         pair_scatter(acc, odd, oa, ob);
@@ -811,11 +847,12 @@ __global__ __launch_bounds__(kBlock) void k_to_bytes(const uint64_t *__restrict_
 // eval[idx] = sum over keys that are subsets of the point's variable set.  With key bit v <-> variable v and table index
 // bit (n-1-v) <-> variable v, that is a zeta (subset-sum) transform of the coefficient vector placed at bit-reversed
 // positions: scatter, then one in-place pass per variable: T[x | b] += T[x].
-__global__ __launch_bounds__(kBlock) void k_scatter_terms(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ coeffs,
-                                                          uint64_t n_terms, uint64_t *__restrict__ table, uint32_t n_vars) {
+// (the round-4 global-pass form, kept behind ZK_ZETA_GLOBAL=1 for A/B; the shipped transform is zeta_kernels.cuh)
+__global__ __launch_bounds__(kBlock) void k_scatter_terms(const uint64_t *__restrict__ idx, const uint64_t *__restrict__ coeffs,
+                                                          uint64_t n_terms, uint64_t *__restrict__ table) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < n_terms; t += stride)
-        fe_store(table, __brevll(keys[t]) >> (64 - n_vars), fe_load(coeffs, t));   // keys are unique (merged on the host)
+        fe_store(table, idx[t], fe_load(coeffs, t));   // idx = bit-reversed keys, unique (merged on the host)
 }
 __global__ __launch_bounds__(kBlock) void k_zeta_pass(uint64_t *table, uint64_t pairs, uint32_t pos, FieldParams P) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;

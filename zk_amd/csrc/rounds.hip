@@ -1,6 +1,7 @@
 // rounds.hip -- instantiations + launch logic of the sumcheck round kernels.
 #include <cstdlib>
 
+#include "env.hpp"
 #include "launch.hpp"
 #include "round_kernels.cuh"
 
@@ -13,10 +14,7 @@ static constexpr uint32_t kCapGrid = 2048;   // 8 workgroups per CU on 256 CUs
 // the cheapest grid is the one with the FEWEST waves that still fills the machine: up to kMaxLazy pairs per thread, but
 // at least kMinBlocks workgroups (2 waves per SIMD on 256 CUs) while there is one pair per thread to give them.
 static uint32_t min_blocks() {
-    static const uint32_t v = [] {
-        const char *e = getenv("ZK_ROUND_MIN_BLOCKS");   // tuning override
-        return e ? (uint32_t)atoi(e) : 512u;
-    }();
+    static const uint32_t v = (uint32_t)env_u64("ZK_ROUND_MIN_BLOCKS", 512, 1, 2048);   // tuning override
     return v;
 }
 // fused rounds with at most this many pairs (and at least 16) use the four-lanes-per-pair-index kernel (ZK_QUAD_MAX_PAIRS;
@@ -24,19 +22,13 @@ static uint32_t min_blocks() {
 // ZK_ROUND0_DOT29: 1 (default) = round 0 of the two-table (2, 2) product on the carry-free kernel; 0 = the wide-accumulator kernel
 // everywhere; 2 = the carry-free kernel for the product-plus-term shape as well (A/B)
 static int round0_dot29_mode() {
-    static const int v = [] {
-        const char *e = getenv("ZK_ROUND0_DOT29");
-        return e ? atoi(e) : 1;
-    }();
+    static const int v = (int)env_u64("ZK_ROUND0_DOT29", 1, 0, 2);
     return v;
 }
 static bool round0_dot29() { return round0_dot29_mode() != 0; }
 static bool round0_dot29_extra() { return round0_dot29_mode() == 2; }
 static uint64_t quad_max_pairs() {
-    static const uint64_t v = [] {
-        const char *e = getenv("ZK_QUAD_MAX_PAIRS");
-        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)1 << 15;
-    }();
+    static const uint64_t v = env_u64("ZK_QUAD_MAX_PAIRS", (uint64_t)1 << 15, 0, (uint64_t)1 << 40);
     return v;
 }
 template <int K, int D, int EXTRA>
@@ -52,10 +44,7 @@ static uint32_t launch_quad(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint
 // and twice the pairs per thread below 2^17 pairs: 7.57 -> 7.50 ms on the depth-8 x 2^20 driver (profiles/r04_round_min_blocks_ab.log);
 // ZK_ROUND_MIN_BLOCKS overrides both
 static uint32_t min_blocks_plus1() {
-    static const uint32_t v = [] {
-        const char *e = getenv("ZK_ROUND_MIN_BLOCKS");
-        return e ? (uint32_t)atoi(e) : 256u;
-    }();
+    static const uint32_t v = (uint32_t)env_u64("ZK_ROUND_MIN_BLOCKS", 256, 1, 2048);
     return v;
 }
 static inline uint32_t round_grid(uint64_t q, uint32_t min_b = min_blocks()) {
