@@ -351,6 +351,27 @@ int32_t zk_bench_modmul(zk_ctx *ctx, int32_t variant, int32_t iters, double *out
 /* plain 16-B/lane streaming copy of `bytes` bytes: achieved GB/s (calibrates the HBM ceiling on this device) */
 int32_t zk_bench_copy(zk_ctx *ctx, uint64_t bytes, int32_t reps, double *out_gbps);
 
+/* ---- environment switches (zk_amd/csrc/env.hpp) ------------------------------------------------------------------
+   Read once per process; every one is a tuning / A-B / debug override and every setting produces bit-identical results.  A value
+   that is not a whole decimal number inside the accepted range is ignored (the default applies) with one line on stderr.
+
+   name                    default   accepted     meaning
+   ZK_SKIP1_MIN_PAIRS      65536     1 .. 2^40    rounds with at least this many pairs leave S(1) to the tail (S(1) = claim - S(0))
+   ZK_LEAD_MIN_PAIRS       65536     1 .. 2^40    ... accumulate the leading coefficient instead of S(D) (K = D shapes)
+   ZK_QUAD_MAX_PAIRS       32768     0 .. 2^40    rounds up to this size run four lanes per pair index (k_round_quad); 0 = never
+   ZK_PIPE_MAX_PAIRS       4096      0 .. 2^40    rounds up to this size are prepared before their challenge exists; 0 = never
+   ZK_ROUND_MIN_BLOCKS     512 / 256 1 .. 2048    smallest grid of the fused round kernels (256 for the GKR shape)
+   ZK_FINISH_PIPE          1         0 .. 1       0: the classic single-workgroup finisher instead of the pipelined one
+   ZK_ROUND0_DOT29         1         0 .. 2       0: round 0 of the two-table degree-2 shapes on the wide accumulator; 2: force dot29
+   ZK_EVAL_FOLDS           off       flag         variable-by-variable evaluate (one fold launch per variable)
+   ZK_EVAL_STREAM_MIN      21        0 .. 1000    smallest table (variables) that takes the streaming evaluate kernel
+   ZK_EVAL_STREAM_LEAVE    8 / 9     7 .. 12      variables the streaming launch leaves (log2 of its grid): 8 at 21 variables, 9 above
+   ZK_EVAL_WEIGHT          3         0 .. 3       bit 0 / bit 1: k_eval_low / k_eval_stream weight their outputs (no second bulk launch)
+   ZK_ZETA_GLOBAL          off       flag         to_evaluation_form by global passes of three index bits (round 4's path)
+   ZK_TO_BYTES_THREADS     affinity  1 .. 4       host threads copying to_bytes chunks to the caller (default: CPUs allowed, at most 4)
+   ZK_SHARD_OVERLAP        1         0 .. 1       0: the sharded prover closes every round before starting the next (no overlap)
+   ZK_PIPE_DEBUG / ZK_HOST_DEBUG  off  flag       phase stamps of the pipelined rounds / host enqueue + wait times on stderr        */
+
 #ifdef __cplusplus
 }
 #endif

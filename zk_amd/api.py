@@ -278,7 +278,11 @@ class MultiLinearPolynomial:
         """to_bytes (evaluation_form.rs:97-103) into a numpy uint8 array (a fresh one, or `out`): no second host copy"""
         if out is None:
             out = np.empty(32 << self.n_vars(), dtype=np.uint8)
-        assert out.dtype == np.uint8 and out.size == 32 << self.n_vars() and out.flags["C_CONTIGUOUS"]
+        want = 32 << self.n_vars()   # zk_mle_to_bytes writes exactly this many bytes, on several host threads
+        if not isinstance(out, np.ndarray) or out.dtype != np.uint8 or out.size != want:
+            raise ValueError(f"to_bytes_array: out must be a numpy uint8 array of {want} bytes")
+        if not out.flags["C_CONTIGUOUS"] or not out.flags["WRITEABLE"]:
+            raise ValueError("to_bytes_array: out must be C-contiguous and writeable")
         check(lib.zk_mle_to_bytes(self.ctx._h, self._h, out.ctypes.data_as(u8p)))
         return out
 

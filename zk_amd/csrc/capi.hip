@@ -5,11 +5,13 @@
 //   transcript/src/lib.rs:16-30, sumcheck/src/verifier.rs:15-78, polynomial/src/univariate_poly.rs:29-80,
 //   fft/src/lib.rs:4-19.  There is no CPU compute fallback: every table operation is a gfx950 kernel.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <array>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <cstdio>
 #include <map>
@@ -791,32 +793,90 @@ extern "C" int32_t zk_mle_evaluate(zk_ctx *c, const zk_mle *t, const uint64_t *p
 static int32_t absorb_tables(zk_ctx *c, Sponge &sp, zk_mle *const *f, uint64_t k);
 template <class Consume>
 static int32_t stream_table_bytes(zk_ctx *c, const zk_mle *const *f, uint64_t k, Consume &&consume);
-// chunk -> caller's buffer on a few host threads: a fresh destination (a new Vec<u8>) is page-fault bound, and faults parallelise
-static void copy_out_parallel(uint8_t *dst, const uint8_t *src, size_t bytes) {
-    constexpr size_t kMinPerThread = (size_t)2 << 20;
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt > 4) nt = 4;
-    if (nt < 2 || bytes < 2 * kMinPerThread) {
-        memcpy(dst, src, bytes);
-        return;
-    }
-    const size_t per = (bytes / nt + 4095) & ~(size_t)4095;
-    std::thread th[3];
-    unsigned started = 0;
-    for (unsigned i = 1; i < nt; ++i) {
-        const size_t off = per * i;
-        if (off >= bytes) break;
-        const size_t len = bytes - off < per ? bytes - off : per;
-        try {
-            th[started] = std::thread([=] { memcpy(dst + off, src + off, len); });
-            ++started;
-        } catch (...) {
-            memcpy(dst + off, src + off, len);   // no thread to be had: copy it here
+// chunk -> caller's buffer on a few host threads: a fresh destination (a new Vec<u8>) is page-fault bound, and faults parallelise.
+// The helpers live for ONE zk_mle_to_bytes call (started once, handed every chunk, joined at its end), never more than three of
+// them; their number follows the CPUs this process may run on (sched_getaffinity, so cgroup / taskset limits count), and
+// ZK_TO_BYTES_THREADS (1..4; 1 = the caller's thread only) overrides it.
+class CopyHelpers {
+  public:
+    explicit CopyHelpers(size_t total_bytes) {
+        static const unsigned from_env = (unsigned)env_u64("ZK_TO_BYTES_THREADS", 0, 1, 4);   // 0: not set
+        unsigned nt = from_env;
+        if (!nt) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            nt = sched_getaffinity(0, sizeof set, &set) == 0 ? (unsigned)CPU_COUNT(&set) : 1u;
+            if (nt > 4) nt = 4;
+        }
+        if (nt < 2 || total_bytes < 2 * kMinPerThread) return;
+        for (unsigned i = 1; i < nt; ++i) {
+            try {
+                th_.emplace_back([this, i] { work(i); });
+            } catch (...) {
+                break;   // no thread to be had: the ones that started (perhaps none) share the work
+            }
         }
     }
-    memcpy(dst, src, per < bytes ? per : bytes);
-    for (unsigned i = 0; i < started; ++i) th[i].join();
-}
+    ~CopyHelpers() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    CopyHelpers(const CopyHelpers &) = delete;
+    CopyHelpers &operator=(const CopyHelpers &) = delete;
+    void copy(uint8_t *dst, const uint8_t *src, size_t bytes) {
+        const unsigned parts = (unsigned)th_.size() + 1;
+        if (parts < 2 || bytes < 2 * kMinPerThread) {
+            memcpy(dst, src, bytes);
+            return;
+        }
+        const size_t per = (bytes / parts + 4095) & ~(size_t)4095;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            dst_ = dst, src_ = src, bytes_ = bytes, per_ = per;
+            pending_ = parts - 1;
+            ++generation_;
+        }
+        cv_.notify_all();
+        memcpy(dst, src, per < bytes ? per : bytes);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+    }
+
+  private:
+    static constexpr size_t kMinPerThread = (size_t)2 << 20;
+    void work(unsigned part) {
+        uint64_t seen = 0;
+        for (;;) {
+            uint8_t *dst;
+            const uint8_t *src;
+            size_t bytes, per;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                dst = dst_, src = src_, bytes = bytes_, per = per_;
+            }
+            const size_t off = per * part;
+            if (off < bytes) memcpy(dst + off, src + off, bytes - off < per ? bytes - off : per);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    uint8_t *dst_ = nullptr;
+    const uint8_t *src_ = nullptr;
+    size_t bytes_ = 0, per_ = 0;
+    unsigned pending_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
 extern "C" int32_t zk_mle_to_bytes(zk_ctx *c, const zk_mle *t, uint8_t *out) {
     if (!c || !t || !out) return ZK_ERR_BAD_ARG;
     if (t->ctx != c) return ZK_ERR_CONTEXT_MISMATCH;
@@ -824,8 +884,9 @@ extern "C" int32_t zk_mle_to_bytes(zk_ctx *c, const zk_mle *t, uint8_t *out) {
     // device serialiser -> pinned staging (two buffers, the copy of chunk i + 1 under the host's copy-out of chunk i) -> caller
     size_t off = 0;
     const zk_mle *one[1] = {t};
+    CopyHelpers helpers((size_t)32 << t->n_vars);
     return stream_table_bytes(c, one, 1, [&](const uint8_t *p, size_t bytes) {
-        copy_out_parallel(out + off, p, bytes);
+        helpers.copy(out + off, p, bytes);
         off += bytes;
     });
 }

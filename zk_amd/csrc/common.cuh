@@ -6,7 +6,6 @@ namespace zk {
 
 constexpr int kBlock = 256;
 constexpr int kMaxFactors = 8;
-constexpr int kMaxLazy = 32;   // products accumulated unreduced between Montgomery reductions: 32 p^2 < 2^515 for every field, top limb <= 7 (redc_wide)
 
 struct FactorPtrs {
     const uint64_t *in[kMaxFactors];

@@ -397,10 +397,13 @@ ZK_HD void wide_mac(WideAcc &w, const uint32_t a[8], const uint32_t b[8]) {
     w.v[15] = acc_shift(acc);
     w.v[16] += (uint32_t)acc.lh;
 }
-// w * R^-1 mod p, fully reduced, for any w < 2^544 with a small top limb (w.v[16] <= 7: at most ~16 products of
-// values < p < 2^255).  redc of the low 512 bits gives s < 2^256 + p; the top limb contributes top * R mod p.
-// The 9-limb sum is < R + p + top*p (< 32p for every supported field while top <= 16) and is brought below p by
-// conditional subtraction of 16p, 8p, 4p, 2p, p.
+constexpr int kMaxLazy = 32;   // products accumulated unreduced between two Montgomery reductions (the contract of redc_wide, below)
+// w * R^-1 mod p, fully reduced, for any w < 2^544 whose top limb is small: the sum of at most kMaxLazy (= 32) products of
+// values < p, so top = w.v[16] <= floor(32 p^2 / 2^512) (1, 6 and 0 for the three shipped fields).  redc of the low 512 bits
+// gives s < R + p; the top limb contributes top * (R mod p) < top * p.  The 9-limb sum is therefore < R + p + top*p, and
+// ladder9<4> (conditional subtraction of 16p, 8p, 4p, 2p, p) brings anything below 32p under p.  So the contract is
+//     R/p + 1 + top_max < 32        (R/p = 5.3, 2.2, 13.7 for BN254 / BLS12-381 / BLS12-377 Fr)
+// which host_field.hpp's field_info() checks for every field it registers (a field that breaks it is refused, not mis-reduced).
 ZK_HD Fe redc_wide(const WideAcc &w, const FieldParams &P) {
     uint32_t m[8];
     Acc acc = {0, 0};

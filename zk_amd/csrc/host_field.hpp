@@ -107,6 +107,17 @@ inline const FieldInfo *field_info(int field) {
         memcpy(P.r2_29, k0.l, sizeof k0.l);
         memcpy(P.r2s_29, k1.l, sizeof k1.l);
     }
+    // redc_wide's contract (field.cuh): R/p + 1 + top_max < 32 with top_max = floor(kMaxLazy * p^2 / 2^512).  Power-of-two upper
+    // bounds of both terms suffice for the shipped fields (11, 13 and 17); a modulus that fails is refused here.
+    {
+        const int rp_log = 257 - (int)P.bits;                                  // R / p < 2^(257 - bits)
+        int lazy_log = 0;
+        while ((1 << lazy_log) < kMaxLazy) ++lazy_log;
+        const int top_log = lazy_log + 2 * (int)P.bits - 512;                  // kMaxLazy * p^2 / 2^512 < 2^top_log
+        const uint64_t rp = rp_log >= 0 && rp_log < 32 ? (1ull << rp_log) : ~0ull;
+        const uint64_t top = top_log < 0 ? 0 : (top_log < 32 ? (1ull << top_log) : ~0ull);
+        if (rp_log < 0 || rp + 1 + top >= 32 || rp + 1 + top < rp) return nullptr;
+    }
     I.two_adicity = adicity[field];
     I.generator = gen[field];
     // TWO_ADIC_ROOT_OF_UNITY = g^t with p - 1 = 2^s * t
