@@ -55,6 +55,35 @@ def test_shard_provers_match_unsharded_oracle(field, world, k, D, n_vars, gather
     ctx.close()
 
 
+def test_shard_rounds_derive_behind_the_allreduce():
+    """The sharded prover's big rounds run the kernels that leave out S(1) and accumulate the leading coefficient instead of S(D)
+    (both linear in the shards); k_lanes_transcript derives the two from the all-reduced lanes.  Child processes force the variants
+    on at every size (tests/shard_skip_check.py), run the default thresholds on shards big enough to reach them, and run with the
+    derivation switched off; every proof is compared with the oracle's proof of the unsharded tables bit for bit."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drop = ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_LEAD_MIN_PAIRS", "ZK_SHARD_SKIP1", "ZK_CHECK_CASES", "ZK_CHECK_FIELDS")
+    base = {k: v for k, v in os.environ.items() if k not in drop}
+    runs = [
+        # SKIP1 + LEAD in every fused round of every shape that has them (no quad kernel: it would take the small rounds)
+        dict(ZK_SKIP1_MIN_PAIRS="1", ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0"),
+        # LEAD only (round 0 included: sums-only LEAD kernels), then SKIP1 only
+        dict(ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0"),
+        dict(ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0"),
+        # the shipped thresholds on shards of 2^18 (two ranks) and 2^17 elements (four ranks, three factors)
+        dict(ZK_CHECK_CASES="2:2:2:19,4:3:3:19", ZK_CHECK_FIELDS="1"),
+        # round 4's behaviour: every sum formed by the round kernels
+        dict(ZK_SHARD_SKIP1="0", ZK_SKIP1_MIN_PAIRS="1", ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_FIELDS="1"),
+    ]
+    for extra in runs:
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "shard_skip_check.py")], env=dict(base, **extra), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0 and "shard skip ok" in r.stdout, str(extra) + r.stdout + r.stderr
+
+
 def test_single_rank_orchestration_equals_plain_prover():
     field = zk_amd.BN254_FR
     ctx = zk_amd.Context(field, 0)

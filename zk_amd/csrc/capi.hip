@@ -1093,7 +1093,7 @@ extern "C" int32_t zk_product_evaluate(zk_ctx *c, const zk_mle *const *f, uint64
 // Per-prover device scratch: the word sponge, the current challenge, and the proof being assembled.  Nothing in the
 // round loop waits on the host: k_round (+fold) -> k_round_tail (reduce + transcript) -> k_round (+fold) -> ...
 constexpr size_t kChalWords = kChallengeBytes / 8;                                   // one challenge record, in u64
-constexpr size_t kEpartBytes = (size_t)(kPipeMaxWorkBlocks + 2) * 16 * 32;         // E partials of one pipelined round (+ total + counter)
+constexpr size_t kEpartBytes = (size_t)((kMidMaxWorkBlocks > kPipeMaxWorkBlocks ? kMidMaxWorkBlocks : kPipeMaxWorkBlocks) + 2) * 16 * 32;         // E partials of one pipelined round (+ total + counter)
 struct ProverScratch {
     WordSponge *d_sponge;
     uint64_t *d_challenge;   // TWO challenge records (round s uses slot s & 1): a pipelined launch reads r_{s-2} while r_{s-1} is written
@@ -1180,6 +1180,8 @@ struct TailTargets {
     uint64_t *out_ch;       // challenge record (device), may be null
     uint64_t *d_challenge;  // challenge for the next fused fold
     uint64_t *lanes;        // 32-bit digit lanes for the cross-GPU all-reduce, may be null
+    TailDerive *lanes_dv;   // with lanes (host memory, may be null): out -- what k_lanes_transcript has to derive after the all-reduce
+                            // (S(1) from the claim, S(D) from the leading coefficient); null: the round kernels compute every sum
 };
 static std::vector<Fe> interp_weights(uint32_t D, const FieldParams &P);   // defined with the verifier
 // Rounds with at least this many pairs leave out the t = 1 sums (k_round_kd SKIP1 + TailDerive): below it the extra
@@ -1208,6 +1210,11 @@ static uint64_t lead_min_pairs() {
     static const uint64_t v = env_u64("ZK_LEAD_MIN_PAIRS", (uint64_t)1 << 16, 1, (uint64_t)1 << 40);
     return v;
 }
+// ZK_SHARD_SKIP1=0: the sharded prover's round kernels compute every sum themselves (round 4's behaviour; A/B)
+static bool shard_skip_on() {
+    static const bool v = env_u64("ZK_SHARD_SKIP1", 1, 0, 1) != 0;
+    return v;
+}
 static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, uint64_t q, uint32_t D, bool fused,
                            const uint64_t *d_r, const TailTargets &tt, const TailDerive *dv = nullptr, DeferredTail *defer = nullptr) {
     if (defer) defer->blocks = 0;
@@ -1215,13 +1222,21 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
     if (fast_degree(D)) {
         uint32_t total = 0;
         int first = 0;
-        bool skip1 = dv && dv->prev_rp && fused && !tt.lanes && D <= (uint32_t)kMaxSkipDegree && q >= skip1_min_pairs();
-        bool lead = !tt.lanes && q >= lead_min_pairs();   // (the launchers clear it for shapes without the variant)
+        // (sharded: both variants accumulate quantities that are linear in the shards, so they survive the all-reduce; the
+        // derivations move behind it -- tt.lanes_dv tells zk_shard_prover_round_finish what to derive)
+        const bool may_derive = !tt.lanes || (tt.lanes_dv && shard_skip_on());
+        bool skip1 = dv && dv->prev_rp && fused && may_derive && D <= (uint32_t)kMaxSkipDegree && q >= skip1_min_pairs();
+        bool lead = may_derive && q >= lead_min_pairs();   // (the launchers clear it for shapes without the variant)
         auto tail_dv = [&]() {
             TailDerive t = skip1 && dv ? *dv : TailDerive{};
             t.lead = lead ? D : 0;
+            if (tt.lanes) {
+                if (tt.lanes_dv) *tt.lanes_dv = t;
+                t.local_only = 1;
+            }
             return t;
         };
+        if (tt.lanes_dv) *tt.lanes_dv = TailDerive{};
         if (ts.n_terms == 2 && ts.term_k[1] == 1) {   // product + one single-factor term (a GKR layer): one pass
             uint32_t g = 0;
             const int lrc = launch_round_plus1(launch_ctx(c), fp, ts.term_k[0], q, D, fused, d_r, &g, &skip1, &lead);
@@ -1504,7 +1519,7 @@ static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uin
 }
 // Enqueue the next round: apply the pending fold (prover.rs:64 of the previous round, fused) and compute this round's
 // sums (prover.rs:49-56).  `lanes` selects the sharded form (sums -> digit lanes, transcript deferred).
-static int32_t round_enqueue(RoundState &st, uint64_t *lanes, DeferredTail *defer = nullptr) {
+static int32_t round_enqueue(RoundState &st, uint64_t *lanes, DeferredTail *defer = nullptr, TailDerive *lanes_dv = nullptr) {
     zk_ctx *c = st.c;
     if (st.pending_fold) st.vars_left -= 1;           // tables shrink by the fold fused into this launch
     const uint64_t m = st.vars_left;                  // variables of this round's table
@@ -1521,6 +1536,7 @@ static int32_t round_enqueue(RoundState &st, uint64_t *lanes, DeferredTail *defe
     tt.out_ch = st.ps.d_ch + st.round * 4;
     tt.d_challenge = chal_cur(st);
     tt.lanes = lanes;
+    tt.lanes_dv = lanes_dv;
     int32_t rc;
     if (st.pending_fold && !fast_degree(st.D)) {
         // generic degree: fold as separate launches, then the per-point passes
@@ -1558,6 +1574,21 @@ static uint64_t pipe_max_pairs() {
     }();
     return v;
 }
+// Above pipe_max_pairs() and up to this many pairs the same schedule can run on k_round_mid (four lanes per pair index instead of
+// a sixteen-lane row): ZK_PIPE_MID_MAX_PAIRS.  DEFAULT 0 = no such rounds: measured on MI355X (profiles/r05_mid_rounds_ab.log) a
+// k_round_mid launch takes 17.5 / 22 / 36 us at 2^13 / 2^14 / 2^15 pairs against 16.4 / 18.3 / 21.6 us for the classic round
+// kernel + k_round_tail it would replace -- every round added to the pipeline made the n = 20 proof ~10 us slower.  The kernel
+// stays (bit-exact under the whole prover grid, tests/test_gpu_parity.py) as the measured answer to "pipeline the middle rounds".
+static uint64_t pipe_mid_max_pairs() {
+    static const uint64_t v = [] {
+        uint64_t x = env_u64("ZK_PIPE_MID_MAX_PAIRS", 0, 0, (uint64_t)1 << 40);
+        if (!pipe_max_pairs()) return (uint64_t)0;   // ZK_PIPE_MAX_PAIRS=0 switches every pipelined round off (1: k_round_mid takes them all)
+        return x > mid_max_pairs() ? mid_max_pairs() : x;
+    }();
+    return v;
+}
+static inline uint64_t pipe_limit_pairs() { return std::max(pipe_max_pairs(), pipe_mid_max_pairs()); }
+static inline bool pipe_use_mid(uint64_t q) { return q > pipe_max_pairs(); }
 static bool pipe_shape(const RoundState &st, int *k, int *extra) {
     if (st.terms.n_terms == 1) {
         *k = st.terms.term_k[0];
@@ -1617,10 +1648,10 @@ static bool finish_pipe_applies(const RoundState &st) {
 // May round (st.round + 1) be prepared by the pipeline, given that round st.round's table has m_s variables?
 static bool pipe_wants_next(const RoundState &st, uint64_t m_s) {
     int k, extra;
-    if (!pipe_max_pairs() || !pipe_shape(st, &k, &extra)) return false;
+    if (!pipe_limit_pairs() || !pipe_shape(st, &k, &extra)) return false;
     if (m_s < 3) return false;                                                       // the launches after it need 8 elements
     if (!finish_pipe_on() && m_s - 1 <= (uint64_t)kFinishVars) return false;          // the classic finisher takes round + 1
-    return ((uint64_t)1 << (m_s - 2)) <= pipe_max_pairs();
+    return ((uint64_t)1 << (m_s - 2)) <= pipe_limit_pairs();
 }
 // every remaining round in one launch of the pipelined finisher, from whatever state the loop is in
 static int32_t finish_pipe_enqueue(RoundState &st) {
@@ -1685,6 +1716,7 @@ static int32_t pipe_enter(RoundState &st, const DeferredTail &dt) {
     pl.fold = false;
     pl.emit = 1;
     pl.q = (uint64_t)1 << (st.vars_left - 2);   // vars_left = variables of this round's table (after its fold)
+    pl.mid = pipe_use_mid(pl.q);
     pl.chal_fold = nullptr;
     pl.e_partials = epart_of_round(st, st.round + 1);
     pl.done_counter = epart_counter(st, st.round + 1);
@@ -1724,6 +1756,7 @@ static int32_t pipe_step(RoundState &st) {
     pl.emit = stay ? 1 : 0;
     pl.q = m >= 3 ? (uint64_t)1 << (m - 3) : 0;
     if (pl.q == 0) return ZK_ERR_BAD_ARG;        // cannot happen: the finisher takes tables this small
+    pl.mid = pipe_use_mid(pl.q);
     pl.chal_fold = chal_prev(st);
     pl.e_partials = epart_of_round(st, st.round + 1);
     pl.done_counter = epart_counter(st, st.round + 1);
@@ -2012,6 +2045,7 @@ struct zk_shard_prover {
     uint32_t world;
     uint64_t local_rounds, total_rounds;
     uint64_t *d_lanes;    // (D+1)*8 u64 lanes
+    TailDerive lanes_dv;  // what round_finish derives from the all-reduced lanes (set by round_begin)
     uint64_t *d_tail;     // k * 2^tail_s elements: this rank's shard tables at the moment of the gather
     size_t tail_bytes;
     uint32_t tail_s;      // variables left in the local tables when gathered
@@ -2084,7 +2118,8 @@ extern "C" int32_t zk_shard_prover_round_begin(zk_shard_prover *sp) {
     RoundState &st = sp->st;
     if (st.round >= sp->local_rounds) return ZK_ERR_BAD_ARG;
     ZKCHK(use_device(st.c));
-    return round_enqueue(st, sp->d_lanes);
+    sp->lanes_dv = TailDerive{};
+    return round_enqueue(st, sp->d_lanes, nullptr, &sp->lanes_dv);
 }
 // after the caller's all-reduce of the lanes: reduce mod p, absorb, squeeze.  Asynchronous.
 extern "C" int32_t zk_shard_prover_round_finish(zk_shard_prover *sp) {
@@ -2094,7 +2129,7 @@ extern "C" int32_t zk_shard_prover_round_finish(zk_shard_prover *sp) {
     if (st.round >= sp->local_rounds || !st.pending_fold) return ZK_ERR_BAD_ARG;
     ZKCHK(use_device(c));
     k_lanes_transcript<<<1, 64, 0, c->stream>>>(sp->d_lanes, st.D + 1, st.ps.d_sponge, st.ps.d_rp + st.round * (st.D + 1) * 4,
-                                                st.ps.d_ch + st.round * 4, chal_cur(st), c->fi->P);
+                                                st.ps.d_ch + st.round * 4, chal_cur(st), c->fi->P, sp->lanes_dv);
     HIPCHK(hipGetLastError());
     ++st.round;
     return ZK_OK;

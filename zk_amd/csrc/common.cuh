@@ -112,6 +112,8 @@ struct TailDerive {
     const uint64_t *prev_chal; // challenge record of the previous round (r_{i-1})
     const uint64_t *w;         // the D + 1 weights, device memory (one buffer per context and degree)
     uint32_t lead;             // D > 0: slot D of the sums holds the leading coefficient L (k_round_kd LEAD); rebuild S(D)
+    uint32_t local_only;       // sharded prover: these are ONE rank's sums -- k_round_tail derives nothing (slot 1 -> 0, slot D keeps L:
+                               // both are linear in the shards); k_lanes_transcript derives from the all-reduced values
 };
 // S(D) of a degree-D round polynomial from S(0..D-1) and its leading coefficient L (in S[D]): D <= 3
 ZK_HD Fe lead_rebuild(uint32_t D, const Fe *S, const FieldParams &P) {

@@ -387,6 +387,10 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
     if (sponge && wave0) sp = lane_sponge_load(sponge, L);
     // wave w owns the sums t = w, w+4, ...: lanes stride over the blocks' partials, one VALU wave reduction, one barrier
     for (uint32_t t = wave; t < ns; t += kBlock / 64) {
+        if (derive1 && t == 1 && dv.local_only) {
+            if (lane == 0) fin[1] = fe_zero();   // no t = 1 partials exist; S(1) is derived after the all-reduce
+            continue;
+        }
         if (derive1 && t == 1) {
             // this wave would own t = 1: it evaluates the previous round polynomial at the previous challenge instead,
             //   claim = sum_t prev[t] * w[t] * prod_{u != t} (r - u)   (lane t takes term t; D + 1 multiplies deep)
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
         if (lane == 0) fin[t] = s;
     }
     __syncthreads();
-    if (derive1 || dv.lead) {
+    if ((derive1 || dv.lead) && !dv.local_only) {
         if (threadIdx.x == 0) {
             if (derive1) fin[1] = fe_sub(claim, fin[0], P);        // S(1) = S_prev(r_prev) - S(0)
             if (dv.lead) fin[dv.lead] = lead_rebuild(dv.lead, fin, P);   // slot D held the leading coefficient (k_round_kd LEAD)
@@ -784,16 +788,21 @@ __global__ void k_store_sponge(WordSponge w, WordSponge *__restrict__ dst, uint6
 }
 
 // Sharded prover, after the all-reduce: lanes hold sums over ranks of 32-bit digits.  Carry-propagate, reduce mod p
-// (value < world * p, world <= 2^16), then the same transcript step.  One lane.
+// (value < world * p, world <= 2^16), then the same transcript step.  One wave.
+// dv: the round kernels left out the t = 1 sums (prev_rp != null: S(1) = S_prev(r_prev) - S(0), the identity holds for the GLOBAL
+// sums) and / or put the leading coefficient in slot D (lead: the slot is linear in the shards, so its all-reduced value is the
+// global leading coefficient) -- the same derivations k_round_tail makes on one GPU, made here on the all-reduced values.
 __global__ void k_lanes_transcript(const uint64_t *__restrict__ lanes, uint32_t ns, WordSponge *__restrict__ sponge,
                                    uint64_t *__restrict__ out_rp, uint64_t *__restrict__ out_ch,
-                                   uint64_t *__restrict__ d_challenge, FieldParams P) {
+                                   uint64_t *__restrict__ d_challenge, FieldParams P, TailDerive dv) {
     __shared__ Fe fin[256];
     if (blockIdx.x != 0 || threadIdx.x >= 64) return;   // one wave, uniform control flow
+    const uint32_t lane = threadIdx.x;
+    const bool fixup = dv.prev_rp != nullptr || dv.lead != 0;
     // lane t takes sum t (t, t + 64, ...): the carry propagation and the 17-step ladder run once for all sums of a batch instead
     // of once per sum on every lane (the ladder is ~350 dependent steps: ~1 us of the serial chain of every exchanging round)
     for (uint32_t t0 = 0; t0 < ns; t0 += 64) {
-        const uint32_t t = t0 + threadIdx.x < ns ? t0 + threadIdx.x : ns - 1;
+        const uint32_t t = t0 + lane < ns ? t0 + lane : ns - 1;
         uint32_t v[9];
         uint64_t carry = 0;
 #pragma unroll
@@ -807,12 +816,38 @@ __global__ void k_lanes_transcript(const uint64_t *__restrict__ lanes, uint32_t 
         Fe r;
 #pragma unroll
         for (int i = 0; i < 8; ++i) r.v[i] = v[i];
-        if (t0 + threadIdx.x < ns) {
+        if (t0 + lane < ns) {
             fin[t] = r;
-            fe_store(out_rp, t, r);
+            if (!fixup) fe_store(out_rp, t, r);
         }
     }
     __syncthreads();
+    if (fixup) {   // (fast degrees only: ns <= 5)
+        if (dv.prev_rp) {
+            // claim = S_prev(r_prev) = sum_t prev[t] * w[t] * prod_{u != t} (r_prev - u): lane t takes term t
+            const Fe r = fe_load(dv.prev_chal, 0);
+            Fe term = fe_zero();
+            if (lane < ns) {
+                Fe one;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
+                term = fe_mul(fe_load(dv.prev_rp, lane), fe_load(dv.w, lane), P);
+                Fe node = fe_zero();   // Montgomery form of u
+                for (uint32_t u = 0; u < ns; ++u) {
+                    if (u != lane) term = fe_mul(term, fe_sub(r, node, P), P);
+                    node = fe_add(node, one, P);
+                }
+            }
+            const Fe claim = fe_wave_sum(term, P, 8);   // valid in lane 0
+            if (lane == 0) fin[1] = fe_sub(claim, fin[0], P);
+            __syncthreads();
+        }
+        if (dv.lead) {
+            if (lane == 0) fin[dv.lead] = lead_rebuild(dv.lead, fin, P);
+            __syncthreads();
+        }
+        if (lane < ns) fe_store(out_rp, lane, fin[lane]);
+    }
     transcript_round(sponge, fin, ns, d_challenge, out_ch, P);
 }
 

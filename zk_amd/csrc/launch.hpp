@@ -30,7 +30,8 @@ int launch_round_single_t(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k,
 
 
 // ---- pipelined rounds (pipe_kernels.cuh / pipe.hip): sums of round s as a polynomial in the pending challenge -------------
-constexpr uint32_t kPipeMaxWorkBlocks = 256;
+constexpr uint32_t kPipeMaxWorkBlocks = 256;   // k_round_pipe (hex rows)
+constexpr uint32_t kMidMaxWorkBlocks = 512;    // k_round_mid (quads): also the capacity of an E-partial buffer
 }  // namespace zk
 #include "pipe_args.hpp"
 namespace zk {
@@ -38,6 +39,7 @@ struct PipeLaunch {
     int k, extra;             // shape: k-factor product (+ one single-factor term)
     uint32_t D;
     bool fold;                // work blocks first fold fp.in (8q elements) -> fp.out (4q) at *chal_fold
+    bool mid;                 // k_round_mid (four lanes per pair index) instead of k_round_pipe's sixteen-lane rows
     int emit;                 // 1: write the E partials of the round with q pairs; 0: fold only (leaving the pipeline)
     uint64_t q;               // pairs of the round whose E is prepared
     const uint64_t *chal_fold;
@@ -49,6 +51,7 @@ bool pipe_shape_ok(int k, uint32_t D, int extra);
 uint32_t pipe_values_per_block(int k, uint32_t D);
 uint32_t pipe_rows_per_block(int k, uint32_t D, int extra);
 uint32_t pipe_work_blocks(int k, uint32_t D, int extra, uint64_t q);
+uint64_t mid_max_pairs();   // pair indices one k_round_mid launch can take (grid cap x unreduced products per lane)
 int launch_round_pipe(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t *out_work_blocks);
 // the pipelined finisher (k_finish_pipe): every remaining round in one launch; entry = kFinEntry* of pipe_kernels.cuh
 // (0 fresh tables, 1 tables with *chal_in pending, 2 the same with the E partials of the first round ready)

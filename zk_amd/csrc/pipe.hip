@@ -52,8 +52,41 @@ static void launch_shape(const RoundLaunchCtx &lc, const FactorPtrs &fp, const P
         k_round_pipe<K, D, EXTRA, false><<<g + 1, kThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail, sc1_handoff());
 }
 
+// k_round_mid: one pair index per quad and pass.  As many blocks as one pass needs, up to the cap (the launch ends with ONE block
+// adding all the block partials up: ~1 us per 128 of them), then more passes (at most kMaxLazy: unreduced products per lane).
+uint64_t mid_max_pairs() { return (uint64_t)kMidMaxWorkBlocks * kMidQuads * kMaxLazy; }
+static uint32_t mid_work_blocks(uint64_t q) {
+    uint64_t g = (q + kMidQuads - 1) / kMidQuads;
+    if (g > kMidMaxWorkBlocks) g = kMidMaxWorkBlocks;
+    return (uint32_t)(g ? g : 1);
+}
+template <int K, int D, int EXTRA>
+static void launch_mid_shape(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t g) {
+    if (pl.fold)
+        k_round_mid<K, D, EXTRA, true><<<g + 1, kMidThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail);
+    else
+        k_round_mid<K, D, EXTRA, false><<<g + 1, kMidThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail);
+}
+static int launch_round_mid(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t *out_work_blocks) {
+    if (pl.q > mid_max_pairs()) return kLaunchUnsupported;
+    const uint32_t g = mid_work_blocks(pl.q);
+    switch (pl.k * 100 + (int)pl.D * 10 + pl.extra) {
+        case 110: launch_mid_shape<1, 1, 0>(lc, fp, pl, g); break;
+        case 120: launch_mid_shape<1, 2, 0>(lc, fp, pl, g); break;
+        case 220: launch_mid_shape<2, 2, 0>(lc, fp, pl, g); break;
+        case 230: launch_mid_shape<2, 3, 0>(lc, fp, pl, g); break;
+        case 330: launch_mid_shape<3, 3, 0>(lc, fp, pl, g); break;
+        case 221: launch_mid_shape<2, 2, 1>(lc, fp, pl, g); break;
+        default: return kLaunchUnsupported;
+    }
+    if (hipGetLastError() != hipSuccess) return kLaunchHipError;
+    *out_work_blocks = g;
+    return kLaunchOk;
+}
+
 int launch_round_pipe(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t *out_work_blocks) {
     if (!pipe_shape_ok(pl.k, pl.D, pl.extra)) return kLaunchUnsupported;
+    if (pl.mid) return launch_round_mid(lc, fp, pl, out_work_blocks);
     const uint32_t g = pipe_work_blocks(pl.k, pl.D, pl.extra, pl.q);
     switch (pl.k * 100 + (int)pl.D * 10 + pl.extra) {
         case 110: launch_shape<1, 1, 0>(lc, fp, pl, g); break;
