@@ -650,16 +650,19 @@ def test_evaluate_fold_path_still_exact():
 
 
 _EVAL_STREAM_CHILD = """
-import sys, numpy as np
+import os, sys, numpy as np
 sys.path.insert(0, %r)
 import zk_amd
 from oracle import binding as orc
 checked = 0
+SIZES = tuple(int(x) for x in os.environ.get("ZK_EVAL_SIZES", "19,20,21,22").split(","))
+ALL_FIELDS = os.environ.get("ZK_EVAL_ALL_FIELDS") == "1"
+MAXN = int(os.environ.get("ZK_EVAL_MAXN", "19"))
 for field in (zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR):
     c = zk_amd.Context(field, 0)
     p = zk_amd.modulus(field)
-    for n in (19, 20, 21, 22):          # ZK_EVAL_STREAM_MIN=19: k_eval_stream with L = 10, 11, 12, 13
-        if n > 20 and field != zk_amd.BN254_FR:
+    for n in SIZES:          # ZK_EVAL_STREAM_MIN=19: k_eval_stream with L = 10, 11, 12, 13 at n = 19..22 (9 variables left)
+        if n > 20 and field != zk_amd.BN254_FR and not ALL_FIELDS:
             continue
         tab = orc.fill_random(field, 4500 + n, 1 << n)
         t = zk_amd.MultiLinearPolynomial.new(c, n, tab)
@@ -671,8 +674,8 @@ for field in (zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR):
             checked += 1
         t.free()
     # worst case of the column sums: every element p - 1 (all limbs of the halves near their maxima) at a point of p - 1's
-    n = 19
-    tab = orc.from_ints(field, [p - 1] * (1 << n))
+    n = MAXN
+    tab = np.tile(orc.from_int(field, p - 1), (1 << n, 1))
     pt = orc.from_ints(field, [p - 1 - i for i in range(n)])
     t = zk_amd.MultiLinearPolynomial.new(c, n, tab)
     assert np.array_equal(t.evaluate(pt), orc.mle_evaluate(field, n, tab, pt)), (field, "max")
@@ -692,8 +695,11 @@ def test_evaluate_streaming_kernel_forced_at_small_sizes():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # 9 variables left (512 workgroups: L = 10, 11, 12, 13) and the shipped choice (8 left up to 21 variables: L = 11, 12, 13, 13)
-    for extra in (dict(ZK_EVAL_STREAM_LEAVE="9"), dict()):
-        env = {k: v for k, v in os.environ.items() if k != "ZK_EVAL_STREAM_LEAVE"}
+    # ... and 7 variables left at n = 21, 22: L = 14 (128 rows per lane) and L = 15 (256 rows: the redc bound 2^136 * p of the column
+    # sums) on ALL three fields, the all-(p - 1) table at L = 15 (L = 14 was never run, L >= 13 only on BN254)
+    for extra in (dict(ZK_EVAL_STREAM_LEAVE="9"), dict(),
+                  dict(ZK_EVAL_STREAM_LEAVE="7", ZK_EVAL_SIZES="21,22", ZK_EVAL_ALL_FIELDS="1", ZK_EVAL_MAXN="22")):
+        env = {k: v for k, v in os.environ.items() if k not in ("ZK_EVAL_STREAM_LEAVE", "ZK_EVAL_SIZES", "ZK_EVAL_ALL_FIELDS", "ZK_EVAL_MAXN")}
         r = subprocess.run([sys.executable, "-c", _EVAL_STREAM_CHILD % root], env=dict(env, ZK_EVAL_STREAM_MIN="19", **extra),
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "evaluate stream ok" in r.stdout, str(extra) + r.stdout + r.stderr

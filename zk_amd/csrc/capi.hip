@@ -2429,11 +2429,14 @@ static int32_t ntt_build_tables(zk_ctx *c, NttPlan &pl, const Fe &omega) {
     }
     pl.w_lo = lo;
     pl.w_hi = hi;
-    // full inter-pass tables for the middle passes while they stay <= 2^24 entries (512 MiB)
+    // full inter-pass tables for the middle passes while they stay <= 2^24 entries (512 MiB): a 32-byte read per element instead
+    // of the multiplication that composes the twiddle from the two-level table -- the passes are bound by VALU issue, not by HBM
+    // (ZK_NTT_FULL_TABLE_MAX_LOG: largest table built, log2 entries; 0 = compose everything.  A/B: profiles/r05_ntt_table_ab.log)
+    static const uint32_t full_max_log = (uint32_t)env_u64("ZK_NTT_FULL_TABLE_MAX_LOG", 24, 0, 24);
     uint32_t lo_sum = 0;
     for (uint32_t p = 0; p + 1 < pl.n_pass; ++p) {
         const uint32_t log_entries = pl.log_n - lo_sum;   // R_p * I_p = n / O_p
-        if (log_entries <= 24) {
+        if (log_entries <= full_max_log) {
             uint64_t *t = nullptr;
             if (raw_alloc(c, (size_t)32 << log_entries, (void **)&t) == ZK_OK) {
                 k_ntt_full_table<<<grid_for(1ull << log_entries), kBlock, 0, c->stream>>>(t, pl, log_entries - pl.l[p], pl.l[p], lo_sum, c->fi->P);

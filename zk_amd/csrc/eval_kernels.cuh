@@ -147,22 +147,12 @@ __global__ __launch_bounds__(kEvalStreamThreads) void k_eval_stream(const uint64
     uint4 x[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) x[i] = nt_load16(src + (uint64_t)i * 256);
-    // ---- the four small eq tables: wave w builds table w, lane j < 16 entry j (chains of <= 3 multiplications, under the loads)
+    // ---- the four small eq tables: wave w builds table w, lane j < 16 entry j (two levels of multiplications, under the loads)
     {
         const uint32_t first = wave == 0 ? 0u : wave == 1 ? 4u : wave == 2 ? 7u : 11u;
         const uint32_t want = wave == 1 ? 3u : 4u;
         const uint32_t nb = first >= L ? 0u : (L - first < want ? L - first : want);
-        Fe one;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
-        Fe acc = one;
-        for (uint32_t k = 0; k < nb; ++k) {
-            Fe r;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) r.v[i] = pt.r[first + k][i];   // wave-uniform index: scalar loads from the argument segment
-            const Fe sel = (lane >> k) & 1 ? r : fe_sub(one, r, P);
-            acc = k == 0 ? sel : fe_mul(acc, sel, P);
-        }
+        const Fe acc = eq_entry_depth2(pt, nb ? first : 0u, nb, lane, P);   // two levels of multiplications (kernels.cuh)
         if (lane < 16) eq[wave][lane] = acc;
     }
     __syncthreads();

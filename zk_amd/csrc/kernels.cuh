@@ -213,6 +213,35 @@ __global__ __launch_bounds__(kBlock) void k_eval_sum(const uint64_t *__restrict_
     }
 }
 
+// Entry j (< 2^nb, nb <= 4) of the eq table over the index bits first .. first + nb - 1 of a point record PT (r[bit][8], Montgomery
+// form; first and nb wave-uniform, so the coordinates are scalar loads from the argument segment):
+//   (sel_0 * sel_1) * (sel_2 * sel_3),   sel_k = r_k if bit k of j is set, else 1 - r_k;   absent factors are 1
+// TWO levels of multiplications, the two of the first level independent of each other (they share the multiplier's issue slots),
+// instead of a chain of three: the table build is the head of every evaluate workgroup's dependent chain.  Exact field
+// arithmetic: the same canonical entries whatever the association.
+template <class PT>
+ZK_D Fe eq_entry_depth2(const PT &pt, uint32_t first, uint32_t nb, uint32_t j, const FieldParams &P) {
+    Fe one;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
+    Fe f[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t idx = (uint32_t)k < nb ? first + k : first;   // (in range even when the factor is absent)
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.v[i] = pt.r[idx][i];
+        const Fe sel = (j >> k) & 1 ? r : fe_sub(one, r, P);
+        f[k] = (uint32_t)k < nb ? sel : one;
+    }
+#ifdef ZK_EQ_CHAIN   // A/B builds only: round 4's chain of three dependent multiplications
+    return fe_mul(fe_mul(fe_mul(f[0], f[1], P), f[2], P), f[3], P);
+#else
+    const Fe a = fe_mul(f[0], f[1], P), b = fe_mul(f[2], f[3], P);
+    return fe_mul(a, b, P);
+#endif
+}
+
 constexpr int kEvalLowMax = 12, kEvalLowMin = 8;   // L = 8: one element per thread
 struct EvalLowPoint {   // r for index bit p (Montgomery form), p = 0 the least significant bit = the LAST variable
     uint32_t r[kEvalLowMax][8];
@@ -232,17 +261,7 @@ __global__ __launch_bounds__(kBlock) void k_eval_low(const uint64_t *__restrict_
         if ((uint32_t)i < n_m) x[i] = fe_load(in, base + (uint64_t)i * 256);
     if (wave < 3) {   // table `wave`: bits 4*wave .. (the third table has L - 8 bits); lane j < 16 builds entry j
         const uint32_t nb = wave < 2 ? 4u : L - 8;
-        Fe one;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
-        Fe acc = one;
-        for (uint32_t k = 0; k < nb; ++k) {
-            Fe r;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) r.v[i] = pt.r[4 * wave + k][i];   // wave-uniform index: scalar loads from the argument segment
-            const Fe sel = (lane >> k) & 1 ? r : fe_sub(one, r, P);
-            acc = k == 0 ? sel : fe_mul(acc, sel, P);
-        }
+        const Fe acc = eq_entry_depth2(pt, wave < 2 ? 4 * wave : 8u, nb, lane, P);
         if (lane < 16) eq[wave][lane] = acc;
     } else if (ph.n) {
         const Fe f = eval_high_weight(ph, blockIdx.x, lane, P);
