@@ -22,7 +22,7 @@ while time.time() < t_end:
     f = rng.randrange(3)
     c = ctxs[f]
     p = zk_amd.modulus(f)
-    kind = rng.choice(["prove", "prove", "terms", "evaluate", "fold", "gkr", "gkr_wide", "evaluate_big", "prod_reduce", "to_bytes", "coeff"])
+    kind = rng.choice(["prove", "prove", "terms", "evaluate", "fold", "gkr", "gkr_wide", "evaluate_big", "prod_reduce", "to_bytes", "coeff", "shard"])
     if kind == "prove":
         k = rng.choice([1, 2, 2, 3, 3, 4, 5, 8])
         D = rng.choice([max(1, k), k, k + 1, rng.randrange(1, 7)])
@@ -33,6 +33,32 @@ while time.time() < t_end:
         pp = ProductPoly.new([MLE.new(c, n, t) for t in tabs])
         proof, ch = SumcheckProver(D).prove_partial(pp, s, consume=rng.random() < 0.5)
         assert np.array_equal(proof.round_polys, want_rp) and np.array_equal(ch, want_ch), ("prove", f, k, D, n)
+    elif kind == "shard":   # W shard provers in this process, the lane all-reduce by hand, vs the oracle's unsharded proof (round 5:
+        # at 2^17+ local pairs the lanes carry [S(0), 0, .., L] and k_lanes_transcript derives S(1), S(D) from the reduced values)
+        import torch
+        from zk_amd.distributed import GpuShardBackend, shard_of
+        world = rng.choice([1, 2, 2, 4, 8])
+        k, D = rng.choice([(2, 2), (2, 2), (3, 3), (1, 1), (2, 3), (1, 2)])
+        w = world.bit_length() - 1
+        n = w + rng.choice([1, 2, 5, 9, 12, 14, 17, 18] if k <= 2 else [1, 4, 9, 13, 17])
+        tabs = [orc.fill_random(f, rng.randrange(1 << 30), 1 << n) for _ in range(k)]
+        s = orc.fill_random(f, rng.randrange(1 << 30), 1)[0]
+        want_rp, want_ch = orc.sumcheck_prove(f, n, tabs, D, s, False)
+        backs = [GpuShardBackend(ProductPoly.new([MLE.new(c, n - w, shard_of(t, g, world)) for t in tabs]), D, s, world) for g in range(world)]
+        gb = rng.choice([0, 0, 3, 10, 13])
+        while backs[0].local_vars_left() > gb:
+            lanes = [b.round_begin() for b in backs]
+            total = torch.stack(lanes).sum(dim=0)
+            for b, l in zip(backs, lanes):
+                l.copy_(total)
+                b.round_finish()
+        gathered = torch.cat([b.tail().clone() for b in backs])
+        for b in backs:
+            b.tail_rounds(gathered)
+        for b in backs:
+            rp, ch = b.results()
+            assert np.array_equal(rp, want_rp) and np.array_equal(ch, want_ch), ("shard", f, world, k, D, n, gb)
+            b.close()
     elif kind == "terms":
         shape = rng.choice([[2, 1], [2, 1], [3, 1], [1, 1], [2, 2], [2, 1, 1], [3, 2]])
         D = max(shape) + rng.randrange(2)
