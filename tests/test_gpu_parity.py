@@ -746,7 +746,7 @@ def test_skip1_rounds_bit_exact():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = {k: v for k, v in os.environ.items()
-            if k not in ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES", "ZK_LEAD_MIN_PAIRS", "ZK_ROUND0_DOT29", "ZK_PIPE_MID_MAX_PAIRS")}
+            if k not in ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES", "ZK_LEAD_MIN_PAIRS", "ZK_ROUND0_DOT29", "ZK_PIPE_MID_MAX_PAIRS", "ZK_CHECK_FIELDS")}
     runs = [
         # SKIP1 kernels everywhere (no quad kernel, no pipeline: they would take the small rounds)
         dict(ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0"),
@@ -771,8 +771,9 @@ def test_skip1_rounds_bit_exact():
         # k_round_mid (four lanes per pair index) instead of the sixteen-lane rows in EVERY pipelined round, small ones included ...
         dict(ZK_PIPE_MAX_PAIRS="1", ZK_CHECK_SIZES="3,4,7,10,12,14,16,18"),
         # ... entered right after LEAD + SKIP1 rounds, up to 2^17 pairs (several passes per quad), no quad kernel in between
+        # (one field: n = 19 is the size whose first pipelined round needs two passes per quad, and its oracle proofs take seconds)
         dict(ZK_PIPE_MAX_PAIRS="1", ZK_PIPE_MID_MAX_PAIRS="131072", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0",
-             ZK_CHECK_SIZES="11,13,15,17,19"),
+             ZK_CHECK_SIZES="11,13,15,17,19", ZK_CHECK_FIELDS="1"),
         # ... and switched off (round 4's schedule: hex rows up to 2^12 pairs, classic rounds above)
         dict(ZK_PIPE_MID_MAX_PAIRS="0", ZK_CHECK_SIZES="14,16,18"),
     ]
