@@ -625,15 +625,6 @@ def main():
         result["roofline"]["note"] = (f"per-rank launch on a 2^{local_vars}-element shard ({(32 << local_vars) >> 20} MiB: within the "
                                       "256 MiB Infinity Cache from 2^22 down, so not an HBM measurement)")
 
-    def clock_warm(ms=60.0):
-        """untimed folds until the shader clock is back up: the rows below are latency-bound calls of tens of microseconds, and several
-        of them follow seconds of host-only work (the absorbing `prove`, the CPU rows) that leave the GPU at idle clocks"""
-        t_w = time.perf_counter()
-        while (time.perf_counter() - t_w) * 1e3 < ms:
-            for _ in range(32):
-                table.fold_into(r, out)
-            ctx.synchronize()
-
     if rank == 0 and not args.no_extra and world == 1:
         extra = {}
         try:
@@ -647,8 +638,8 @@ def main():
                 s = pp.round_sums(1)
                 claimed = zk_amd.fe_from_int(field, zk_amd.fe_to_int(field, s[0]) + zk_amd.fe_to_int(field, s[1]))
                 prover = zk_amd.SumcheckProver(2)
-                prover.prove_partial(pp, claimed)   # warm
-                clock_warm()
+                for _ in range(3):
+                    prover.prove_partial(pp, claimed)   # warm (the rows below are latency-bound: their own calls are the warm-up)
                 # the whole call under std::chrono inside the library (every launch, the transcript, the download of the
                 # proof, the one host wait) -- what a compiled host sees; the same call through this Python binding beside it
                 ms = sorted(zk_amd.bench_prove_partial(pp, 2, claimed, 11))
@@ -682,8 +673,8 @@ def main():
             for n in (18, 19, 20, 21):
                 tn = zk_amd.MultiLinearPolynomial.random(ctx, n, 0x5EED0E00 + n, 0)
                 pt = tr2.sample_n_field_elements(field, n)
-                tn.evaluate(pt)
-                clock_warm()
+                for _ in range(10):
+                    tn.evaluate(pt)   # warm
                 ms = sorted(zk_amd.bench_evaluate(tn, pt, 11))      # std::chrono around zk_mle_evaluate inside the library
                 extra[f"evaluate_us_n{n}"] = ms[5] * 1e3
                 ts = []
@@ -700,8 +691,8 @@ def main():
                 for n in sizes:
                     tn = zk_amd.MultiLinearPolynomial.random(cx, n, 0x5EED0E00 + n, 0)
                     pt = tr2.sample_n_field_elements(fld, n)
-                    tn.evaluate(pt)
-                    clock_warm()
+                    for _ in range(10):
+                        tn.evaluate(pt)   # warm
                     ms = sorted(zk_amd.bench_evaluate(tn, pt, 21))
                     extra[f"evaluate_us_n{n}_{tag}"] = ms[10] * 1e3
                     extra[f"evaluate_us_n{n}_{tag}_min"] = ms[0] * 1e3
