@@ -1231,6 +1231,7 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
             TailDerive t = skip1 && dv ? *dv : TailDerive{};
             t.lead = lead ? D : 0;
             if (tt.lanes) {
+                if (t.prev_rp) t.claim = tt.lanes + (size_t)kMaxSums * 8;   // one element behind the lanes (zk_shard_prover_create allocates it)
                 if (tt.lanes_dv) *tt.lanes_dv = t;
                 t.local_only = 1;
             }
@@ -2074,7 +2075,7 @@ extern "C" int32_t zk_shard_prover_create(zk_ctx *c, zk_mle *const *f, uint64_t 
     sp->gathered_bytes = 0;
     // the shard tables are consumed (folded in place) unless one is listed twice (see prove_core)
     int32_t rc = round_state_init(sp->st, c, f, k, D, /*consume=*/!has_duplicate_handles(f, k), sp->total_rounds);
-    if (rc == ZK_OK) rc = pool_alloc(c, (size_t)kMaxSums * 8 * sizeof(uint64_t), (void **)&sp->d_lanes);
+    if (rc == ZK_OK) rc = pool_alloc(c, ((size_t)kMaxSums * 8 + 4) * sizeof(uint64_t), (void **)&sp->d_lanes);
     if (rc == ZK_OK) {
         Sponge host;
         host.init();
@@ -2093,7 +2094,7 @@ extern "C" int32_t zk_shard_prover_destroy(zk_shard_prover *sp) {
     zk_ctx *c = sp->st.c;
     (void)hipSetDevice(c->device);
     round_state_release(sp->st);
-    pool_free(c, sp->d_lanes, (size_t)kMaxSums * 8 * sizeof(uint64_t));
+    pool_free(c, sp->d_lanes, ((size_t)kMaxSums * 8 + 4) * sizeof(uint64_t));
     pool_free(c, sp->d_tail, sp->tail_bytes);
     pool_free(c, sp->d_gathered, sp->gathered_bytes);
     delete sp;
@@ -2128,7 +2129,12 @@ extern "C" int32_t zk_shard_prover_round_finish(zk_shard_prover *sp) {
     zk_ctx *c = st.c;
     if (st.round >= sp->local_rounds || !st.pending_fold) return ZK_ERR_BAD_ARG;
     ZKCHK(use_device(c));
-    k_lanes_transcript<<<1, 64, 0, c->stream>>>(sp->d_lanes, st.D + 1, st.ps.d_sponge, st.ps.d_rp + st.round * (st.D + 1) * 4,
+    {
+        uint32_t lw = 0;
+        while ((1u << lw) < sp->world) ++lw;
+        sp->lanes_dv.log_world = lw;
+    }
+    k_lanes_transcript<<<1, 128, 0, c->stream>>>(sp->d_lanes, st.D + 1, st.ps.d_sponge, st.ps.d_rp + st.round * (st.D + 1) * 4,
                                                 st.ps.d_ch + st.round * 4, chal_cur(st), c->fi->P, sp->lanes_dv);
     HIPCHK(hipGetLastError());
     ++st.round;

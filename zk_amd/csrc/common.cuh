@@ -114,6 +114,11 @@ struct TailDerive {
     uint32_t lead;             // D > 0: slot D of the sums holds the leading coefficient L (k_round_kd LEAD); rebuild S(D)
     uint32_t local_only;       // sharded prover: these are ONE rank's sums -- k_round_tail derives nothing (slot 1 -> 0, slot D keeps L:
                                // both are linear in the shards); k_lanes_transcript derives from the all-reduced values
+    uint64_t *claim;           // sharded prover: one element of device memory.  The claim S_prev(r_prev) depends on GLOBAL data of the round
+                               // before only, so k_round_tail (local_only, in front of the all-reduce, on a wave that has nothing to reduce)
+                               // evaluates it and parks it here; k_lanes_transcript reads it instead of running the Lagrange chain on the
+                               // serial path behind the all-reduce
+    uint32_t log_world;        // k_lanes_transcript: the all-reduced value is below 2^log_world * p (how far its reduction ladder must reach)
 };
 // S(D) of a degree-D round polynomial from S(0..D-1) and its leading coefficient L (in S[D]): D <= 3
 ZK_HD Fe lead_rebuild(uint32_t D, const Fe *S, const FieldParams &P) {

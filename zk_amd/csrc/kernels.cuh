@@ -406,10 +406,6 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
     if (sponge && wave0) sp = lane_sponge_load(sponge, L);
     // wave w owns the sums t = w, w+4, ...: lanes stride over the blocks' partials, one VALU wave reduction, one barrier
     for (uint32_t t = wave; t < ns; t += kBlock / 64) {
-        if (derive1 && t == 1 && dv.local_only) {
-            if (lane == 0) fin[1] = fe_zero();   // no t = 1 partials exist; S(1) is derived after the all-reduce
-            continue;
-        }
         if (derive1 && t == 1) {
             // this wave would own t = 1: it evaluates the previous round polynomial at the previous challenge instead,
             //   claim = sum_t prev[t] * w[t] * prod_{u != t} (r - u)   (lane t takes term t; D + 1 multiplies deep)
@@ -428,7 +424,13 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
                 }
             }
             term = fe_wave_sum(term, P, 8);
-            if (lane == 0) claim = term;
+            if (lane == 0) {
+                claim = term;
+                if (dv.local_only) {          // sharded: no t = 1 partials exist here; S(1) is derived after the all-reduce, from this claim
+                    fin[1] = fe_zero();
+                    if (dv.claim) fe_store(dv.claim, 0, term);
+                }
+            }
             continue;
         }
         Fe s = fe_zero();
@@ -811,63 +813,81 @@ __global__ void k_store_sponge(WordSponge w, WordSponge *__restrict__ dst, uint6
 // dv: the round kernels left out the t = 1 sums (prev_rp != null: S(1) = S_prev(r_prev) - S(0), the identity holds for the GLOBAL
 // sums) and / or put the leading coefficient in slot D (lead: the slot is linear in the shards, so its all-reduced value is the
 // global leading coefficient) -- the same derivations k_round_tail makes on one GPU, made here on the all-reduced values.
-__global__ void k_lanes_transcript(const uint64_t *__restrict__ lanes, uint32_t ns, WordSponge *__restrict__ sponge,
-                                   uint64_t *__restrict__ out_rp, uint64_t *__restrict__ out_ch,
-                                   uint64_t *__restrict__ d_challenge, FieldParams P, TailDerive dv) {
+__global__ __launch_bounds__(128) void k_lanes_transcript(const uint64_t *__restrict__ lanes, uint32_t ns, WordSponge *__restrict__ sponge,
+                                                          uint64_t *__restrict__ out_rp, uint64_t *__restrict__ out_ch,
+                                                          uint64_t *__restrict__ d_challenge, FieldParams P, TailDerive dv) {
     __shared__ Fe fin[256];
-    if (blockIdx.x != 0 || threadIdx.x >= 64) return;   // one wave, uniform control flow
-    const uint32_t lane = threadIdx.x;
+    __shared__ Fe claim_s;
+    if (blockIdx.x != 0 || threadIdx.x >= 128) return;   // two waves, wave-uniform control flow
+    const uint32_t lane = threadIdx.x & 63;
+    const bool wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
     const bool fixup = dv.prev_rp != nullptr || dv.lead != 0;
-    // lane t takes sum t (t, t + 64, ...): the carry propagation and the 17-step ladder run once for all sums of a batch instead
-    // of once per sum on every lane (the ladder is ~350 dependent steps: ~1 us of the serial chain of every exchanging round)
-    for (uint32_t t0 = 0; t0 < ns; t0 += 64) {
-        const uint32_t t = t0 + lane < ns ? t0 + lane : ns - 1;
-        uint32_t v[9];
-        uint64_t carry = 0;
+    // wave 0 fetches the sponge first, so that load is in flight while the lanes are reduced (as k_round_tail does)
+    const LaneKeccak L = lane_keccak_init();
+    LaneSponge sp = {0, 0};
+    if (wave0) {
+        sp = lane_sponge_load(sponge, L);
+        Fe claim_early = fe_zero();
+        if (dv.prev_rp && dv.claim) claim_early = fe_load(dv.claim, 0);   // evaluated by k_round_tail in front of the all-reduce; in flight with the lanes
+        // lane t takes sum t (t, t + 64, ...): the carry propagation and the 17-step ladder run once for all sums of a batch instead
+        // of once per sum on every lane (the ladder is ~350 dependent steps: ~1 us of the serial chain of every exchanging round)
+        for (uint32_t t0 = 0; t0 < ns; t0 += 64) {
+            const uint32_t t = t0 + lane < ns ? t0 + lane : ns - 1;
+            uint32_t v[9];
+            uint64_t carry = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            carry += lanes[8 * t + i];
-            v[i] = (uint32_t)carry;
-            carry >>= 32;
-        }
-        v[8] = (uint32_t)carry;
-        ladder9<16>(v, P);
-        Fe r;
+            for (int i = 0; i < 8; ++i) {
+                carry += lanes[8 * t + i];
+                v[i] = (uint32_t)carry;
+                carry >>= 32;
+            }
+            v[8] = (uint32_t)carry;
+            if (dv.log_world <= 3) ladder9<4>(v, P);   // value < 2^log_world * p: up to eight ranks 16p .. p suffices (wave-uniform branch)
+            else ladder9<16>(v, P);
+            Fe r;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r.v[i] = v[i];
-        if (t0 + lane < ns) {
-            fin[t] = r;
-            if (!fixup) fe_store(out_rp, t, r);
+            for (int i = 0; i < 8; ++i) r.v[i] = v[i];
+            if (t0 + lane < ns) {
+                fin[t] = r;
+                if (!fixup) fe_store(out_rp, t, r);
+            }
         }
+        if (dv.prev_rp && dv.claim && lane == 0) claim_s = claim_early;
+    } else if (dv.prev_rp && !dv.claim) {
+        // wave 1, beside the ladder (nothing here depends on the lanes): claim = S_prev(r_prev) = sum_t prev[t] * w[t] * prod_{u != t} (r_prev - u),
+        // lane t takes term t (fast degrees only: ns <= 5)
+        const Fe r = fe_load(dv.prev_chal, 0);
+        Fe term = fe_zero();
+        if (lane < ns) {
+            Fe one;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
+            term = fe_mul(fe_load(dv.prev_rp, lane), fe_load(dv.w, lane), P);
+            Fe node = fe_zero();   // Montgomery form of u
+            for (uint32_t u = 0; u < ns; ++u) {
+                if (u != lane) term = fe_mul(term, fe_sub(r, node, P), P);
+                node = fe_add(node, one, P);
+            }
+        }
+        const Fe claim = fe_wave_sum(term, P, 8);   // valid in lane 0
+        if (lane == 0) claim_s = claim;
     }
     __syncthreads();
-    if (fixup) {   // (fast degrees only: ns <= 5)
-        if (dv.prev_rp) {
-            // claim = S_prev(r_prev) = sum_t prev[t] * w[t] * prod_{u != t} (r_prev - u): lane t takes term t
-            const Fe r = fe_load(dv.prev_chal, 0);
-            Fe term = fe_zero();
-            if (lane < ns) {
-                Fe one;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
-                term = fe_mul(fe_load(dv.prev_rp, lane), fe_load(dv.w, lane), P);
-                Fe node = fe_zero();   // Montgomery form of u
-                for (uint32_t u = 0; u < ns; ++u) {
-                    if (u != lane) term = fe_mul(term, fe_sub(r, node, P), P);
-                    node = fe_add(node, one, P);
-                }
-            }
-            const Fe claim = fe_wave_sum(term, P, 8);   // valid in lane 0
-            if (lane == 0) fin[1] = fe_sub(claim, fin[0], P);
-            __syncthreads();
+    if (!wave0) return;
+    if (fixup) {
+        if (lane == 0) {
+            if (dv.prev_rp) fin[1] = fe_sub(claim_s, fin[0], P);             // S(1) = S_prev(r_prev) - S(0), on the GLOBAL sums
+            if (dv.lead) fin[dv.lead] = lead_rebuild(dv.lead, fin, P);        // slot D held the (global) leading coefficient
         }
-        if (dv.lead) {
-            if (lane == 0) fin[dv.lead] = lead_rebuild(dv.lead, fin, P);
-            __syncthreads();
-        }
+        __builtin_amdgcn_wave_barrier();   // same wave: LDS operations execute in order
         if (lane < ns) fe_store(out_rp, lane, fin[lane]);
     }
-    transcript_round(sponge, fin, ns, d_challenge, out_ch, P);
+    lane_absorb_elems(sp, L, fin, ns, P);
+    Mul29 ch29;
+    Fe ch;
+    challenge_forms(lane_squeeze_x(sp, L), (uint32_t)L.lane, P, ch29, ch);
+    publish_challenge_forms(d_challenge, out_ch, ch, ch29, (uint32_t)L.lane);
+    lane_sponge_store(sponge, sp, L);
 }
 
 // interleave the all-gathered shard tables [rank][factor][2^s] into k tables of world * 2^s elements:
