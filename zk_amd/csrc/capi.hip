@@ -342,7 +342,7 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIPCHK(hipMalloc(&c->d_partials, (size_t)kMaxGrid * kMaxSums * 32));
-    HIPCHK(hipMalloc(&c->d_sums, (size_t)kMaxSums * 32 * 3));
+    HIPCHK(hipMalloc(&c->d_sums, (size_t)kMaxSums * 32 * 3 + 32));   // (+ one element: the claim of a SKIP1 round, ClaimJob)
     // completion word + result staging are POLLED by the host while the kernel that writes them is still running: ask for
     // coherent (fine-grained) mapped memory explicitly instead of relying on HIP_HOST_COHERENT's default
     HIPCHK(hipHostMalloc(&c->h_pinned, (size_t)kMaxSums * 32 * 3, kPolledHostFlags));
@@ -1168,8 +1168,14 @@ static int32_t results_staging(zk_ctx *c, size_t bytes, uint8_t **out) {
 }
 
 static inline RoundLaunchCtx launch_ctx(zk_ctx *c) {
-    RoundLaunchCtx lc = {c->stream, &c->fi->P, c->d_partials, (uint64_t)kMaxGrid * kMaxSums};
+    RoundLaunchCtx lc = {c->stream, &c->fi->P, c->d_partials, (uint64_t)kMaxGrid * kMaxSums, {}};
     return lc;
+}
+static inline uint64_t *claim_slot(zk_ctx *c) { return c->d_sums + (size_t)kMaxSums * 4 * 3; }
+// ZK_CLAIM_IN_ROUND=0: the tails evaluate the SKIP1 claim themselves (round 4's behaviour; A/B)
+static bool claim_in_round() {
+    static const bool v = env_u64("ZK_CLAIM_IN_ROUND", 1, 0, 1) != 0;
+    return v;
 }
 static inline bool fast_degree(uint32_t D) { return D >= 1 && D <= 4; }
 
@@ -1203,6 +1209,7 @@ struct DeferredTail {
     uint32_t blocks;
     bool skip1;
     bool lead;    // slot D of the partials holds the leading coefficient (k_round_kd LEAD)
+    const uint64_t *claim;   // skip1: where the round kernel's claim workgroup left S_prev(r_prev) (null: the tail evaluates it)
 };
 // Rounds with at least this many pairs accumulate the leading coefficient instead of S(D) (k_round_kd LEAD): one modular
 // addition per factor and pair index fewer against three to six more in the tail.  ZK_LEAD_MIN_PAIRS overrides (tests).
@@ -1227,11 +1234,18 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
         const bool may_derive = !tt.lanes || (tt.lanes_dv && shard_skip_on());
         bool skip1 = dv && dv->prev_rp && fused && may_derive && D <= (uint32_t)kMaxSkipDegree && q >= skip1_min_pairs();
         bool lead = may_derive && q >= lead_min_pairs();   // (the launchers clear it for shapes without the variant)
+        // a SKIP1 kernel, if one is launched below, evaluates the claim its tail needs beside its work blocks (ClaimJob)
+        ClaimJob cjob = {};
+        if (skip1 && claim_in_round()) cjob = ClaimJob{dv->prev_rp, dv->prev_chal, dv->w, claim_slot(c), D + 1};
+        auto with_claim = [&](RoundLaunchCtx lc) {
+            lc.claim = cjob;
+            return lc;
+        };
         auto tail_dv = [&]() {
             TailDerive t = skip1 && dv ? *dv : TailDerive{};
             t.lead = lead ? D : 0;
+            t.claim = (t.prev_rp && cjob.out) ? cjob.out : nullptr;
             if (tt.lanes) {
-                if (t.prev_rp) t.claim = tt.lanes + (size_t)kMaxSums * 8;   // one element behind the lanes (zk_shard_prover_create allocates it)
                 if (tt.lanes_dv) *tt.lanes_dv = t;
                 t.local_only = 1;
             }
@@ -1240,7 +1254,7 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
         if (tt.lanes_dv) *tt.lanes_dv = TailDerive{};
         if (ts.n_terms == 2 && ts.term_k[1] == 1) {   // product + one single-factor term (a GKR layer): one pass
             uint32_t g = 0;
-            const int lrc = launch_round_plus1(launch_ctx(c), fp, ts.term_k[0], q, D, fused, d_r, &g, &skip1, &lead);
+            const int lrc = launch_round_plus1(with_claim(launch_ctx(c)), fp, ts.term_k[0], q, D, fused, d_r, &g, &skip1, &lead);
             if (lrc == kLaunchHipError) {
                 g_hip_err = "round kernel launch failed";
                 return ZK_ERR_HIP;
@@ -1249,6 +1263,7 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
                 if (defer) {
                     defer->blocks = g;
                     defer->skip1 = skip1;
+                    defer->claim = skip1 ? cjob.out : nullptr;
                     defer->lead = lead;
                     return ZK_OK;
                 }
@@ -1265,7 +1280,7 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
                 sub.in[f] = fp.in[first + f];
                 sub.out[f] = fp.out[first + f];
             }
-            RoundLaunchCtx lc = launch_ctx(c);
+            RoundLaunchCtx lc = with_claim(launch_ctx(c));
             lc.d_partials += (size_t)total * (D + 1) * 4;
             lc.capacity_elems -= (uint64_t)total * (D + 1);
             uint32_t g = 0;
@@ -1281,6 +1296,7 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
         if (defer) {
             defer->blocks = total;
             defer->skip1 = skip1;
+            defer->claim = skip1 ? cjob.out : nullptr;
             defer->lead = lead;
             return ZK_OK;
         }
@@ -1726,6 +1742,7 @@ static int32_t pipe_enter(RoundState &st, const DeferredTail &dt) {
         pl.tail.dv = st.dv;
         pl.tail.dv.prev_rp = pl.tail.out_rp - (size_t)(st.D + 1) * 4;
         pl.tail.dv.prev_chal = chal_prev(st);
+        pl.tail.dv.claim = dt.claim;
     }
     pl.tail.dv.lead = dt.lead ? st.D : 0;
     FactorPtrs fp = {};
@@ -1868,7 +1885,7 @@ static int32_t prover_step(RoundState &st, bool *finished_in_kernel) {
     // the table of this round has m_s variables; if the NEXT round belongs to the pipeline, this round's tail is merged
     // into the launch that prepares it
     const uint64_t m_s = st.pending_fold ? st.vars_left - 1 : st.vars_left;
-    DeferredTail dt = {0, false, false};
+    DeferredTail dt = {0, false, false, nullptr};
     const bool enter = fast_degree(st.D) && pipe_wants_next(st, m_s);
     ZKCHK(round_enqueue(st, nullptr, enter ? &dt : nullptr));
     // dt.blocks == 0: round_enqueue's contract for "the tail was launched after all" (a sums path that cannot defer it) --
@@ -2075,7 +2092,7 @@ extern "C" int32_t zk_shard_prover_create(zk_ctx *c, zk_mle *const *f, uint64_t 
     sp->gathered_bytes = 0;
     // the shard tables are consumed (folded in place) unless one is listed twice (see prove_core)
     int32_t rc = round_state_init(sp->st, c, f, k, D, /*consume=*/!has_duplicate_handles(f, k), sp->total_rounds);
-    if (rc == ZK_OK) rc = pool_alloc(c, ((size_t)kMaxSums * 8 + 4) * sizeof(uint64_t), (void **)&sp->d_lanes);
+    if (rc == ZK_OK) rc = pool_alloc(c, (size_t)kMaxSums * 8 * sizeof(uint64_t), (void **)&sp->d_lanes);
     if (rc == ZK_OK) {
         Sponge host;
         host.init();
@@ -2094,7 +2111,7 @@ extern "C" int32_t zk_shard_prover_destroy(zk_shard_prover *sp) {
     zk_ctx *c = sp->st.c;
     (void)hipSetDevice(c->device);
     round_state_release(sp->st);
-    pool_free(c, sp->d_lanes, ((size_t)kMaxSums * 8 + 4) * sizeof(uint64_t));
+    pool_free(c, sp->d_lanes, (size_t)kMaxSums * 8 * sizeof(uint64_t));
     pool_free(c, sp->d_tail, sp->tail_bytes);
     pool_free(c, sp->d_gathered, sp->gathered_bytes);
     delete sp;

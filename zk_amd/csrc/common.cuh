@@ -114,11 +114,19 @@ struct TailDerive {
     uint32_t lead;             // D > 0: slot D of the sums holds the leading coefficient L (k_round_kd LEAD); rebuild S(D)
     uint32_t local_only;       // sharded prover: these are ONE rank's sums -- k_round_tail derives nothing (slot 1 -> 0, slot D keeps L:
                                // both are linear in the shards); k_lanes_transcript derives from the all-reduced values
-    uint64_t *claim;           // sharded prover: one element of device memory.  The claim S_prev(r_prev) depends on GLOBAL data of the round
-                               // before only, so k_round_tail (local_only, in front of the all-reduce, on a wave that has nothing to reduce)
-                               // evaluates it and parks it here; k_lanes_transcript reads it instead of running the Lagrange chain on the
-                               // serial path behind the all-reduce
+    const uint64_t *claim;     // one element of device memory: S_prev(r_prev), evaluated by the round kernel's claim workgroup (ClaimJob) --
+                               // the tails read it instead of running the Lagrange chain themselves (null: they evaluate it)
     uint32_t log_world;        // k_lanes_transcript: the all-reduced value is below 2^log_world * p (how far its reduction ladder must reach)
+};
+// The claim S_prev(r_prev) a SKIP1 round needs (S(1) = claim - S(0)) depends on the round BEFORE only, so the round kernel itself
+// evaluates it -- one extra workgroup, first wave, beside the work blocks -- and parks it in device memory (`out`); the tail that
+// closes the round reads one element instead of running a chain of D + 1 dependent multiplications on the prover's serial path.
+struct ClaimJob {
+    const uint64_t *prev_rp;   // previous round polynomial (ns elements); null: no job
+    const uint64_t *prev_chal; // challenge record of the previous round
+    const uint64_t *w;         // Lagrange weights on 0..ns-1
+    uint64_t *out;             // one element
+    uint32_t ns;
 };
 // S(D) of a degree-D round polynomial from S(0..D-1) and its leading coefficient L (in S[D]): D <= 3
 ZK_HD Fe lead_rebuild(uint32_t D, const Fe *S, const FieldParams &P) {
@@ -171,6 +179,24 @@ ZK_D Fe fe_wave_sum(Fe s, const FieldParams &P, uint32_t width = 64) {
     if (width > 2) s = fe_add(s, fe_dpp<0x12E>(s), P);
     if (width > 1) s = fe_add(s, fe_dpp<0x12F>(s), P);
     return s;
+}
+// one wave: claim = sum_t prev[t] * w[t] * prod_{u != t} (r - u); lane t takes term t (ns <= 8); valid in lane 0
+ZK_D Fe claim_eval(const ClaimJob &cj, const FieldParams &P) {
+    const uint32_t lane = threadIdx.x & 63;
+    const Fe r = fe_load(cj.prev_chal, 0);
+    Fe term = fe_zero();
+    if (lane < cj.ns) {
+        Fe one;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) one.v[i] = P.r1[i];
+        term = fe_mul(fe_load(cj.prev_rp, lane), fe_load(cj.w, lane), P);
+        Fe node = fe_zero();   // Montgomery form of u
+        for (uint32_t u = 0; u < cj.ns; ++u) {
+            if (u != lane) term = fe_mul(term, fe_sub(r, node, P), P);
+            node = fe_add(node, one, P);
+        }
+    }
+    return fe_wave_sum(term, P, 8);
 }
 
 // ---- the variables a bulk launch leaves over, applied as a weight on its outputs (round 4) ------------------------------------

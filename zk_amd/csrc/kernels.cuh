@@ -406,6 +406,14 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
     if (sponge && wave0) sp = lane_sponge_load(sponge, L);
     // wave w owns the sums t = w, w+4, ...: lanes stride over the blocks' partials, one VALU wave reduction, one barrier
     for (uint32_t t = wave; t < ns; t += kBlock / 64) {
+        if (derive1 && t == 1 && dv.claim) {
+            // this wave would own t = 1: the round kernel's claim workgroup has evaluated S_prev(r_prev) already
+            if (lane == 0) {
+                claim = fe_load(dv.claim, 0);
+                if (dv.local_only) fin[1] = fe_zero();   // sharded: S(1) is derived after the all-reduce (k_lanes_transcript reads the same claim)
+            }
+            continue;
+        }
         if (derive1 && t == 1) {
             // this wave would own t = 1: it evaluates the previous round polynomial at the previous challenge instead,
             //   claim = sum_t prev[t] * w[t] * prod_{u != t} (r - u)   (lane t takes term t; D + 1 multiplies deep)
@@ -426,10 +434,7 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
             term = fe_wave_sum(term, P, 8);
             if (lane == 0) {
                 claim = term;
-                if (dv.local_only) {          // sharded: no t = 1 partials exist here; S(1) is derived after the all-reduce, from this claim
-                    fin[1] = fe_zero();
-                    if (dv.claim) fe_store(dv.claim, 0, term);
-                }
+                if (dv.local_only) fin[1] = fe_zero();   // sharded: no t = 1 partials exist here; S(1) is derived after the all-reduce
             }
             continue;
         }

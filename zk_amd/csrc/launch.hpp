@@ -12,6 +12,7 @@ struct RoundLaunchCtx {
     const FieldParams *P;
     uint64_t *d_partials;          // block sums: capacity_elems field elements
     uint64_t capacity_elems;
+    ClaimJob claim;                // out != null: a SKIP1 kernel, if one is launched, also evaluates the tail's claim (one extra workgroup)
 };
 enum { kLaunchOk = 0, kLaunchUnsupported = -1, kLaunchHipError = -2 };
 // One round: (fold at *d_r when fused +) sums for t = 0..D over q pairs -> per-block partials; *out_grid blocks.

@@ -380,8 +380,13 @@ ZK_D void pipe_tail_block(const PipeTailArgs &ta, const FieldParams &P) {
             s = pipe_eval_canon<K, D>(red, W, rh29, rc29, lane, P);   // CANONICAL
         } else {
             s = red[lane < (uint32_t)NS ? lane : 0];
-            if (ta.dv.prev_rp) {
-                // S(1) = S_prev(r_prev) - S(0): the round kernel left the t = 1 products out (k_round_kd SKIP1)
+            if (ta.dv.prev_rp && ta.dv.claim) {
+                // S(1) = S_prev(r_prev) - S(0): the round kernel left the t = 1 products out (k_round_kd SKIP1) and its claim workgroup
+                // has evaluated S_prev(r_prev)
+                const Fe c0 = fe_load(ta.dv.claim, 0);
+                const Fe s0 = red[0];
+                if (lane == 1) s = fe_sub(c0, s0, P);
+            } else if (ta.dv.prev_rp) {
                 const Fe r = fe_load(ta.dv.prev_chal, 0);
                 Fe term = fe_zero();
                 if (lane < (uint32_t)NS) {

@@ -198,8 +198,23 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, u
 #endif
 template <int K, int D, bool FUSED, int EXTRA = 0, bool SKIP1 = false, bool LEAD = false>
 __global__ __launch_bounds__(kBlock, ZK_KD_MIN_BLOCKS(K, EXTRA, FUSED, SKIP1)) void k_round_kd(FactorPtrs fp, uint64_t q, FieldParams P,
-                                                        const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials) {
+                                                        const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials, ClaimJob cj = {}) {
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
+    // SKIP1 with a claim job: the LAST workgroup of the grid is not a work block -- its first wave evaluates S_prev(r_prev) for the
+    // tail (common.cuh ClaimJob) while the others stream the table
+    uint32_t nblk = gridDim.x;
+    if constexpr (SKIP1) {
+        if (cj.out) {
+            nblk -= 1;
+            if (blockIdx.x == nblk) {
+                if (threadIdx.x < 64) {
+                    const Fe claim = claim_eval(cj, P);
+                    if (threadIdx.x == 0) fe_store(cj.out, 0, claim);
+                }
+                return;
+            }
+        }
+    }
     Mul29 r = {};
     if (FUSED) r = load_challenge29(rptr);
     RoundRegs<K, D, FUSED, EXTRA> R;
@@ -209,7 +224,7 @@ __global__ __launch_bounds__(kBlock, ZK_KD_MIN_BLOCKS(K, EXTRA, FUSED, SKIP1)) v
         if (EXTRA) R.sum_b[t] = fe_zero();
         if (K > 1) wide_zero(R.acc[t]);
     }
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t stride = (uint64_t)nblk * kBlock;
     uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j < q) {
 #pragma unroll

@@ -60,6 +60,9 @@ static inline uint32_t capped_grid(uint64_t q) {
     return (uint32_t)(b ? b : 1);
 }
 
+// a SKIP1 kernel launched with a claim job carries one workgroup more than its work grid (round_kernels.cuh)
+static inline uint32_t claim_blocks(const RoundLaunchCtx &lc) { return lc.claim.out ? 1u : 0u; }
+
 template <int K, int D>
 static void launch_kd(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, bool fused, const uint64_t *d_r, uint32_t g) {
     if (fused) k_round_kd<K, D, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
@@ -88,8 +91,8 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
             else k_round_kd<3, 3, false, 0, false, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
             if (skip1) *skip1 = false;
         } else if (skip1 && *skip1) {
-            if (shl == 22) k_round_kd<2, 2, true, 0, true, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
-            else k_round_kd<3, 3, true, 0, true, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+            if (shl == 22) k_round_kd<2, 2, true, 0, true, true><<<g + claim_blocks(lc), kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.claim);
+            else k_round_kd<3, 3, true, 0, true, true><<<g + claim_blocks(lc), kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.claim);
         } else {
             done = false;
         }
@@ -116,8 +119,8 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
     if (skip1 && *skip1) {   // the variants without the t = 1 products exist for the GKR-style shapes, fused only
         const bool fits1 = (uint64_t)g * (D + 1) <= lc.capacity_elems;
         const int shape1 = (fits1 && fused) ? k * 10 + (int)D : 0;
-        if (shape1 == 22) k_round_kd<2, 2, true, 0, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
-        else if (shape1 == 33) k_round_kd<3, 3, true, 0, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        if (shape1 == 22) k_round_kd<2, 2, true, 0, true><<<g + claim_blocks(lc), kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.claim);
+        else if (shape1 == 33) k_round_kd<3, 3, true, 0, true><<<g + claim_blocks(lc), kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.claim);
         else *skip1 = false;
         if (*skip1) {
             if (hipGetLastError() != hipSuccess) return kLaunchHipError;
@@ -166,7 +169,7 @@ int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, ui
             else k_round_kd<2, 2, false, 1, false, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
             if (skip1) *skip1 = false;
         } else {
-            k_round_kd<2, 2, true, 1, true, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+            k_round_kd<2, 2, true, 1, true, true><<<g + claim_blocks(lc), kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.claim);
         }
         if (hipGetLastError() != hipSuccess) return kLaunchHipError;
         *out_grid = g;
@@ -182,7 +185,7 @@ int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, ui
     }
     if (skip1 && *skip1 && !(shape == 22 && fused)) *skip1 = false;
     if (shape == 22) {
-        if (fused && skip1 && *skip1) k_round_kd<2, 2, true, 1, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        if (fused && skip1 && *skip1) k_round_kd<2, 2, true, 1, true><<<g + claim_blocks(lc), kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.claim);
         else if (fused) k_round_kd<2, 2, true, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
         else k_round_kd<2, 2, false, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
     } else if (shape == 33) {
