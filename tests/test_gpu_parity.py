@@ -746,7 +746,7 @@ def test_skip1_rounds_bit_exact():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = {k: v for k, v in os.environ.items()
-            if k not in ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES", "ZK_LEAD_MIN_PAIRS", "ZK_ROUND0_DOT29", "ZK_PIPE_MID_MAX_PAIRS", "ZK_CHECK_FIELDS")}
+            if k not in ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES", "ZK_LEAD_MIN_PAIRS", "ZK_ROUND0_DOT29", "ZK_PIPE_MID_MAX_PAIRS", "ZK_CHECK_FIELDS", "ZK_CLAIM_IN_ROUND")}
     runs = [
         # SKIP1 kernels everywhere (no quad kernel, no pipeline: they would take the small rounds)
         dict(ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0"),
@@ -774,6 +774,9 @@ def test_skip1_rounds_bit_exact():
         # (one field: n = 19 is the size whose first pipelined round needs two passes per quad, and its oracle proofs take seconds)
         dict(ZK_PIPE_MAX_PAIRS="1", ZK_PIPE_MID_MAX_PAIRS="131072", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0",
              ZK_CHECK_SIZES="11,13,15,17,19", ZK_CHECK_FIELDS="1"),
+        # SKIP1 + LEAD everywhere with the claim evaluated by the TAILS (round 4's form; shipped: the round kernel's claim workgroup), with
+        # and without the pipeline behind them (k_round_tail / the deferred tail of the first pipelined launch)
+        dict(ZK_CLAIM_IN_ROUND="0", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="3,7,11,13", ZK_CHECK_FIELDS="2"),
         # ... and switched off (round 4's schedule: hex rows up to 2^12 pairs, classic rounds above)
         dict(ZK_PIPE_MID_MAX_PAIRS="0", ZK_CHECK_SIZES="14,16,18"),
     ]

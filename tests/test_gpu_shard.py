@@ -65,7 +65,7 @@ def test_shard_rounds_derive_behind_the_allreduce():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    drop = ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_LEAD_MIN_PAIRS", "ZK_SHARD_SKIP1", "ZK_CHECK_CASES", "ZK_CHECK_FIELDS")
+    drop = ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_LEAD_MIN_PAIRS", "ZK_SHARD_SKIP1", "ZK_CHECK_CASES", "ZK_CHECK_FIELDS", "ZK_CLAIM_IN_ROUND")
     base = {k: v for k, v in os.environ.items() if k not in drop}
     runs = [
         # SKIP1 + LEAD in every fused round of every shape that has them (no quad kernel: it would take the small rounds)
@@ -77,6 +77,8 @@ def test_shard_rounds_derive_behind_the_allreduce():
         dict(ZK_CHECK_CASES="2:2:2:19,4:3:3:19", ZK_CHECK_FIELDS="1"),
         # round 4's behaviour: every sum formed by the round kernels
         dict(ZK_SHARD_SKIP1="0", ZK_SKIP1_MIN_PAIRS="1", ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_FIELDS="1"),
+        # the claim S_prev(r_prev) evaluated by k_lanes_transcript itself (no claim workgroup in the round kernels)
+        dict(ZK_CLAIM_IN_ROUND="0", ZK_SKIP1_MIN_PAIRS="1", ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_FIELDS="1"),
     ]
     for extra in runs:
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "shard_skip_check.py")], env=dict(base, **extra), capture_output=True,
