@@ -1470,6 +1470,8 @@ struct RoundState {
     // round - 1, before its challenge was known); `cur` still awaits that fold (pending_fold is true)
     bool pipe_active;
     uint32_t pipe_blocks;             // work blocks that wrote them
+    FinishPublish pub;                // flag != null: the pipelined finisher, being the call's last launch, publishes the proof block itself
+    bool published;                   // ... and has been enqueued with that job
 };
 // challenge records alternate between two slots: round s publishes into slot s & 1
 static inline uint64_t *chal_of_round(const RoundState &st, uint64_t round) { return st.ps.d_challenge + (round & 1) * kChalWords; }
@@ -1503,6 +1505,8 @@ static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uin
     st.dv = {};
     st.pipe_active = false;
     st.pipe_blocks = 0;
+    st.pub = {};
+    st.published = false;
     for (uint64_t i = 0; i < (uint64_t)kMaxFactors; ++i) {
         st.cur[i] = i < k ? f[i]->d : nullptr;
         st.scratch[i] = nullptr;
@@ -1692,6 +1696,7 @@ static int32_t finish_pipe_enqueue(RoundState &st) {
     fl.out_ch = st.ps.d_ch + st.round * 4;
     fl.out_final = st.d_final;
     fl.dbg = pipe_dbg_slot(c, true);
+    fl.pub = st.pub;
     FactorPtrs fp = {};
     for (uint64_t i = 0; i < st.k; ++i) fp.in[i] = st.cur[i];
     const int lrc = launch_finish_pipe(launch_ctx(c), fp, fl);
@@ -1703,6 +1708,7 @@ static int32_t finish_pipe_enqueue(RoundState &st) {
     st.vars_left = 0;
     st.pending_fold = false;
     st.pipe_active = false;
+    st.published = st.pub.flag != nullptr;
     return ZK_OK;
 }
 static PipeTailArgs pipe_tail_args(const RoundState &st, int mode, const uint64_t *partials, uint32_t nblocks, uint32_t n_in) {
@@ -1967,6 +1973,18 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
     int32_t rc = ZK_OK;
     if (out_final) st.d_final = st.ps.d_final;
     if (rc == ZK_OK) rc = sponge_to_device(c, sp, st.ps.d_sponge, st.ps.d_epart);
+    // one copy of [round polys | challenges | finals] into pinned memory behind a completion word: by the pipelined finisher itself
+    // when it is the call's last launch (ZK_PUBLISH_IN_FINISHER=0: always by k_publish_host), else by k_publish_host below
+    uint8_t *stage = nullptr;
+    const size_t block = st.ps.rp_bytes + st.ps.ch_bytes + kMaxFactors * 32;
+    if (rc == ZK_OK) rc = results_staging(c, block, &stage);
+    uint32_t seq = 0;
+    static const bool publish_in_finisher = env_u64("ZK_PUBLISH_IN_FINISHER", 1, 0, 1) != 0;
+    if (rc == ZK_OK) {
+        seq = next_flag_seq(c);
+        if (publish_in_finisher && !d_keep_ch && !d_keep_final)
+            st.pub = FinishPublish{st.ps.d_rp, reinterpret_cast<uint64_t *>(stage), (uint32_t)(block / 8), c->h_flag, seq};
+    }
     bool finished_in_kernel = false;
     while (st.round < n && rc == ZK_OK) rc = prover_step(st, &finished_in_kernel);   // prover.rs:44-68, all on device
     // prover.rs:64 after the LAST round folds to a 0-variable polynomial the reference drops: computed only on request.
@@ -1983,13 +2001,7 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
     if (rc == ZK_OK && d_keep_final && out_final &&
         hipMemcpyAsync(d_keep_final, st.ps.d_final, (size_t)k * 32, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
         rc = ZK_ERR_HIP;
-    // one copy of [round polys | challenges | finals] into pinned memory, one synchronisation
-    uint8_t *stage = nullptr;
-    const size_t block = st.ps.rp_bytes + st.ps.ch_bytes + kMaxFactors * 32;
-    if (rc == ZK_OK) rc = results_staging(c, block, &stage);
-    uint32_t seq = 0;
-    if (rc == ZK_OK) {   // the proof block goes to pinned memory by a kernel that also stores the completion word
-        seq = next_flag_seq(c);
+    if (rc == ZK_OK && !st.published) {   // the proof block goes to pinned memory by a kernel that also stores the completion word
         k_publish_host<<<1, 64, 0, c->stream>>>(st.ps.d_rp, reinterpret_cast<uint64_t *>(stage), (uint32_t)(block / 8), c->h_flag, seq);
         if (hipGetLastError() != hipSuccess) rc = ZK_ERR_HIP;
     }

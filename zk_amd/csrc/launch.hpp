@@ -69,6 +69,7 @@ struct FinishPipeLaunch {
     WordSponge *sponge;
     uint64_t *out_rp, *out_ch, *out_final;
     uint64_t *dbg;            // optional timestamps (ZK_PIPE_DEBUG)
+    FinishPublish pub;        // flag != null: this launch ends the call -- publish the proof block and the completion word
 };
 int launch_finish_pipe(const RoundLaunchCtx &lc, const FactorPtrs &fp, const FinishPipeLaunch &fl);
 uint32_t finish_pipe_max_vars(int n_factors);   // largest after-fold table (variables) the pipelined finisher keeps in LDS

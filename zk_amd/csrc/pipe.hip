@@ -113,7 +113,7 @@ static hipError_t launch_fin_shape(const RoundLaunchCtx &lc, const FactorPtrs &f
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_finish_pipe<K, D, EXTRA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     k_finish_pipe<K, D, EXTRA><<<1, kFinishPipeThreads, lds, lc.stream>>>(fp, fl.m_in, fl.entry, fl.e_partials, fl.e_blocks, *lc.P, fl.pc, fl.chal_in,
-                                                                         fl.chal_last, fl.sponge, fl.out_rp, fl.out_ch, fl.out_final, fl.dbg);
+                                                                         fl.chal_last, fl.sponge, fl.out_rp, fl.out_ch, fl.out_final, fl.dbg, fl.pub);
     return hipGetLastError();
 }
 int launch_finish_pipe(const RoundLaunchCtx &lc, const FactorPtrs &fp, const FinishPipeLaunch &fl) {

@@ -11,6 +11,16 @@ struct PipeConsts {
     Mul29 k266;    // limbs of 2^266 mod p: fe_mul29(x, k266) = x * 2^5 mod p, whose 29-bit split is the prepared CANONICAL challenge
 };
 
+// The finisher as the LAST launch of a call: wave 0 copies the finished proof block into pinned host memory and stores the completion
+// word behind a system-scope fence (what k_publish_host does as a launch of its own, ~4 us + a launch boundary).  flag == null: no.
+struct FinishPublish {
+    const uint64_t *src;        // device: [round polys | challenges | factor values], n_u64 words (even)
+    uint64_t *dst_host;         // pinned, mapped
+    uint32_t n_u64;
+    volatile uint32_t *flag;    // pinned, coherent
+    uint32_t seq;
+};
+
 struct PipeTailArgs {
     const uint64_t *partials;   // per-block partials of the round being closed: [block][n_in] elements
     uint32_t nblocks;

@@ -816,7 +816,7 @@ template <int K, int D, int EXTRA>
 __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs fp, uint32_t m_in, int entry, const uint64_t *__restrict__ e_partials,
                                                                     uint32_t e_blocks, FieldParams P, PipeConsts pc, const uint64_t *__restrict__ chal_in,
                                                                     uint64_t *__restrict__ chal_last, WordSponge *gsponge, uint64_t *out_rp,
-                                                                    uint64_t *out_ch, uint64_t *out_final, uint64_t *dbg) {
+                                                                    uint64_t *out_ch, uint64_t *out_final, uint64_t *dbg, FinishPublish pub) {
     constexpr int NF = K + EXTRA, NS = D + 1, NR = K + 1, NE = NS * NR;
     extern __shared__ __attribute__((aligned(32))) unsigned char fp_smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1049,6 +1049,15 @@ __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs f
         const Fe x0 = fe_load(T, 0), x1 = fe_load(T, 1), x2 = fe_load(T, 2), x3 = fe_load(T, 3);
         const Fe lo = fe_sub(x0, fe_mul29(fe_sub(x0, x2, P), r2, P), P), hi = fe_sub(x1, fe_mul29(fe_sub(x1, x3, P), r2, P), P);
         fe_store(out_final, tid, fe_sub(lo, fe_mul29(fe_sub(lo, hi, P), rprev, P), P));
+    }
+    if (pub.flag) {   // this launch ends the call: the proof block goes to pinned host memory from here (pipe_args.hpp FinishPublish)
+        __syncthreads();   // the round polynomials / challenges / factor values stored above by the other waves
+        if (wave0) {
+            for (uint32_t i = 2 * lane; i < pub.n_u64; i += 2 * 64)
+                *reinterpret_cast<uint4 *>(pub.dst_host + i) = *reinterpret_cast<const uint4 *>(pub.src + i);
+            __threadfence_system();
+            if (lane == 0) *pub.flag = pub.seq;
+        }
     }
 }
 
