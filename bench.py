@@ -474,9 +474,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--event-group", type=int, default=8,
+    ap.add_argument("--event-group", type=int, default=0,
                     help="launches per HIP-event bracket in the timed region (an event record stalls the stream ~4 us: 3 %% of a 2^24 "
-                         "fold, 25 %% of a 2^21 shard's); 1 = one event per launch boundary")
+                         "fold, 25 %% of a 2^21 shard's); 1 = one event per launch boundary; default: 8, one bracket for <= 32 steps")
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -569,7 +569,10 @@ def main():
     t0 = time.perf_counter()
     # the K timed steps, bracketed by HIP events on the launch stream every `event_group` launches (zk_bench_fold_samples):
     # a sample is the average launch duration inside its bracket
-    group = max(1, min(args.event_group, args.steps))
+    # (default: 8 launches per bracket; ONE bracket when there are at most 32 steps -- every event record stalls the stream ~4 us, which
+    # is 0.5-1 us per launch of a short run's average and no part of the kernel)
+    eg = args.event_group if args.event_group > 0 else (args.steps if args.steps <= 32 else 8)
+    group = max(1, min(eg, args.steps))
     samples = table.bench_fold_samples(r, out, args.steps, group)
     ctx.synchronize()
     torch.cuda.synchronize()
