@@ -373,6 +373,7 @@ int32_t zk_bench_copy(zk_ctx *ctx, uint64_t bytes, int32_t reps, double *out_gbp
    ZK_PIPE_MID_MAX_PAIRS   0         0 .. 2^40    rounds above ZK_PIPE_MAX_PAIRS up to this size take the pipelined schedule on k_round_mid (off: slower)
    ZK_PUBLISH_IN_FINISHER  1         0 .. 1       0: the proof block always goes to pinned host memory by a launch of its own (k_publish_host)
    ZK_CLAIM_IN_ROUND       1         0 .. 1       0: the tails evaluate the SKIP1 claim S_prev(r_prev) themselves instead of reading it from the round kernel's claim workgroup
+   ZK_PIPE_MID_TOTAL       0         0 .. 1       1: k_round_mid's last workgroup adds the block partials up; 0: the next launch's transcript block does
    ZK_SHARD_SKIP1          1         0 .. 1       0: the sharded prover's round kernels form every sum (no S(1) / S(D) derivation behind the all-reduce)
    ZK_PIPE_DEBUG / ZK_HOST_DEBUG  off  flag       phase stamps of the pipelined rounds / host enqueue + wait times on stderr        */
 

@@ -1470,6 +1470,8 @@ struct RoundState {
     // round - 1, before its challenge was known); `cur` still awaits that fold (pending_fold is true)
     bool pipe_active;
     uint32_t pipe_blocks;             // work blocks that wrote them
+    bool pipe_total;                  // slot 0 of their buffer holds the total (k_round_pipe, k_round_mid with a totalling last block);
+                                      // false: the next launch's transcript block (or the finisher) adds the pipe_blocks partials up
     FinishPublish pub;                // flag != null: the pipelined finisher, being the call's last launch, publishes the proof block itself
     bool published;                   // ... and has been enqueued with that job
 };
@@ -1505,6 +1507,7 @@ static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uin
     st.dv = {};
     st.pipe_active = false;
     st.pipe_blocks = 0;
+    st.pipe_total = true;
     st.pub = {};
     st.published = false;
     for (uint64_t i = 0; i < (uint64_t)kMaxFactors; ++i) {
@@ -1597,15 +1600,22 @@ static uint64_t pipe_max_pairs() {
 }
 // Above pipe_max_pairs() and up to this many pairs the same schedule can run on k_round_mid (four lanes per pair index instead of
 // a sixteen-lane row): ZK_PIPE_MID_MAX_PAIRS.  DEFAULT 0 = no such rounds: measured on MI355X (profiles/r05_mid_rounds_ab.log) a
-// k_round_mid launch takes 17.5 / 22 / 36 us at 2^13 / 2^14 / 2^15 pairs against 16.4 / 18.3 / 21.6 us for the classic round
-// kernel + k_round_tail it would replace -- every round added to the pipeline made the n = 20 proof ~10 us slower.  The kernel
-// stays (bit-exact under the whole prover grid, tests/test_gpu_parity.py) as the measured answer to "pipeline the middle rounds".
+// k_round_mid launch takes 11.4 / 15.5 / 22.8 us at 2^13 / 2^14 / 2^15 pairs (17.5 / 22 / 36 us in its first version) against
+// 16.4 / 18.3 / 21.6 us for the classic round kernel + k_round_tail it replaces, and end to end the provers tie (n = 20 0.328-0.330
+// vs 0.326-0.332 ms).  The kernel stays (bit-exact under the whole prover grid, tests/test_gpu_parity.py) as the measured answer to
+// "pipeline the middle rounds".
 static uint64_t pipe_mid_max_pairs() {
     static const uint64_t v = [] {
         uint64_t x = env_u64("ZK_PIPE_MID_MAX_PAIRS", 0, 0, (uint64_t)1 << 40);
         if (!pipe_max_pairs()) return (uint64_t)0;   // ZK_PIPE_MAX_PAIRS=0 switches every pipelined round off (1: k_round_mid takes them all)
         return x > mid_max_pairs() ? mid_max_pairs() : x;
     }();
+    return v;
+}
+// ZK_PIPE_MID_TOTAL=1: k_round_mid's last block adds the block partials up (fence + counter + reduction at the end of the launch);
+// default 0: the next launch's transcript block does
+static bool mid_totals() {
+    static const bool v = env_u64("ZK_PIPE_MID_TOTAL", 0, 0, 1) != 0;
     return v;
 }
 static inline uint64_t pipe_limit_pairs() { return std::max(pipe_max_pairs(), pipe_mid_max_pairs()); }
@@ -1686,7 +1696,11 @@ static int32_t finish_pipe_enqueue(RoundState &st) {
     fl.m_in = (uint32_t)st.vars_left;
     fl.entry = st.pipe_active ? 2 : (st.pending_fold ? 1 : 0);
     fl.e_partials = epart_of_round(st, st.round);
-    fl.e_blocks = 1;   // slot 0 of the buffer holds the total
+    fl.e_blocks = 1;   // slot 0 of the buffer holds the total ...
+    if (st.pipe_active && !st.pipe_total) {   // ... unless the launch before left its block partials only (slots 1 .. pipe_blocks)
+        fl.e_partials += (size_t)pipe_values_per_block(k, st.D) * 4;
+        fl.e_blocks = st.pipe_blocks;
+    }
     fl.pc = c->pipe_consts;
     fl.chal_in = chal_prev(st);
     const uint64_t remaining = st.pending_fold ? st.vars_left - 1 : st.vars_left;
@@ -1740,6 +1754,7 @@ static int32_t pipe_enter(RoundState &st, const DeferredTail &dt) {
     pl.emit = 1;
     pl.q = (uint64_t)1 << (st.vars_left - 2);   // vars_left = variables of this round's table (after its fold)
     pl.mid = pipe_use_mid(pl.q);
+    pl.mid_total = pl.mid && mid_totals();
     pl.chal_fold = nullptr;
     pl.e_partials = epart_of_round(st, st.round + 1);
     pl.done_counter = epart_counter(st, st.round + 1);
@@ -1761,6 +1776,7 @@ static int32_t pipe_enter(RoundState &st, const DeferredTail &dt) {
     }
     st.pipe_active = true;
     st.pipe_blocks = g;
+    st.pipe_total = !pl.mid || pl.mid_total;
     return ZK_OK;
 }
 // Pipelined state at round s = st.round: cur = table of round s-1 (vars_left variables), its challenge r_{s-1} pending, E_s
@@ -1781,10 +1797,15 @@ static int32_t pipe_step(RoundState &st) {
     pl.q = m >= 3 ? (uint64_t)1 << (m - 3) : 0;
     if (pl.q == 0) return ZK_ERR_BAD_ARG;        // cannot happen: the finisher takes tables this small
     pl.mid = pipe_use_mid(pl.q);
+    pl.mid_total = pl.mid && mid_totals();
     pl.chal_fold = chal_prev(st);
     pl.e_partials = epart_of_round(st, st.round + 1);
     pl.done_counter = epart_counter(st, st.round + 1);
     pl.tail = pipe_tail_args(st, 1, epart_of_round(st, st.round), 1, pipe_values_per_block(k, st.D));   // slot 0: the total
+    if (!st.pipe_total) {   // the launch before left its block partials only: this transcript block adds them up
+        pl.tail.partials = epart_of_round(st, st.round) + (size_t)pipe_values_per_block(k, st.D) * 4;
+        pl.tail.nblocks = st.pipe_blocks;
+    }
     FactorPtrs fp = {};
     for (uint64_t i = 0; i < st.k; ++i) {
         fp.in[i] = st.cur[i];
@@ -1801,6 +1822,7 @@ static int32_t pipe_step(RoundState &st) {
     st.vars_left = m - 1;                        // cur = table of round s, r_s pending
     st.pipe_active = stay;
     st.pipe_blocks = g;
+    st.pipe_total = !pl.mid || pl.mid_total;
     ++st.round;
     return ZK_OK;
 }

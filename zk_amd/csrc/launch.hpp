@@ -41,6 +41,7 @@ struct PipeLaunch {
     uint32_t D;
     bool fold;                // work blocks first fold fp.in (8q elements) -> fp.out (4q) at *chal_fold
     bool mid;                 // k_round_mid (four lanes per pair index) instead of k_round_pipe's sixteen-lane rows
+    bool mid_total;           // ... whose last block adds the block partials up (slot 0); false: the next launch's transcript block does
     int emit;                 // 1: write the E partials of the round with q pairs; 0: fold only (leaving the pipeline)
     uint64_t q;               // pairs of the round whose E is prepared
     const uint64_t *chal_fold;

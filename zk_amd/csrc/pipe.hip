@@ -63,9 +63,9 @@ static uint32_t mid_work_blocks(uint64_t q) {
 template <int K, int D, int EXTRA>
 static void launch_mid_shape(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t g) {
     if (pl.fold)
-        k_round_mid<K, D, EXTRA, true><<<g + 1, kMidThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail);
+        k_round_mid<K, D, EXTRA, true><<<g + 1, kMidThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail, pl.mid_total ? 1 : 0);
     else
-        k_round_mid<K, D, EXTRA, false><<<g + 1, kMidThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail);
+        k_round_mid<K, D, EXTRA, false><<<g + 1, kMidThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail, pl.mid_total ? 1 : 0);
 }
 static int launch_round_mid(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t *out_work_blocks) {
     if (pl.q > mid_max_pairs()) return kLaunchUnsupported;

@@ -595,20 +595,14 @@ ZK_D void fe_store_wt(uint64_t *base, uint64_t idx, const Fe &r) {
 #endif
 }
 template <int F, int K, int D, int EXTRA, bool FOLD>
-ZK_D void mid_factor(const FactorPtrs &fp, uint64_t j, uint64_t q, bool live, uint32_t c, const Mul29 &r, const NodeMasks &m, Fe (&prod)[D + 1],
-                     WideAcc (&acc)[D + 1], Fe (&sum)[D + 1], const FieldParams &P) {
+ZK_D void mid_factor(const FactorPtrs &fp, const Fe &x, const Fe &y, uint64_t j, uint64_t q, bool live, uint32_t c, const Mul29 &r, const NodeMasks &m,
+                     Fe (&prod)[D + 1], WideAcc (&acc)[D + 1], Fe (&sum)[D + 1], const FieldParams &P) {
     constexpr int NS = D + 1;
-    // ---- A: this lane's value of factor F
-    Fe a = fe_zero();
-    if (live) {
-        const Fe x = fe_load(fp.in[F], j + (uint64_t)c * q);
-        if constexpr (FOLD) {
-            const Fe y = fe_load(fp.in[F], j + (uint64_t)(c + 4) * q);
-            a = fe_sub(x, fe_mul29(fe_sub(x, y, P), r, P), P);   // evaluation_form.rs:68
-            fe_store_wt(fp.out[F], j + (uint64_t)c * q, a);
-        } else {
-            a = x;
-        }
+    // ---- A: this lane's value of factor F (x, y: its two table elements, loaded by the caller for ALL factors before any arithmetic)
+    Fe a = x;
+    if constexpr (FOLD) {
+        a = fe_sub(x, fe_mul29(fe_sub(x, y, P), r, P), P);   // evaluation_form.rs:68
+        if (live) fe_store_wt(fp.out[F], j + (uint64_t)c * q, a);
     }
     const Fe a0 = quad_bcast<0>(a), a1 = quad_bcast<1>(a), a2 = quad_bcast<2>(a), a3 = quad_bcast<3>(a);
     // ---- B: the factor's value at this lane's node, t = 0 and t = 1, then linear in t
@@ -636,7 +630,7 @@ ZK_D void mid_factor(const FactorPtrs &fp, uint64_t j, uint64_t q, bool live, ui
 // grid: block 0 = transcript block, blocks 1.. = work (at most kMaxLazy pair indices per quad: the host sizes the grid)
 template <int K, int D, int EXTRA, bool FOLD>
 __global__ __launch_bounds__(kMidThreads) void k_round_mid(FactorPtrs fp, uint64_t q, int emit, FieldParams P, const uint64_t *__restrict__ chal_fold,
-                                                           uint64_t *__restrict__ e_partials, uint32_t *done_counter, PipeTailArgs ta) {
+                                                           uint64_t *__restrict__ e_partials, uint32_t *done_counter, PipeTailArgs ta, int total) {
     using S = PipeShape<K, D, EXTRA>;
     constexpr int NS = S::NS, NR = S::NR, NE = S::NE, kWaves = kMidThreads / 64;
     if (blockIdx.x == 0) {
@@ -669,10 +663,20 @@ __global__ __launch_bounds__(kMidThreads) void k_round_mid(FactorPtrs fp, uint64
         const uint64_t j = j0 + (threadIdx.x >> 2);
         const bool live = j < q;
         if (emit) {
-            mid_factor<0, K, D, EXTRA, FOLD>(fp, j, q, live, c, r, m, prod, acc, sum, P);
-            if constexpr (K + EXTRA > 1) mid_factor<1, K, D, EXTRA, FOLD>(fp, j, q, live, c, r, m, prod, acc, sum, P);
-            if constexpr (K + EXTRA > 2) mid_factor<2, K, D, EXTRA, FOLD>(fp, j, q, live, c, r, m, prod, acc, sum, P);
-            if constexpr (K + EXTRA > 3) mid_factor<3, K, D, EXTRA, FOLD>(fp, j, q, live, c, r, m, prod, acc, sum, P);
+            Fe x[S::NF], y[S::NF];   // every load of this pair index is issued before any arithmetic: one memory round trip per pass
+#pragma unroll
+            for (int f = 0; f < S::NF; ++f) {
+                x[f] = fe_zero();
+                y[f] = fe_zero();
+                if (live) {
+                    x[f] = fe_load(fp.in[f], j + (uint64_t)c * q);
+                    if constexpr (FOLD) y[f] = fe_load(fp.in[f], j + (uint64_t)(c + 4) * q);
+                }
+            }
+            mid_factor<0, K, D, EXTRA, FOLD>(fp, x[0], y[0], j, q, live, c, r, m, prod, acc, sum, P);
+            if constexpr (K + EXTRA > 1) mid_factor<1, K, D, EXTRA, FOLD>(fp, x[1], y[1], j, q, live, c, r, m, prod, acc, sum, P);
+            if constexpr (K + EXTRA > 2) mid_factor<2, K, D, EXTRA, FOLD>(fp, x[2], y[2], j, q, live, c, r, m, prod, acc, sum, P);
+            if constexpr (K + EXTRA > 3) mid_factor<3, K, D, EXTRA, FOLD>(fp, x[3], y[3], j, q, live, c, r, m, prod, acc, sum, P);
         } else if (FOLD && live) {   // the launch that leaves the pipeline: fold only
 #pragma unroll
             for (int f = 0; f < S::NF; ++f) {
@@ -713,6 +717,10 @@ __global__ __launch_bounds__(kMidThreads) void k_round_mid(FactorPtrs fp, uint64
         for (int w = 1; w < kWaves; ++w) tot = fe_add(tot, redw[w][threadIdx.x], P);
         fe_store(e_partials, (uint64_t)(wb + 1) * NE + threadIdx.x, tot);   // slot 0 is the total
     }
+    // total == 0: the per-block partials are the launch's result -- the NEXT launch's transcript block adds them up (it has the time: in
+    // these rounds the work blocks, not the transcript block, decide when a launch ends), and this one ends without fence, counter or a
+    // last block's reduction (~4 us of its chain)
+    if (!total) return;
     // the block that finishes last adds the partials up (as k_round_pipe: release / acquire at agent scope)
     __syncthreads();
     if (threadIdx.x == 0) {
