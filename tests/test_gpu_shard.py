@@ -86,6 +86,37 @@ def test_shard_rounds_derive_behind_the_allreduce():
         assert r.returncode == 0 and "shard skip ok" in r.stdout, str(extra) + r.stdout + r.stderr
 
 
+def test_interleaved_shard_provers_and_plain_proofs_on_one_context():
+    """The claim S_prev(r_prev) a SKIP1 round kernel parks for k_lanes_transcript stays live from round_begin to round_finish, i.e.
+    across API calls: it belongs to the prover (ProverScratch), not to the context.  Two DIFFERENT sharded proofs (one rank each,
+    tables of 2^18 elements: the shipped thresholds select SKIP1 + LEAD from 2^16 pairs) stepped in lockstep on ONE context, with
+    a plain prove_partial of a third polynomial enqueued between every begin and finish, each equal to the oracle's proof."""
+    field = zk_amd.BN254_FR
+    ctx = zk_amd.Context(field, 0)
+    n, k, D = 18, 2, 2
+    cases = []
+    for j in range(3):
+        tabs = [orc.fill_random(field, 9100 + 10 * j + f, 1 << n) for f in range(k)]
+        claimed = claimed_sum(field, n, tabs)
+        cases.append((tabs, claimed, orc.sumcheck_prove(field, n, tabs, D, claimed, False)))
+    polys = [ProductPoly.new([MLE.new(ctx, n, t) for t in tabs]) for tabs, _, _ in cases]
+    a, b = (GpuShardBackend(polys[j], D, cases[j][1], 1) for j in (0, 1))
+    plain = zk_amd.SumcheckProver(D)
+    while a.local_vars_left() > 3:
+        a.round_begin()
+        b.round_begin()
+        proof, ch = plain.prove_partial(polys[2], cases[2][1])
+        assert np.array_equal(proof.round_polys, cases[2][2][0]) and np.array_equal(ch, cases[2][2][1])
+        b.round_finish()      # the other order than begin
+        a.round_finish()
+    for j, be in enumerate((a, b)):
+        be.tail_rounds(be.tail().clone())
+        rp, ch = be.results()
+        assert np.array_equal(rp, cases[j][2][0]) and np.array_equal(ch, cases[j][2][1]), f"prover {j}"
+        be.close()
+    ctx.close()
+
+
 def test_single_rank_orchestration_equals_plain_prover():
     field = zk_amd.BN254_FR
     ctx = zk_amd.Context(field, 0)

@@ -342,7 +342,7 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIPCHK(hipMalloc(&c->d_partials, (size_t)kMaxGrid * kMaxSums * 32));
-    HIPCHK(hipMalloc(&c->d_sums, (size_t)kMaxSums * 32 * 3 + 32));   // (+ one element: the claim of a SKIP1 round, ClaimJob)
+    HIPCHK(hipMalloc(&c->d_sums, (size_t)kMaxSums * 32 * 3));
     // completion word + result staging are POLLED by the host while the kernel that writes them is still running: ask for
     // coherent (fine-grained) mapped memory explicitly instead of relying on HIP_HOST_COHERENT's default
     HIPCHK(hipHostMalloc(&c->h_pinned, (size_t)kMaxSums * 32 * 3, kPolledHostFlags));
@@ -1094,9 +1094,13 @@ extern "C" int32_t zk_product_evaluate(zk_ctx *c, const zk_mle *const *f, uint64
 // round loop waits on the host: k_round (+fold) -> k_round_tail (reduce + transcript) -> k_round (+fold) -> ...
 constexpr size_t kChalWords = kChallengeBytes / 8;                                   // one challenge record, in u64
 constexpr size_t kEpartBytes = (size_t)((kMidMaxWorkBlocks > kPipeMaxWorkBlocks ? kMidMaxWorkBlocks : kPipeMaxWorkBlocks) + 2) * 16 * 32;         // E partials of one pipelined round (+ total + counter)
+constexpr size_t kChalBlockBytes = 2 * kChallengeBytes + 32;   // two challenge records + the claim element
 struct ProverScratch {
     WordSponge *d_sponge;
     uint64_t *d_challenge;   // TWO challenge records (round s uses slot s & 1): a pipelined launch reads r_{s-2} while r_{s-1} is written
+    uint64_t *d_claim;       // one element behind them: the claim S_prev(r_prev) a SKIP1 round kernel parks for its tail (ClaimJob).  Per
+                             // PROVER, not per context: the sharded prover keeps it live from round_begin to round_finish, across API
+                             // calls in which other provers of the same context may run their own SKIP1 rounds
     uint64_t *d_epart;       // two E-partial buffers (pipelined rounds), same alternation
     uint64_t *d_rp;          // rounds * (D+1) elements
     uint64_t *d_ch;          // rounds elements
@@ -1129,11 +1133,13 @@ static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint
         ps.d_ch = chain->d_ch;
         ps.d_final = chain->d_final;
         ps.d_epart = chain->d_epart;
-        ZKCHK(pool_alloc(c, 2 * kChallengeBytes, (void **)&ps.d_challenge));
+        ZKCHK(pool_alloc(c, kChalBlockBytes, (void **)&ps.d_challenge));
+        ps.d_claim = ps.d_challenge + 2 * kChalWords;
         return ZK_OK;
     }
     ZKCHK(pool_alloc(c, sizeof(WordSponge), (void **)&ps.d_sponge));
-    ZKCHK(pool_alloc(c, 2 * kChallengeBytes, (void **)&ps.d_challenge));
+    ZKCHK(pool_alloc(c, kChalBlockBytes, (void **)&ps.d_challenge));
+    ps.d_claim = ps.d_challenge + 2 * kChalWords;
     ZKCHK(pool_alloc(c, 2 * kEpartBytes + 16, (void **)&ps.d_epart));   // counters: cleared by sponge_to_device
     ZKCHK(pool_alloc(c, ps.rp_bytes + ps.ch_bytes + kMaxFactors * 32, (void **)&ps.d_rp));
     ps.d_ch = ps.d_rp + ps.rp_bytes / 8;
@@ -1142,12 +1148,12 @@ static int32_t scratch_alloc(zk_ctx *c, ProverScratch &ps, uint64_t rounds, uint
 }
 static void scratch_free(zk_ctx *c, ProverScratch &ps) {
     if (ps.external) {
-        pool_free(c, ps.d_challenge, 2 * kChallengeBytes);
+        pool_free(c, ps.d_challenge, kChalBlockBytes);
         ps = {};
         return;
     }
     pool_free(c, ps.d_sponge, sizeof(WordSponge));
-    pool_free(c, ps.d_challenge, 2 * kChallengeBytes);
+    pool_free(c, ps.d_challenge, kChalBlockBytes);
     pool_free(c, ps.d_epart, 2 * kEpartBytes + 16);
     pool_free(c, ps.d_rp, ps.rp_bytes + ps.ch_bytes + kMaxFactors * 32);
     ps = {};
@@ -1171,7 +1177,6 @@ static inline RoundLaunchCtx launch_ctx(zk_ctx *c) {
     RoundLaunchCtx lc = {c->stream, &c->fi->P, c->d_partials, (uint64_t)kMaxGrid * kMaxSums, {}};
     return lc;
 }
-static inline uint64_t *claim_slot(zk_ctx *c) { return c->d_sums + (size_t)kMaxSums * 4 * 3; }
 // ZK_CLAIM_IN_ROUND=0: the tails evaluate the SKIP1 claim themselves (round 4's behaviour; A/B)
 static bool claim_in_round() {
     static const bool v = env_u64("ZK_CLAIM_IN_ROUND", 1, 0, 1) != 0;
@@ -1186,6 +1191,7 @@ struct TailTargets {
     uint64_t *out_ch;       // challenge record (device), may be null
     uint64_t *d_challenge;  // challenge for the next fused fold
     uint64_t *lanes;        // 32-bit digit lanes for the cross-GPU all-reduce, may be null
+    uint64_t *claim_park;   // one element owned by the prover (ProverScratch::d_claim); null: no SKIP1 round is possible (no previous round)
     TailDerive *lanes_dv;   // with lanes (host memory, may be null): out -- what k_lanes_transcript has to derive after the all-reduce
                             // (S(1) from the claim, S(D) from the leading coefficient); null: the round kernels compute every sum
 };
@@ -1232,11 +1238,11 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
         // (sharded: both variants accumulate quantities that are linear in the shards, so they survive the all-reduce; the
         // derivations move behind it -- tt.lanes_dv tells zk_shard_prover_round_finish what to derive)
         const bool may_derive = !tt.lanes || (tt.lanes_dv && shard_skip_on());
-        bool skip1 = dv && dv->prev_rp && fused && may_derive && D <= (uint32_t)kMaxSkipDegree && q >= skip1_min_pairs();
+        bool skip1 = dv && dv->prev_rp && tt.claim_park && fused && may_derive && D <= (uint32_t)kMaxSkipDegree && q >= skip1_min_pairs();
         bool lead = may_derive && q >= lead_min_pairs();   // (the launchers clear it for shapes without the variant)
         // a SKIP1 kernel, if one is launched below, evaluates the claim its tail needs beside its work blocks (ClaimJob)
         ClaimJob cjob = {};
-        if (skip1 && claim_in_round()) cjob = ClaimJob{dv->prev_rp, dv->prev_chal, dv->w, claim_slot(c), D + 1};
+        if (skip1 && claim_in_round()) cjob = ClaimJob{dv->prev_rp, dv->prev_chal, dv->w, tt.claim_park, D + 1};
         auto with_claim = [&](RoundLaunchCtx lc) {
             lc.claim = cjob;
             return lc;
@@ -1273,7 +1279,10 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
                 return ZK_OK;
             }
         }
-        if (ts.n_terms != 1) skip1 = lead = false;
+        if (ts.n_terms != 1) {
+            skip1 = lead = false;
+            cjob = {};   // no SKIP1 kernel below: no claim workgroup either
+        }
         for (int i = 0; i < ts.n_terms; ++i) {
             FactorPtrs sub = {};
             for (int f = 0; f < ts.term_k[i]; ++f) {
@@ -1331,7 +1340,7 @@ extern "C" int32_t zk_round_sums(zk_ctx *c, const zk_mle *const *f, uint64_t k, 
     for (uint64_t i = 0; i < k; ++i) fp.in[i] = f[i]->d;
     const uint64_t q = 1ull << (f[0]->n_vars - 1);
     uint64_t *d_out = c->d_sums + 4 * kMaxSums;   // second third of d_sums
-    TailTargets tt = {nullptr, d_out, nullptr, nullptr, nullptr};
+    TailTargets tt = {nullptr, d_out, nullptr, nullptr, nullptr, nullptr, nullptr};
     ZKCHK(launch_sums(c, fp, single_term((int)k), q, D, false, nullptr, tt));
     HIPCHK(hipMemcpyAsync(out, d_out, (size_t)(D + 1) * 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1560,6 +1569,7 @@ static int32_t round_enqueue(RoundState &st, uint64_t *lanes, DeferredTail *defe
     tt.out_ch = st.ps.d_ch + st.round * 4;
     tt.d_challenge = chal_cur(st);
     tt.lanes = lanes;
+    tt.claim_park = st.ps.d_claim;
     tt.lanes_dv = lanes_dv;
     int32_t rc;
     if (st.pending_fold && !fast_degree(st.D)) {

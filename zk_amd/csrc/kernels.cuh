@@ -406,11 +406,12 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
     if (sponge && wave0) sp = lane_sponge_load(sponge, L);
     // wave w owns the sums t = w, w+4, ...: lanes stride over the blocks' partials, one VALU wave reduction, one barrier
     for (uint32_t t = wave; t < ns; t += kBlock / 64) {
-        if (derive1 && t == 1 && dv.claim) {
-            // this wave would own t = 1: the round kernel's claim workgroup has evaluated S_prev(r_prev) already
+        if (derive1 && t == 1 && (dv.claim || dv.local_only)) {
+            // this wave would own t = 1: the round kernel's claim workgroup has evaluated S_prev(r_prev) already -- or nobody needs
+            // it here: a sharded round derives S(1) after the all-reduce (k_lanes_transcript reads or evaluates the claim itself)
             if (lane == 0) {
-                claim = fe_load(dv.claim, 0);
-                if (dv.local_only) fin[1] = fe_zero();   // sharded: S(1) is derived after the all-reduce (k_lanes_transcript reads the same claim)
+                if (dv.local_only) fin[1] = fe_zero();
+                else claim = fe_load(dv.claim, 0);
             }
             continue;
         }
@@ -432,10 +433,7 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
                 }
             }
             term = fe_wave_sum(term, P, 8);
-            if (lane == 0) {
-                claim = term;
-                if (dv.local_only) fin[1] = fe_zero();   // sharded: no t = 1 partials exist here; S(1) is derived after the all-reduce
-            }
+            if (lane == 0) claim = term;
             continue;
         }
         Fe s = fe_zero();
