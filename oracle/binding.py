@@ -153,7 +153,16 @@ def from_int(field, v):
 
 
 def from_ints(field, vs):
-    return np.stack([from_int(field, v) for v in vs]) if len(vs) else np.zeros((0, 4), dtype=np.uint64)
+    """canonical Python ints (any sign/size, reduced mod p) -> (n, 4) Montgomery elements, one library call"""
+    n = len(vs)
+    if n == 0:
+        return np.zeros((0, 4), dtype=np.uint64)
+    p = modulus(field)
+    raw = b"".join((int(v) % p).to_bytes(32, "little") for v in vs)
+    limbs = np.frombuffer(raw, dtype="<u8").astype(np.uint64).reshape(n, 4)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    _lib.orc_from_canonical_n(field, _p(limbs), _c.c_uint64(n), _p(out))
+    return out
 
 
 def to_int(field, a):
@@ -165,7 +174,13 @@ def to_int(field, a):
 
 def to_ints(field, arr):
     arr = _arr(arr).reshape(-1, 4)
-    return [to_int(field, arr[i]) for i in range(arr.shape[0])]
+    n = arr.shape[0]
+    if n == 0:
+        return []
+    limbs = np.zeros((n, 4), dtype=np.uint64)
+    _lib.orc_to_canonical_n(field, _p(arr), _c.c_uint64(n), _p(limbs))
+    raw = limbs.astype("<u8").tobytes()
+    return [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(n)]
 
 
 def to_bytes_be(field, a):
@@ -269,6 +284,14 @@ def prod_reduce(field, n_vars, tables):
     tabs, ptrs = _table_ptrs(tables, n_vars)
     out = np.zeros((1 << n_vars, 4), dtype=np.uint64)
     _lib.orc_prod_reduce(field, _c.c_uint64(len(tabs)), _c.c_uint64(n_vars), ptrs, _p(out))
+    return out
+
+
+def sum_elems(field, elems):
+    """iter().sum::<F>() (prover.rs:53-54) of an (n, 4) array"""
+    a = _arr(elems)
+    out = np.zeros(4, dtype=np.uint64)
+    _lib.orc_sum(field, _p(a), _c.c_uint64(a.shape[0]), _p(out))
     return out
 
 

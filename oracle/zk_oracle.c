@@ -214,6 +214,15 @@ void orc_from_u64(int field, u64 v, u64 out[4]) {
 }
 void orc_from_canonical(int field, const u64 limbs[4], u64 out[4]) { f_from_canonical(field_get(field), limbs, out); }
 void orc_to_canonical(int field, const u64 a[4], u64 limbs[4]) { f_to_canonical(field_get(field), a, limbs); }
+/* the same for n elements at once (test harness convenience: Python big-int lists <-> element arrays) */
+void orc_from_canonical_n(int field, const u64 *limbs, u64 n, u64 *out) {
+    const fparams *F = field_get(field);
+    for (u64 i = 0; i < n; ++i) f_from_canonical(F, limbs + 4 * i, out + 4 * i);
+}
+void orc_to_canonical_n(int field, const u64 *a, u64 n, u64 *limbs) {
+    const fparams *F = field_get(field);
+    for (u64 i = 0; i < n; ++i) f_to_canonical(F, a + 4 * i, limbs + 4 * i);
+}
 
 /* elem.into_bigint().to_bytes_be()  (evaluation_form.rs:100, sumcheck/src/lib.rs:26, prover.rs:42) */
 void orc_to_bytes_be(int field, const u64 a[4], uint8_t out[32]) {
@@ -424,6 +433,13 @@ void orc_prod_reduce(int field, u64 k, u64 n_vars, const u64 *const *tables, u64
     memcpy(out, tables[0], len * 32);                                                /* :67 to_vec */
     for (u64 f = 1; f < k; ++f)
         for (u64 i = 0; i < len; ++i) f_mul(F, out + 4 * i, tables[f] + 4 * i, out + 4 * i); /* :70 */
+}
+/* .iter().sum::<F>() of a slice (sumcheck/src/prover.rs:53-54; the tests' "claimed sum" of a product table, sumcheck/src/lib.rs:56) */
+void orc_sum(int field, const u64 *elems, u64 n, u64 out[4]) {
+    const fparams *F = field_get(field);
+    u64 s[4] = {0, 0, 0, 0};
+    for (u64 j = 0; j < n; ++j) f_add(F, s, elems + 4 * j, s);
+    memcpy(out, s, 32);
 }
 int orc_product_evaluate(int field, u64 k, u64 n_vars, const u64 *const *tables, const u64 *point,
                          u64 n_point, u64 out[4]) {                                 /* :36-44 */

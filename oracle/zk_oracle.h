@@ -63,6 +63,8 @@ int orc_inverse(int field, const uint64_t a[4], uint64_t out[4]); /* 0 ok, 1 if 
 void orc_from_u64(int field, uint64_t v, uint64_t out[4]);                 /* F::from(v) */
 void orc_from_canonical(int field, const uint64_t limbs[4], uint64_t out[4]); /* int -> Montgomery (int must be < p) */
 void orc_to_canonical(int field, const uint64_t a[4], uint64_t limbs[4]);  /* into_bigint() */
+void orc_from_canonical_n(int field, const uint64_t *limbs, uint64_t n, uint64_t *out);
+void orc_to_canonical_n(int field, const uint64_t *a, uint64_t n, uint64_t *limbs);
 void orc_to_bytes_be(int field, const uint64_t a[4], uint8_t out[32]);     /* into_bigint().to_bytes_be() */
 void orc_from_be_bytes_mod_order(int field, const uint8_t *bytes, size_t len, uint64_t out[4]);
 int orc_root_of_unity(int field, uint64_t n, uint64_t out[4]);             /* F::get_root_of_unity(n) */
@@ -97,6 +99,7 @@ int orc_coeff_to_evaluation(int field, uint64_t n_vars, const uint64_t *keys, co
 int orc_product_new_check(uint64_t k, const uint64_t *n_vars_each);           /* :14-32 */
 void orc_prod_reduce(int field, uint64_t k, uint64_t n_vars,
                      const uint64_t *const *tables, uint64_t *out);           /* :66-74 */
+void orc_sum(int field, const uint64_t *elems, uint64_t n, uint64_t out[4]);   /* iter().sum::<F>(), prover.rs:53-54 */
 int orc_product_evaluate(int field, uint64_t k, uint64_t n_vars, const uint64_t *const *tables,
                          const uint64_t *point, uint64_t n_point, uint64_t out[4]); /* :36-44 */
 

@@ -94,9 +94,7 @@ def test_keccak_and_transcript_match_oracle():
 def test_verify_partial_matches_oracle(field, k, D, n_vars):
     """verifier.rs:38-78 host logic on proofs produced by the ORACLE prover (no GPU involved)."""
     tabs = [orc.fill_random(field, 100 + f, 1 << n_vars) for f in range(k)]
-    claimed = np.zeros(4, dtype=np.uint64)
-    for e in orc.prod_reduce(field, n_vars, tabs):
-        claimed = orc.add(field, claimed, e)
+    claimed = orc.sum_elems(field, orc.prod_reduce(field, n_vars, tabs))   # iter().sum::<F>()
     rp, ch = orc.sumcheck_prove(field, n_vars, tabs, D, claimed, absorb_table=False)
     sub = zk_amd.SumcheckVerifier.verify_partial(field, zk_amd.SumcheckProof(claimed, rp))
     osub, och = orc.sumcheck_verify_partial(field, D, claimed, rp)

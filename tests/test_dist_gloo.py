@@ -33,9 +33,7 @@ def _worker(rank, world, port, field, k, D, n_vars, out_dir, gather_below=0):
         from zk_amd.distributed import ShardedSumcheckProver, shard_of
 
         tabs = [orc.fill_random(field, 900 + f, 1 << n_vars) for f in range(k)]
-        claimed = np.zeros(4, dtype=np.uint64)
-        for e in orc.prod_reduce(field, n_vars, tabs):
-            claimed = orc.add(field, claimed, e)
+        claimed = orc.sum_elems(field, orc.prod_reduce(field, n_vars, tabs))   # iter().sum::<F>()
         backend = OracleShardBackend(field, [shard_of(t, rank, world) for t in tabs], D, claimed, world)
         rp, ch = ShardedSumcheckProver(backend, gather_below=gather_below).prove_partial()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rp=rp, ch=ch)
@@ -56,9 +54,7 @@ def test_sharded_prover_matches_single_process_oracle(tmp_path, world, field, k,
     port = _free_port()
     mp.spawn(_worker, args=(world, port, field, k, D, n_vars, str(tmp_path), gather_below), nprocs=world, join=True)
     tabs = [orc.fill_random(field, 900 + f, 1 << n_vars) for f in range(k)]
-    claimed = np.zeros(4, dtype=np.uint64)
-    for e in orc.prod_reduce(field, n_vars, tabs):
-        claimed = orc.add(field, claimed, e)
+    claimed = orc.sum_elems(field, orc.prod_reduce(field, n_vars, tabs))   # iter().sum::<F>()
     want_rp, want_ch = orc.sumcheck_prove(field, n_vars, tabs, D, claimed, False)
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))

@@ -21,9 +21,7 @@ def _workload(field, seed):
     """inputs + oracle answers for one thread: n = 16 prover (k = 2, D = 2), n = 18 evaluate, 2^14-point NTT"""
     n = 16
     tabs = [orc.fill_random(field, seed + f, 1 << n) for f in range(2)]
-    claimed = np.zeros(4, dtype=np.uint64)
-    for e in orc.prod_reduce(field, n, tabs):
-        claimed = orc.add(field, claimed, e)
+    claimed = orc.sum_elems(field, orc.prod_reduce(field, n, tabs))   # iter().sum::<F>()
     rp, ch = orc.sumcheck_prove(field, n, tabs, 2, claimed, False)
     ev_tab = orc.fill_random(field, seed + 7, 1 << 18)
     ev_pt = orc.fill_random(field, seed + 8, 18)

@@ -54,9 +54,7 @@ def _worker(rank, world, port, out_dir):
             for n in (12, 13, 14, 15, 16):
                 k, D = (3, 3) if n == 13 else (2, 2)
                 tabs = [orc.fill_random(field, 7000 + 16 * n + f, 1 << n) for f in range(k)]
-                claimed = np.zeros(4, dtype=np.uint64)
-                for e in orc.prod_reduce(field, n, tabs):
-                    claimed = orc.add(field, claimed, e)
+                claimed = orc.sum_elems(field, orc.prod_reduce(field, n, tabs))   # iter().sum::<F>()
                 want_rp, want_ch = orc.sumcheck_prove(field, n, tabs, D, claimed, False)
                 for gather_below in (0, 10):
                     for driver in ("py", "lib"):

@@ -40,10 +40,7 @@ def ints(field, arr):
 
 
 def sum_elems(field, arr):
-    acc = np.zeros(4, dtype=np.uint64)
-    for e in np.asarray(arr).reshape(-1, 4):
-        acc = orc.add(field, acc, e)
-    return acc
+    return orc.sum_elems(field, np.asarray(arr).reshape(-1, 4))   # iter().sum::<F>() (prover.rs:53-54)
 
 
 # ------------------------------------------------------------------ reference KATs through the GPU path
@@ -361,9 +358,7 @@ for field in (zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR):
         for t in range(D + 1):
             a = orc.from_int(field, t)[None, :]
             folded = [orc.mle_partial_evaluate(field, n, tb, 0, a) for tb in tabs]
-            acc = np.zeros(4, dtype=np.uint64)
-            for e in orc.prod_reduce(field, n - 1, folded):
-                acc = orc.add(field, acc, e)
+            acc = orc.sum_elems(field, orc.prod_reduce(field, n - 1, folded))   # iter().sum::<F>()
             want.append(acc)
         pp = zk_amd.ProductPoly.new([zk_amd.MultiLinearPolynomial.new(c, n, t) for t in tabs])
         assert np.array_equal(pp.round_sums(D), np.stack(want)), (field, k, D, n)
@@ -736,54 +731,87 @@ def test_evaluate_n24_vs_oracle():
     t.free()
 
 
-def test_skip1_rounds_bit_exact():
-    """Big fused rounds leave out the t = 1 sums and derive S(1) from the previous round's claim (k_round_kd SKIP1,
-    TailDerive).  A child process with the threshold forced to 1 pair proves the (k, D) grid that way and compares every
-    proof with the oracle bit for bit (tests/skip1_check.py)."""
-    import os
-    import subprocess
-    import sys
+# Forced kernel-selection paths (the library reads its ZK_* switches once per process: each switch set is a child process running
+# tests/skip1_check.py over the (k, D) grid, wrong claimed sums and the two-term GKR layer shape, every proof compared with the oracle
+# bit for bit).  The children are independent: they run four at a time (the box admits six processes on its card), and the oracle
+# proofs of the whole grid are computed once, before them, on CPU-only workers (tests/oracle_cache.py) instead of in every child.
+SKIP1_RUNS = {
+    # SKIP1 kernels everywhere (no quad kernel, no pipeline: they would take the small rounds)
+    "skip1_everywhere": dict(ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0"),
+    # plain k_round_kd at small sizes
+    "plain_kd_small": dict(ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0"),
+    # the four-lanes-per-pair kernel + classic tails (the pipeline off)
+    "quad_classic_tails": dict(ZK_PIPE_MAX_PAIRS="0", ZK_CHECK_SIZES="7,11,13,15"),
+    # the pipeline from 2^17 pairs down, entered right after SKIP1 rounds (the transcript block derives S(1))
+    "pipe_from_2p17_after_skip1": dict(ZK_PIPE_MAX_PAIRS="131072", ZK_SKIP1_MIN_PAIRS="1", ZK_CHECK_SIZES="11,12,13,15,17"),
+    # the pipeline with defaults at more sizes
+    "pipe_defaults": dict(ZK_CHECK_SIZES="10,12,14,16,18"),
+    # LEAD kernels everywhere (slot D = leading coefficient, the tail rebuilds S(D)): with SKIP1 in every fused round, classic tails
+    "lead_skip1_classic": dict(ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0"),
+    # ... and with the pipeline entered right after a LEAD + SKIP1 round (the transcript block derives S(1), then rebuilds S(D))
+    "lead_skip1_pipe": dict(ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="11,12,13,15"),
+    # LEAD in round 0 only (sums-only kernel), everything else default
+    "lead_round0": dict(ZK_LEAD_MIN_PAIRS="1", ZK_CHECK_SIZES="3,9,14,16"),
+    # round 0 on the wide-accumulator kernel (k_round_kd<2,2,sums only,LEAD>: the A/B fallback of k_round0_dot29) ...
+    "round0_wide": dict(ZK_ROUND0_DOT29="0", ZK_LEAD_MIN_PAIRS="1", ZK_CHECK_SIZES="3,9,14"),
+    # ... and the carry-free round-0 kernel for the product-plus-term shape as well (k_round0_dot29<1>, not selected by default)
+    "round0_dot29_terms": dict(ZK_ROUND0_DOT29="2", ZK_LEAD_MIN_PAIRS="1", ZK_CHECK_SIZES="3,9,13,14"),
+    # k_round_mid (four lanes per pair index) instead of the sixteen-lane rows in EVERY pipelined round, small ones included ...
+    "mid_every_pipelined_round": dict(ZK_PIPE_MAX_PAIRS="1", ZK_CHECK_SIZES="3,4,7,10,12,14,16,18"),
+    # ... entered right after LEAD + SKIP1 rounds, up to 2^17 pairs (several passes per quad), no quad kernel in between
+    # (one field: n = 19 is the size whose first pipelined round needs two passes per quad)
+    "mid_to_2p17_after_lead_skip1": dict(ZK_PIPE_MAX_PAIRS="1", ZK_PIPE_MID_MAX_PAIRS="131072", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1",
+                                         ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="11,13,15,17,19", ZK_CHECK_FIELDS="1"),
+    # SKIP1 + LEAD everywhere with the claim evaluated by the TAILS (round 4's form; shipped: the round kernel's claim workgroup), with
+    # and without the pipeline behind them (k_round_tail / the deferred tail of the first pipelined launch)
+    "claim_in_tails": dict(ZK_CLAIM_IN_ROUND="0", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="3,7,11,13",
+                           ZK_CHECK_FIELDS="2"),
+    # ... and switched off (round 4's schedule: hex rows up to 2^12 pairs, classic rounds above)
+    "mid_off": dict(ZK_PIPE_MID_MAX_PAIRS="0", ZK_CHECK_SIZES="14,16,18"),
+}
+_SWEEP_ENV_KEYS = ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES", "ZK_LEAD_MIN_PAIRS", "ZK_ROUND0_DOT29",
+                   "ZK_PIPE_MID_MAX_PAIRS", "ZK_CHECK_FIELDS", "ZK_CLAIM_IN_ROUND")
 
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    base = {k: v for k, v in os.environ.items()
-            if k not in ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES", "ZK_LEAD_MIN_PAIRS", "ZK_ROUND0_DOT29", "ZK_PIPE_MID_MAX_PAIRS", "ZK_CHECK_FIELDS", "ZK_CLAIM_IN_ROUND")}
-    runs = [
-        # SKIP1 kernels everywhere (no quad kernel, no pipeline: they would take the small rounds)
-        dict(ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0"),
-        # plain k_round_kd at small sizes
-        dict(ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0"),
-        # the four-lanes-per-pair kernel + classic tails (the pipeline off)
-        dict(ZK_PIPE_MAX_PAIRS="0", ZK_CHECK_SIZES="7,11,13,15"),
-        # the pipeline from 2^17 pairs down, entered right after SKIP1 rounds (the transcript block derives S(1))
-        dict(ZK_PIPE_MAX_PAIRS="131072", ZK_SKIP1_MIN_PAIRS="1", ZK_CHECK_SIZES="11,12,13,15,17"),
-        # the pipeline with defaults at more sizes
-        dict(ZK_CHECK_SIZES="10,12,14,16,18"),
-        # LEAD kernels everywhere (slot D = leading coefficient, the tail rebuilds S(D)): with SKIP1 in every fused round, classic tails
-        dict(ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0"),
-        # ... and with the pipeline entered right after a LEAD + SKIP1 round (the transcript block derives S(1), then rebuilds S(D))
-        dict(ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="11,12,13,15"),
-        # LEAD in round 0 only (sums-only kernel), everything else default
-        dict(ZK_LEAD_MIN_PAIRS="1", ZK_CHECK_SIZES="3,9,14,16"),
-        # round 0 on the wide-accumulator kernel (k_round_kd<2,2,sums only,LEAD>: the A/B fallback of k_round0_dot29) ...
-        dict(ZK_ROUND0_DOT29="0", ZK_LEAD_MIN_PAIRS="1", ZK_CHECK_SIZES="3,9,14"),
-        # ... and the carry-free round-0 kernel for the product-plus-term shape as well (k_round0_dot29<1>, not selected by default)
-        dict(ZK_ROUND0_DOT29="2", ZK_LEAD_MIN_PAIRS="1", ZK_CHECK_SIZES="3,9,13,14"),
-        # k_round_mid (four lanes per pair index) instead of the sixteen-lane rows in EVERY pipelined round, small ones included ...
-        dict(ZK_PIPE_MAX_PAIRS="1", ZK_CHECK_SIZES="3,4,7,10,12,14,16,18"),
-        # ... entered right after LEAD + SKIP1 rounds, up to 2^17 pairs (several passes per quad), no quad kernel in between
-        # (one field: n = 19 is the size whose first pipelined round needs two passes per quad, and its oracle proofs take seconds)
-        dict(ZK_PIPE_MAX_PAIRS="1", ZK_PIPE_MID_MAX_PAIRS="131072", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0",
-             ZK_CHECK_SIZES="11,13,15,17,19", ZK_CHECK_FIELDS="1"),
-        # SKIP1 + LEAD everywhere with the claim evaluated by the TAILS (round 4's form; shipped: the round kernel's claim workgroup), with
-        # and without the pipeline behind them (k_round_tail / the deferred tail of the first pipelined launch)
-        dict(ZK_CLAIM_IN_ROUND="0", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="3,7,11,13", ZK_CHECK_FIELDS="2"),
-        # ... and switched off (round 4's schedule: hex rows up to 2^12 pairs, classic rounds above)
-        dict(ZK_PIPE_MID_MAX_PAIRS="0", ZK_CHECK_SIZES="14,16,18"),
-    ]
-    for extra in runs:
-        r = subprocess.run([sys.executable, os.path.join(root, "tests", "skip1_check.py")], env=dict(base, **extra), capture_output=True,
-                           text=True, timeout=900)
-        assert r.returncode == 0 and "skip1 ok" in r.stdout, str(extra) + r.stdout + r.stderr
+
+@pytest.fixture(scope="module")
+def skip1_sweeps(tmp_path_factory):
+    """prefill the oracle cache for the union of the runs' grids, then start every child (four at a time); -> {name: Future}"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_cache
+    import skip1_check
+
+    cache = str(tmp_path_factory.mktemp("oracle_cache"))
+    base = {k: v for k, v in os.environ.items() if k not in _SWEEP_ENV_KEYS}
+    base["ZK_ORACLE_CACHE"] = cache
+    spec = []
+    for extra in SKIP1_RUNS.values():
+        sizes = tuple(int(x) for x in extra.get("ZK_CHECK_SIZES", "2,3,7,11,13").split(","))
+        spec += skip1_check.spec(sizes, int(extra.get("ZK_CHECK_FIELDS", "3")))
+    os.environ["ZK_ORACLE_CACHE"] = cache
+    try:
+        oracle_cache.prefill(spec, workers=min(12, max(2, (os.cpu_count() or 4) - 2)))
+    finally:
+        del os.environ["ZK_ORACLE_CACHE"]
+
+    def child(extra):
+        return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "skip1_check.py")], env=dict(base, **extra), capture_output=True,
+                              text=True, timeout=900)
+
+    pool = ThreadPoolExecutor(max_workers=4)
+    futures = {name: pool.submit(child, extra) for name, extra in SKIP1_RUNS.items()}
+    yield futures
+    pool.shutdown(wait=True)
+
+
+@pytest.mark.parametrize("name", list(SKIP1_RUNS))
+def test_skip1_rounds_bit_exact(skip1_sweeps, name):
+    """Big fused rounds leave out the t = 1 sums and derive S(1) from the previous round's claim (k_round_kd SKIP1, TailDerive), LEAD
+    rounds rebuild S(D), pipelined rounds interpolate: one child process per switch set proves the grid that way and compares every
+    proof with the oracle bit for bit (tests/skip1_check.py).  A failure names its switch set."""
+    r = skip1_sweeps[name].result()
+    assert r.returncode == 0 and "skip1 ok" in r.stdout, str(SKIP1_RUNS[name]) + r.stdout + r.stderr
 
 
 def test_beyond_baseline_sizes_properties():
@@ -847,9 +875,7 @@ def test_product_with_a_repeated_factor(field, k, D, n_vars):
     t = orc.fill_random(field, 41, 1 << n_vars)
     u = orc.fill_random(field, 42, 1 << n_vars)
     tabs = [t, t] + [u] * (k - 2)
-    claimed = np.zeros(4, dtype=np.uint64)
-    for e in orc.prod_reduce(field, n_vars, tabs):
-        claimed = orc.add(field, claimed, e)
+    claimed = orc.sum_elems(field, orc.prod_reduce(field, n_vars, tabs))   # iter().sum::<F>()
     want_rp, want_ch = orc.sumcheck_prove(field, n_vars, tabs, D, claimed, False)
     for consume in (False, True):
         a, b = MLE.new(c, n_vars, t), MLE.new(c, n_vars, u)

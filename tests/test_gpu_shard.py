@@ -15,10 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 def claimed_sum(field, n, tabs):
-    acc = np.zeros(4, dtype=np.uint64)
-    for e in orc.prod_reduce(field, n, tabs):
-        acc = orc.add(field, acc, e)
-    return acc
+    return orc.sum_elems(field, orc.prod_reduce(field, n, tabs))   # iter().sum::<F>() (sumcheck/src/lib.rs:56)
 
 
 @pytest.mark.parametrize("field", [zk_amd.BN254_FR, zk_amd.BLS12_381_FR, zk_amd.BLS12_377_FR])
@@ -55,35 +52,67 @@ def test_shard_provers_match_unsharded_oracle(field, world, k, D, n_vars, gather
     ctx.close()
 
 
-def test_shard_rounds_derive_behind_the_allreduce():
+SHARD_RUNS = {
+    # SKIP1 + LEAD in every fused round of every shape that has them (no quad kernel: it would take the small rounds)
+    "skip1_lead_everywhere": dict(ZK_SKIP1_MIN_PAIRS="1", ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0"),
+    # LEAD only (round 0 included: sums-only LEAD kernels), then SKIP1 only
+    "lead_only": dict(ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0"),
+    "skip1_only": dict(ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0"),
+    # the shipped thresholds on shards of 2^18 (two ranks) and 2^17 elements (four ranks, three factors)
+    "shipped_thresholds_big_shards": dict(ZK_CHECK_CASES="2:2:2:19,4:3:3:19", ZK_CHECK_FIELDS="1"),
+    # round 4's behaviour: every sum formed by the round kernels
+    "derivation_off": dict(ZK_SHARD_SKIP1="0", ZK_SKIP1_MIN_PAIRS="1", ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_FIELDS="1"),
+    # the claim S_prev(r_prev) evaluated by k_lanes_transcript itself (no claim workgroup in the round kernels)
+    "claim_in_lanes_transcript": dict(ZK_CLAIM_IN_ROUND="0", ZK_SKIP1_MIN_PAIRS="1", ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_FIELDS="1"),
+}
+
+
+@pytest.fixture(scope="module")
+def shard_sweeps(tmp_path_factory):
+    """oracle proofs of the runs' grids once (tests/oracle_cache.py), then every child process, three at a time; -> {name: Future}"""
+    import os
+    import subprocess
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import oracle_cache
+    import shard_skip_check
+
+    drop = ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_LEAD_MIN_PAIRS", "ZK_SHARD_SKIP1", "ZK_CHECK_CASES", "ZK_CHECK_FIELDS",
+            "ZK_CLAIM_IN_ROUND")
+    cache = str(tmp_path_factory.mktemp("oracle_cache_shard"))
+    base = {k: v for k, v in os.environ.items() if k not in drop}
+    base["ZK_ORACLE_CACHE"] = cache
+    spec = []
+    for extra in SHARD_RUNS.values():
+        spec += shard_skip_check.spec(shard_skip_check.parse_cases(extra.get("ZK_CHECK_CASES", shard_skip_check.DEFAULT_CASES)),
+                                      int(extra.get("ZK_CHECK_FIELDS", "3")))
+    os.environ["ZK_ORACLE_CACHE"] = cache
+    try:
+        oracle_cache.prefill(spec, workers=min(8, max(2, (os.cpu_count() or 4) - 2)))
+    finally:
+        del os.environ["ZK_ORACLE_CACHE"]
+
+    def child(extra):
+        return subprocess.run([sys.executable, os.path.join(root, "tests", "shard_skip_check.py")], env=dict(base, **extra), capture_output=True,
+                              text=True, timeout=900)
+
+    pool = ThreadPoolExecutor(max_workers=3)
+    futures = {name: pool.submit(child, extra) for name, extra in SHARD_RUNS.items()}
+    yield futures
+    pool.shutdown(wait=True)
+
+
+@pytest.mark.parametrize("name", list(SHARD_RUNS))
+def test_shard_rounds_derive_behind_the_allreduce(shard_sweeps, name):
     """The sharded prover's big rounds run the kernels that leave out S(1) and accumulate the leading coefficient instead of S(D)
     (both linear in the shards); k_lanes_transcript derives the two from the all-reduced lanes.  Child processes force the variants
     on at every size (tests/shard_skip_check.py), run the default thresholds on shards big enough to reach them, and run with the
     derivation switched off; every proof is compared with the oracle's proof of the unsharded tables bit for bit."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    drop = ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_LEAD_MIN_PAIRS", "ZK_SHARD_SKIP1", "ZK_CHECK_CASES", "ZK_CHECK_FIELDS", "ZK_CLAIM_IN_ROUND")
-    base = {k: v for k, v in os.environ.items() if k not in drop}
-    runs = [
-        # SKIP1 + LEAD in every fused round of every shape that has them (no quad kernel: it would take the small rounds)
-        dict(ZK_SKIP1_MIN_PAIRS="1", ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0"),
-        # LEAD only (round 0 included: sums-only LEAD kernels), then SKIP1 only
-        dict(ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0"),
-        dict(ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0"),
-        # the shipped thresholds on shards of 2^18 (two ranks) and 2^17 elements (four ranks, three factors)
-        dict(ZK_CHECK_CASES="2:2:2:19,4:3:3:19", ZK_CHECK_FIELDS="1"),
-        # round 4's behaviour: every sum formed by the round kernels
-        dict(ZK_SHARD_SKIP1="0", ZK_SKIP1_MIN_PAIRS="1", ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_FIELDS="1"),
-        # the claim S_prev(r_prev) evaluated by k_lanes_transcript itself (no claim workgroup in the round kernels)
-        dict(ZK_CLAIM_IN_ROUND="0", ZK_SKIP1_MIN_PAIRS="1", ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_FIELDS="1"),
-    ]
-    for extra in runs:
-        r = subprocess.run([sys.executable, os.path.join(root, "tests", "shard_skip_check.py")], env=dict(base, **extra), capture_output=True,
-                           text=True, timeout=900)
-        assert r.returncode == 0 and "shard skip ok" in r.stdout, str(extra) + r.stdout + r.stderr
+    r = shard_sweeps[name].result()
+    assert r.returncode == 0 and "shard skip ok" in r.stdout, str(SHARD_RUNS[name]) + r.stdout + r.stderr
 
 
 def test_interleaved_shard_provers_and_plain_proofs_on_one_context():

@@ -228,3 +228,19 @@ def test_ragged_verifier_matches_model(field):
         else:
             with pytest.raises(orc.OracleError):
                 orc.sumcheck_verify_partial_lengths(field, orc.from_int(field, claimed), arrs)
+
+
+def test_vector_helpers_match_big_ints():
+    """orc.sum_elems (iter().sum::<F>(), prover.rs:53-54) and the batched from_ints / to_ints against Python big ints"""
+    import random
+
+    for field in (0, 1, 2):
+        p = orc.modulus(field)
+        rng = random.Random(4400 + field)
+        vs = [rng.randrange(-p, 2 * p) for _ in range(777)] + [0, 1, p - 1, p, -1]
+        a = orc.from_ints(field, vs)
+        assert np.array_equal(a, np.stack([orc.from_int(field, v) for v in vs]))
+        assert orc.to_ints(field, a) == [v % p for v in vs]
+        assert orc.to_int(field, orc.sum_elems(field, a)) == sum(vs) % p
+        assert orc.to_int(field, orc.sum_elems(field, a[:0])) == 0
+        assert orc.from_ints(field, []).shape == (0, 4) and orc.to_ints(field, np.zeros((0, 4), dtype=np.uint64)) == []
