@@ -56,7 +56,7 @@ const ZK_ERR_VERIFY_SUM: i32 = -9;
 const ZK_ERR_GKR_REJECT: i32 = -27;
 
 /// The ABI revision this file was written against (`ZK_AMD_ABI_VERSION` in include/zk_amd.h); checked once per context.
-const ZK_AMD_ABI_VERSION: i32 = 5;
+const ZK_AMD_ABI_VERSION: i32 = 6;
 
 extern "C" {
     fn zk_abi_version() -> i32;

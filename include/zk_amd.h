@@ -29,9 +29,10 @@
 extern "C" {
 #endif
 
-#define ZK_AMD_ABI_VERSION 5   /* 3: + zk_comm (RCCL / host), zk_shard_prover_run, zk_ntt_sharded, sample_n, zk_ctx_trim, zk_mle_equal
+#define ZK_AMD_ABI_VERSION 6   /* 3: + zk_comm (RCCL / host), zk_shard_prover_run, zk_ntt_sharded, sample_n, zk_ctx_trim, zk_mle_equal
                                   4: + zk_sumcheck_verify_lengths / _verify_partial_lengths (per-round degrees, verifier.rs:55-58)
-                                  5: + zk_comm_info, zk_bench_evaluate_device */
+                                  5: + zk_comm_info, zk_bench_evaluate_device
+                                  6: + zk_sumcheck_prove_batch, zk_batch_last_stats */
 
 typedef enum zk_field {
     ZK_FIELD_BN254_FR = 0,     /* north-star field (not a dependency of the reference: SURVEY D2) */
@@ -162,6 +163,20 @@ int32_t zk_keccak256(const uint8_t *data, size_t len, uint8_t out[32]);
 int32_t zk_sumcheck_prove(zk_ctx *ctx, zk_mle *const *factors, uint64_t k, uint32_t max_var_degree,
                           const uint64_t sum[4], int32_t absorb_table, int32_t consume,
                           uint64_t *out_round_polys, uint64_t *out_challenges);
+/* n_proofs INDEPENDENT ::prove_partial calls (prover.rs:24-30: one per ProductPoly; the reference's callers -- a GKR prover's layers,
+ * SURVEY 8d config 4 -- simply call it n_proofs times) of ONE shape (k factors, max_var_degree) and ONE size, proved side by side:
+ * each proof keeps its own transcript and is bit-identical to what zk_sumcheck_prove(absorb_table = 0) returns for the same inputs,
+ * but every round of all proofs is ONE kernel launch (up to 8 proofs per launch; larger batches run in groups), so the per-round
+ * latency chain is paid once per group instead of once per proof.
+ * factors: n_proofs * k handles, proof after proof; sums: n_proofs * 4 u64; out_round_polys: n_proofs * n_vars * (max_var_degree+1)
+ * elements; out_challenges: n_proofs * n_vars elements (proof-major).  consume as in zk_sumcheck_prove (a handle listed twice
+ * anywhere in the batch is proved out of place).  Errors: those of zk_sumcheck_prove; proofs of different n_vars ->
+ * ZK_ERR_ARITY_MISMATCH. */
+int32_t zk_sumcheck_prove_batch(zk_ctx *ctx, uint64_t n_proofs, zk_mle *const *factors, uint64_t k, uint32_t max_var_degree,
+                                const uint64_t *sums, int32_t consume, uint64_t *out_round_polys, uint64_t *out_challenges);
+/* what the calling thread's last zk_sumcheck_prove_batch did: launches issued once for all proofs of a group (merged) / launches
+ * issued proof by proof because the kernel has no batched form for that shape (replayed).  Diagnostics only. */
+int32_t zk_batch_last_stats(uint64_t *out_merged, uint64_t *out_replayed);
 /* value-semantics form: k host tables of 2^n_vars elements each */
 int32_t zk_sumcheck_prove_host(zk_ctx *ctx, const uint64_t *const *tables, uint64_t k, uint64_t n_vars,
                                uint32_t max_var_degree, const uint64_t sum[4], int32_t absorb_table,

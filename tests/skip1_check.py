@@ -46,13 +46,21 @@ def main():
         for k, D in KD:
             for n in SIZES:
                 tabs = oracle_cache.sumcheck_tables(field, k, n, SEED + 10 * k)
+                both = []
                 for wrong in (0, 5):   # a WRONG claimed sum too: the SKIP1 identity is about the prover's own sums
                     _, s, want_rp, want_ch = oracle_cache.sumcheck_case(field, k, D, n, SEED + 10 * k, wrong, tabs=tabs)
                     pp = ProductPoly.new([MLE.new(ctx, n, t) for t in tabs])
                     proof, ch = SumcheckProver(D).prove_partial(pp, s)
                     assert np.array_equal(proof.round_polys, want_rp), (field, k, D, n, wrong)
                     assert np.array_equal(ch, want_ch), (field, k, D, n, wrong)
+                    both.append((pp, s, want_rp, want_ch))
                     checked += 1
+                # the same two proofs (+ a third on the first one's handles) side by side: zk_sumcheck_prove_batch under the same
+                # forced kernel selection -- the batched twins of whatever kernels the switches picked
+                got = SumcheckProver(D).prove_partial_batch([both[0][0], both[1][0], both[0][0]], [both[0][1], both[1][1], both[0][1]])
+                for (proof, ch), (_, _, want_rp, want_ch) in zip(got, both + both[:1]):
+                    assert np.array_equal(proof.round_polys, want_rp) and np.array_equal(ch, want_ch), ("batch", field, k, D, n)
+                checked += 1
         # the two-term GKR layer shape (A.B + C) through the merged kernel, against the big-int definition (oracle/gkr_ref.py)
         for n in (3, 8, 12) + tuple(x for x in SIZES if x > 12):
             tabs, s, want_rp, want_ch, want_fin = oracle_cache.terms_case(field, n)

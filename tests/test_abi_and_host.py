@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 50
     missing = [n for n in names if not hasattr(_lib.lib, n)]
     assert missing == []
-    assert _lib.lib.zk_abi_version() == 5
+    assert _lib.lib.zk_abi_version() == 6
 
 
 def test_every_declared_symbol_has_a_python_signature():

@@ -116,6 +116,8 @@ _sig = {
     "zk_transcript_sample_challenge": [c.c_void_p, c.c_char_p],
     "zk_keccak256": [c.c_char_p, c.c_size_t, c.c_char_p],
     "zk_sumcheck_prove": [c.c_void_p, vpp, c.c_uint64, c.c_uint32, u64p, c.c_int32, c.c_int32, u64p, u64p],
+    "zk_sumcheck_prove_batch": [c.c_void_p, c.c_uint64, vpp, c.c_uint64, c.c_uint32, u64p, c.c_int32, u64p, u64p],
+    "zk_batch_last_stats": [u64p, u64p],
     "zk_sumcheck_prove_host": [c.c_void_p, c.POINTER(u64p), c.c_uint64, c.c_uint64, c.c_uint32, u64p, c.c_int32, u64p, u64p],
     "zk_shard_prover_create": [c.c_void_p, vpp, c.c_uint64, c.c_uint32, u64p, c.c_uint32, vpp],
     "zk_shard_prover_destroy": [c.c_void_p],

@@ -421,6 +421,24 @@ class SumcheckProver:
         check(lib.zk_sumcheck_prove(poly.ctx._h, hp, k, D, _p(s), int(absorb), int(consume), _p(rp), _p(ch)))
         return SumcheckProof(s.reshape(4).copy(), rp), ch
 
+    def prove_partial_batch(self, polys, sums, consume=False):
+        """len(polys) independent prove_partial calls (prover.rs:24-30), one ProductPoly each, same number of factors and variables,
+        proved side by side (zk_sumcheck_prove_batch: one launch per round for all proofs).  Returns [(SumcheckProof, challenges)], each
+        pair equal to what prove_partial(poly, sum) returns."""
+        polys = list(polys)
+        if not polys:
+            return []
+        D, n, k = self.max_var_degree, polys[0].n_vars(), len(polys[0].polynomials)
+        if any(len(q.polynomials) != k for q in polys):
+            raise ValueError("prove_partial_batch: every ProductPoly must have the same number of factors")
+        B = len(polys)
+        s = _elems(sums, B)
+        rp = np.zeros((B, n, D + 1, 4), dtype=np.uint64)
+        ch = np.zeros((B, n, 4), dtype=np.uint64)
+        hp, keep = _handles([f for q in polys for f in q.polynomials])
+        check(lib.zk_sumcheck_prove_batch(polys[0].ctx._h, B, hp, k, D, _p(s), int(consume), _p(rp), _p(ch)))
+        return [(SumcheckProof(s[b].copy(), rp[b]), ch[b]) for b in range(B)]
+
     def prove(self, poly, sum_, consume=False):  # prover.rs:15-20
         return self._run(poly, sum_, True, consume)[0]
 
@@ -493,6 +511,13 @@ def ntt(ctx, vec_in, vec_out, inverse=False):
     return vec_out
 
 
+def batch_last_stats():
+    """(launches merged for all proofs, launches replayed proof by proof) of this thread's last prove_partial_batch"""
+    a, b = c.c_uint64(), c.c_uint64()
+    check(lib.zk_batch_last_stats(c.byref(a), c.byref(b)))
+    return a.value, b.value
+
+
 def bench_prove_partial(poly, max_var_degree, sum_, reps=10):
     """per-call wall clock (ms) of `reps` prove_partial calls measured inside the library with std::chrono (what a compiled host
     sees: no binding overhead)"""
@@ -527,6 +552,6 @@ def bench_ntt(ctx, vec_in, vec_out, inverse=False, reps=5):
 
 __all__ = [
     "BN254_FR", "BLS12_381_FR", "BLS12_377_FR", "Context", "MultiLinearPolynomial", "CoeffMultilinearPolynomial", "ProductPoly", "SumcheckProof",
-    "SubClaim", "SumcheckProver", "SumcheckVerifier", "Transcript", "ZkError", "fft", "ifft", "fft_internal", "ntt", "bench_ntt", "bench_prove_partial", "bench_evaluate", "bench_evaluate_device",
+    "SubClaim", "SumcheckProver", "SumcheckVerifier", "Transcript", "ZkError", "fft", "ifft", "fft_internal", "ntt", "bench_ntt", "bench_prove_partial", "batch_last_stats", "bench_evaluate", "bench_evaluate_device",
     "fe_from_int", "fe_from_ints", "fe_to_int", "fe_to_ints", "keccak256", "modulus", "two_adicity", "root_of_unity", "mask", "index_pair",
 ]

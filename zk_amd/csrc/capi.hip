@@ -123,8 +123,8 @@ static inline uint32_t next_flag_seq(zk_ctx *c) {
     if (++c->flag_seq == 0) ++c->flag_seq;
     return c->flag_seq;
 }
-static int32_t host_flag_wait(zk_ctx *c, uint32_t seq) {
-    volatile uint32_t *flag = c->h_flag;
+static int32_t host_flag_wait(zk_ctx *c, uint32_t seq, uint32_t slot = 0) {
+    volatile uint32_t *flag = c->h_flag + 16 * slot;
     for (uint32_t spins = 1;; ++spins) {
         if (*flag == seq) break;
         if ((spins & 0x3FFF) == 0) {
@@ -346,8 +346,8 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     // completion word + result staging are POLLED by the host while the kernel that writes them is still running: ask for
     // coherent (fine-grained) mapped memory explicitly instead of relying on HIP_HOST_COHERENT's default
     HIPCHK(hipHostMalloc(&c->h_pinned, (size_t)kMaxSums * 32 * 3, kPolledHostFlags));
-    HIPCHK(hipHostMalloc((void **)&c->h_flag, 64, kPolledHostFlags));
-    *c->h_flag = 0;
+    HIPCHK(hipHostMalloc((void **)&c->h_flag, 64 * kMaxBatch, kPolledHostFlags));   // one 64-byte line per proof of a batch (slot 0: every other call)
+    memset(c->h_flag, 0, 64 * kMaxBatch);
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
     *out = c;
@@ -1173,9 +1173,26 @@ static int32_t results_staging(zk_ctx *c, size_t bytes, uint8_t **out) {
     return ZK_OK;
 }
 
+// the block partials of a round: the context's buffer -- inside a batch (launch.hpp BatchRecorder) each proof has its own eighth of it
+static inline uint64_t partials_capacity() { return g_batch ? (uint64_t)kMaxGrid * kMaxSums / kMaxBatch : (uint64_t)kMaxGrid * kMaxSums; }
+static inline uint64_t *partials_of(zk_ctx *c) { return g_batch ? c->d_partials + (size_t)g_batch->cur * partials_capacity() * 4 : c->d_partials; }
 static inline RoundLaunchCtx launch_ctx(zk_ctx *c) {
-    RoundLaunchCtx lc = {c->stream, &c->fi->P, c->d_partials, (uint64_t)kMaxGrid * kMaxSums, {}};
+    RoundLaunchCtx lc = {c->stream, &c->fi->P, partials_of(c), partials_capacity(), {}};
     return lc;
+}
+// k_round_tail on the current proof's partials: launched, or recorded for the batch's merged launch (one transcript block per proof)
+static int32_t launch_tail(zk_ctx *c, uint32_t nblocks, uint32_t ns, WordSponge *sponge, uint64_t *out_rp, uint64_t *out_ch, uint64_t *d_challenge,
+                           uint64_t *lanes, const TailDerive &dv) {
+    const uint64_t *part = partials_of(c);
+    hipStream_t st = c->stream;
+    const FieldParams *P = &c->fi->P;
+    auto single = [=]() {
+        k_round_tail<<<1, kBlock, 0, st>>>(part, nblocks, ns, sponge, out_rp, out_ch, d_challenge, lanes, *P, dv);
+        return hipGetLastError();
+    };
+    if (!lanes && batch_record(BK_TAIL, 0, 1, kBlock, 0, nblocks, ns, 0, 0, TailSlot{part, sponge, out_rp, out_ch, d_challenge, dv}, single)) return ZK_OK;
+    HIPCHK(single());
+    return ZK_OK;
 }
 // ZK_CLAIM_IN_ROUND=0: the tails evaluate the SKIP1 claim themselves (round 4's behaviour; A/B)
 static bool claim_in_round() {
@@ -1273,10 +1290,7 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
                     defer->lead = lead;
                     return ZK_OK;
                 }
-                k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, g, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
-                                                          tt.lanes, P, tail_dv());
-                HIPCHK(hipGetLastError());
-                return ZK_OK;
+                return launch_tail(c, g, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge, tt.lanes, tail_dv());
             }
         }
         if (ts.n_terms != 1) {
@@ -1309,10 +1323,7 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
             defer->lead = lead;
             return ZK_OK;
         }
-        k_round_tail<<<1, kBlock, 0, c->stream>>>(c->d_partials, total, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge,
-                                                  tt.lanes, P, tail_dv());
-        HIPCHK(hipGetLastError());
-        return ZK_OK;
+        return launch_tail(c, total, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge, tt.lanes, tail_dv());
     }
     if (ts.n_terms != 1) return ZK_ERR_UNSUPPORTED;
     const int k = ts.term_k[0];
@@ -1768,7 +1779,7 @@ static int32_t pipe_enter(RoundState &st, const DeferredTail &dt) {
     pl.chal_fold = nullptr;
     pl.e_partials = epart_of_round(st, st.round + 1);
     pl.done_counter = epart_counter(st, st.round + 1);
-    pl.tail = pipe_tail_args(st, 0, c->d_partials, dt.blocks, st.D + 1);
+    pl.tail = pipe_tail_args(st, 0, partials_of(c), dt.blocks, st.D + 1);
     if (dt.skip1) {
         pl.tail.dv = st.dv;
         pl.tail.dv.prev_rp = pl.tail.out_rp - (size_t)(st.D + 1) * 4;
@@ -1846,8 +1857,14 @@ static int32_t launch_finish(zk_ctx *c, const FactorPtrs &fp, uint32_t m_in, int
     const uint32_t m = pending ? m_in - 1 : m_in;
     const size_t lds = (size_t)K * ((size_t)32 << m) + (kBlock / 64) * (D + 1) * 32 + (D + 1) * 32 + 48;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_finish<K, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_finish<K, D><<<1, kBlock, lds, c->stream>>>(fp, m_in, pending, c->fi->P, d_challenge, sp, out_rp, out_ch, out_final);
-    HIPCHK(hipGetLastError());
+    hipStream_t st = c->stream;
+    const FieldParams *P = &c->fi->P;
+    auto single = [=]() {
+        k_finish<K, D><<<1, kBlock, lds, st>>>(fp, m_in, pending, *P, d_challenge, sp, out_rp, out_ch, out_final);
+        return hipGetLastError();
+    };
+    if (batch_record_other(single)) return ZK_OK;   // (no batched twin: a batch replays the classic finisher proof by proof)
+    HIPCHK(single());
     return ZK_OK;
 }
 static bool finish_shape_ok(uint64_t k, uint32_t D) {
@@ -1939,8 +1956,14 @@ static int32_t prover_step(RoundState &st, bool *finished_in_kernel) {
 static int32_t sponge_to_device(zk_ctx *c, const Sponge &host, WordSponge *d_sponge, uint64_t *d_epart) {
     WordSponge w;
     if (!w.from_byte_sponge(host)) return ZK_ERR_BAD_ARG;
-    k_store_sponge<<<1, 64, 0, c->stream>>>(w, d_sponge, d_epart ? epart_counters(d_epart) : nullptr);
-    HIPCHK(hipGetLastError());
+    uint64_t *zero2 = d_epart ? epart_counters(d_epart) : nullptr;
+    hipStream_t st = c->stream;
+    auto single = [=]() {
+        k_store_sponge<<<1, 64, 0, st>>>(w, d_sponge, zero2);
+        return hipGetLastError();
+    };
+    if (batch_record(BK_STORE_SPONGE, 0, 1, 64, 0, 0, 0, 0, 0, SpongeSlot{w, d_sponge, zero2}, single)) return ZK_OK;
+    HIPCHK(single());
     return ZK_OK;
 }
 
@@ -2097,6 +2120,205 @@ extern "C" int32_t zk_sumcheck_prove_host(zk_ctx *c, const uint64_t *const *tabl
     if (rc == ZK_OK) rc = zk_sumcheck_prove(c, h, k, D, sum, absorb_table, 1, out_rp, out_ch);
     for (uint64_t i = 0; i < k; ++i) (void)zk_mle_free(c, h[i]);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// B independent proofs in ONE launch sequence (config 4 as SURVEY 8d words it: "8 independent layers x (k = 3, n = 20)")
+// ------------------------------------------------------------------------------------------------------------
+// n_proofs separate prove_partial calls (prover.rs:24-30: one per ProductPoly; nothing in the reference orders independent calls) of
+// one shape (k, D) and one size, each with its own transcript, proved side by side: the host schedule of a proof runs once per proof
+// with a recorder installed (launch.hpp), and launch i of all proofs is issued as one launch of the kernel's batched twin -- the B
+// transcript steps of a round run next to each other instead of one after the other, and the number of launches does not grow with B.
+// Every proof is bit-identical to the one zk_sumcheck_prove returns for the same inputs (same kernels' bodies, same arithmetic).
+static thread_local uint64_t g_batch_merged = 0, g_batch_replayed = 0;
+static int32_t batch_flush(zk_ctx *c, BatchRecorder &r) {
+    int32_t rc = ZK_OK;
+    const size_t len = r.recs[0].size();
+    bool same_len = true;
+    for (int b = 1; b < r.n; ++b) same_len = same_len && r.recs[b].size() == len;
+    auto replay = [&](int b, size_t i) {
+        if (rc == ZK_OK && r.recs[b][i].single() != hipSuccess) {
+            g_hip_err = "batched prover: a replayed launch failed";
+            rc = ZK_ERR_HIP;
+        }
+        ++r.replayed;
+    };
+    if (!same_len) {   // cannot happen for proofs of one shape and size; proofs are independent, so proof-by-proof order is valid too
+        for (int b = 0; b < r.n; ++b)
+            for (size_t i = 0; i < r.recs[b].size(); ++i) replay(b, i);
+    } else {
+        for (size_t i = 0; i < len && rc == ZK_OK; ++i) {
+            const BatchRecord &r0 = r.recs[0][i];
+            bool same = r0.kernel != BK_OTHER;
+            for (int b = 1; b < r.n && same; ++b) {
+                const BatchRecord &x = r.recs[b][i];
+                same = x.kernel == r0.kernel && x.shape == r0.shape && x.grid == r0.grid && x.block == r0.block && x.lds == r0.lds &&
+                       memcmp(x.s, r0.s, sizeof r0.s) == 0;
+            }
+            int lrc = kLaunchUnsupported;
+            if (same) {
+                const dim3 grid(r0.grid, (uint32_t)r.n);
+                if (r0.kernel == BK_STORE_SPONGE) {
+                    BatchOf<SpongeSlot> slots;
+                    batch_gather(r, i, slots);
+                    k_store_sponge_b<<<grid, r0.block, 0, r.stream>>>(slots);
+                    lrc = hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchHipError;
+                } else if (r0.kernel == BK_TAIL) {
+                    BatchOf<TailSlot> slots;
+                    batch_gather(r, i, slots);
+                    k_round_tail_b<<<grid, r0.block, 0, r.stream>>>(slots, (uint32_t)r0.s[0], (uint32_t)r0.s[1], *r.P);
+                    lrc = hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchHipError;
+                } else if (r0.kernel == BK_PIPE || r0.kernel == BK_FINISH_PIPE) {
+                    lrc = batch_launch_pipe(r, i);
+                } else {
+                    lrc = batch_launch_rounds(r, i);
+                }
+            }
+            if (lrc == kLaunchOk) {
+                ++r.merged;
+            } else if (lrc == kLaunchHipError) {
+                g_hip_err = "batched prover: a merged launch failed";
+                rc = ZK_ERR_HIP;
+            } else {
+                for (int b = 0; b < r.n; ++b) replay(b, i);
+            }
+        }
+    }
+    for (int b = 0; b < r.n; ++b) r.recs[b].clear();
+    (void)c;
+    return rc;
+}
+// up to kMaxBatch proofs; f = B * k handles (proof-major), sums = B * 4 words, outputs proof-major
+static int32_t prove_batch_group(zk_ctx *c, int B, zk_mle *const *f, uint64_t k, uint32_t D, const uint64_t *sums, int32_t consume, uint64_t *out_rp,
+                                 uint64_t *out_ch) {
+    const uint64_t n = f[0]->n_vars;
+    const size_t rp_words = (size_t)n * (D + 1) * 4, ch_words = (size_t)n * 4;
+    if (B == 1 || n == 0 || !fast_degree(D)) {   // nothing to merge, or a degree whose rounds go through context-wide scratch: one by one
+        for (int b = 0; b < B; ++b)
+            ZKCHK(prove_core(c, f + (size_t)b * k, k, single_term((int)k), D, sums + 4 * b, 0, consume, out_rp + b * rp_words, out_ch + b * ch_words, nullptr));
+        return ZK_OK;
+    }
+    const FieldParams &P = c->fi->P;
+    BatchRecorder rec;
+    rec.n = B;
+    rec.stream = c->stream;
+    rec.P = &P;
+    struct Guard {   // the recorder is installed for this thread only while the schedule runs
+        explicit Guard(BatchRecorder *r) { g_batch = r; }
+        ~Guard() { g_batch = nullptr; }
+    };
+    std::vector<RoundState> st((size_t)B);
+    int inited = 0;
+    int32_t rc = ZK_OK;
+    uint32_t seq[kMaxBatch] = {};
+    uint8_t *stage = nullptr;
+    size_t block = 0;
+    static const bool publish_in_finisher = env_u64("ZK_PUBLISH_IN_FINISHER", 1, 0, 1) != 0;
+    {
+        Guard guard(&rec);
+        for (int b = 0; b < B && rc == ZK_OK; ++b) {
+            rec.cur = b;
+            rc = round_state_init(st[(size_t)b], c, f + (size_t)b * k, k, D, consume != 0, n);
+            if (rc == ZK_OK) ++inited;
+        }
+        if (rc == ZK_OK) {
+            block = (st[0].ps.rp_bytes + st[0].ps.ch_bytes + kMaxFactors * 32 + 63) & ~(size_t)63;
+            rc = results_staging(c, block * (size_t)B, &stage);
+        }
+        for (int b = 0; b < B && rc == ZK_OK; ++b) {
+            rec.cur = b;
+            RoundState &s = st[(size_t)b];
+            s.terms = single_term((int)k);
+            Sponge sp;
+            sp.init();                                        // Transcript::new (prover.rs:28)
+            absorb_elements(sp, sums + 4 * b, 1, P);          // prover.rs:42
+            rc = sponge_to_device(c, sp, s.ps.d_sponge, s.ps.d_epart);
+            seq[b] = next_flag_seq(c);
+            if (publish_in_finisher)
+                s.pub = FinishPublish{s.ps.d_rp, reinterpret_cast<uint64_t *>(stage + block * (size_t)b), (uint32_t)(block / 8), c->h_flag + 16 * b, seq[b]};
+        }
+        if (rc == ZK_OK) rc = batch_flush(c, rec);
+        while (rc == ZK_OK && st[0].round < n) {              // prover.rs:44-68: one step of every proof, then the merged launches
+            for (int b = 0; b < B && rc == ZK_OK; ++b) {
+                rec.cur = b;
+                bool fin = false;
+                rc = prover_step(st[(size_t)b], &fin);
+            }
+            if (rc == ZK_OK) rc = batch_flush(c, rec);
+        }
+        for (int b = 0; b < B && rc == ZK_OK; ++b) {
+            rec.cur = b;
+            RoundState &s = st[(size_t)b];
+            if (s.round != n) rc = ZK_ERR_BAD_ARG;            // (the proofs must have advanced in lockstep)
+            if (rc == ZK_OK && !s.published) {
+                const uint64_t *src = s.ps.d_rp;
+                uint64_t *dst = reinterpret_cast<uint64_t *>(stage + block * (size_t)b);
+                const uint32_t words = (uint32_t)((s.ps.rp_bytes + s.ps.ch_bytes + kMaxFactors * 32) / 8);
+                volatile uint32_t *flag = c->h_flag + 16 * b;
+                const uint32_t sq = seq[b];
+                hipStream_t stream = c->stream;
+                (void)batch_record_other([=]() {
+                    k_publish_host<<<1, 64, 0, stream>>>(src, dst, words, flag, sq);
+                    return hipGetLastError();
+                });
+            }
+        }
+        if (rc == ZK_OK) rc = batch_flush(c, rec);
+    }
+    g_batch_merged = rec.merged;
+    g_batch_replayed = rec.replayed;
+    for (int b = 0; b < B; ++b) {
+        if (rc == ZK_OK) rc = host_flag_wait(c, seq[b], (uint32_t)b);
+    }
+    if (rc != ZK_OK) (void)stream_wait(c->stream);
+    if (rc == ZK_OK) {
+        for (int b = 0; b < B; ++b) {
+            const uint8_t *src = stage + block * (size_t)b;
+            memcpy(out_rp + b * rp_words, src, rp_words * 8);
+            memcpy(out_ch + b * ch_words, src + st[(size_t)b].ps.rp_bytes, ch_words * 8);
+        }
+    }
+    for (int b = 0; b < inited; ++b) round_state_release(st[(size_t)b]);
+    return rc;
+}
+extern "C" int32_t zk_sumcheck_prove_batch(zk_ctx *c, uint64_t n_proofs, zk_mle *const *f, uint64_t k, uint32_t D, const uint64_t *sums, int32_t consume,
+                                           uint64_t *out_rp, uint64_t *out_ch) {
+    if (!c || !f || !sums) return ZK_ERR_BAD_ARG;
+    if (n_proofs == 0) return ZK_OK;
+    if (k == 0) return ZK_ERR_EMPTY_PRODUCT;
+    if (k > (uint64_t)kMaxFactors || D >= kMaxSums) return ZK_ERR_UNSUPPORTED;
+    for (uint64_t p = 0; p < n_proofs; ++p) {
+        ZKCHK(product_args(c, (const zk_mle *const *)(f + p * k), k));          // each proof: ProductPoly::new's checks (product_poly.rs:14-32)
+        if (f[p * k]->n_vars != f[0]->n_vars) return ZK_ERR_ARITY_MISMATCH;      // a batch is one size
+    }
+    const uint64_t n = f[0]->n_vars;
+    if (n && (!out_rp || !out_ch)) return ZK_ERR_BAD_ARG;
+    // in-place folds need every table to be its proof's own: a handle listed twice (inside a proof, or by two proofs) -> out of place
+    if (consume) {
+        std::set<const zk_mle *> seen;
+        for (uint64_t i = 0; i < n_proofs * k && consume; ++i)
+            if (!seen.insert(f[i]).second) consume = 0;
+    }
+    g_batch_merged = g_batch_replayed = 0;
+    uint64_t merged = 0, replayed = 0;
+    const size_t rp_words = (size_t)n * (D + 1) * 4, ch_words = (size_t)n * 4;
+    for (uint64_t p0 = 0; p0 < n_proofs; p0 += kMaxBatch) {
+        const int B = (int)std::min<uint64_t>(kMaxBatch, n_proofs - p0);
+        ZKCHK(prove_batch_group(c, B, f + p0 * k, k, D, sums + 4 * p0, consume, out_rp ? out_rp + p0 * rp_words : nullptr,
+                                out_ch ? out_ch + p0 * ch_words : nullptr));
+        merged += g_batch_merged;
+        replayed += g_batch_replayed;
+    }
+    g_batch_merged = merged;
+    g_batch_replayed = replayed;
+    return ZK_OK;
+}
+// what the last zk_sumcheck_prove_batch of this thread did: launches issued for all proofs at once / replayed proof by proof
+extern "C" int32_t zk_batch_last_stats(uint64_t *out_merged, uint64_t *out_replayed) {
+    if (!out_merged || !out_replayed) return ZK_ERR_BAD_ARG;
+    *out_merged = g_batch_merged;
+    *out_replayed = g_batch_replayed;
+    return ZK_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -12,6 +12,29 @@ struct FactorPtrs {
     uint64_t *out[kMaxFactors];
 };
 
+// ---- batched launches (zk_sumcheck_prove_batch): ONE launch per round for up to kMaxBatch independent proofs of the same shape and
+// size.  blockIdx.y selects the proof; its pointers come from slot blockIdx.y of an argument array passed by value (kernarg), every
+// other argument (sizes, field, grid) is shared.  The per-proof kernel bodies are the single-proof kernels' own bodies.
+constexpr int kMaxBatch = 8;
+template <class Slot>
+struct BatchOf {
+    Slot a[kMaxBatch];
+};
+struct FactorPtrs4 {   // the batched shapes have at most four tables per proof (keeps the slot arrays small)
+    const uint64_t *in[4];
+    uint64_t *out[4];
+};
+ZK_HD FactorPtrs4 factor_ptrs4(const FactorPtrs &f) {
+    FactorPtrs4 r;
+    for (int i = 0; i < 4; ++i) r.in[i] = f.in[i], r.out[i] = f.out[i];
+    return r;
+}
+ZK_HD FactorPtrs factor_ptrs_of(const FactorPtrs4 &f) {
+    FactorPtrs r = {};
+    for (int i = 0; i < 4; ++i) r.in[i] = f.in[i], r.out[i] = f.out[i];
+    return r;
+}
+
 // Challenge record in device memory (written by the on-device transcript): 8 words of r (Montgomery form), the 9 words of
 // its prepared multiplier form (Mul29 of r: what folds multiply by), and the 9 words of the prepared form of the CANONICAL
 // challenge (Mul29 of r * R^-1: a Montgomery-form value times it is a canonical product -- the pipelined rounds close with

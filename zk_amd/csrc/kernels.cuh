@@ -391,10 +391,9 @@ __global__ __launch_bounds__(kBlock) void k_prod_reduce(FactorPtrs fp, int k, ui
 //   lanes    != null : store them as 8 zero-extended 32-bit digits per element (uint64 lanes) for the cross-GPU
 //                      all-reduce (RCCL has no mod-p sum; integer lane sums cannot overflow);
 //   sponge   != null : run the transcript step and publish the challenge.
-__global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restrict__ partials, uint32_t nblocks, uint32_t ns,
-                                                       WordSponge *__restrict__ sponge, uint64_t *__restrict__ out_rp,
-                                                       uint64_t *__restrict__ out_ch, uint64_t *__restrict__ d_challenge,
-                                                       uint64_t *__restrict__ lanes, FieldParams P, TailDerive dv = {}) {
+ZK_D void round_tail_body(const uint64_t *__restrict__ partials, uint32_t nblocks, uint32_t ns, WordSponge *__restrict__ sponge,
+                          uint64_t *__restrict__ out_rp, uint64_t *__restrict__ out_ch, uint64_t *__restrict__ d_challenge,
+                          uint64_t *__restrict__ lanes, const FieldParams &P, const TailDerive &dv) {
     __shared__ Fe fin[256];
     __shared__ Fe claim;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -470,6 +469,23 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
         publish_challenge_forms(d_challenge, out_ch, ch, ch29, (uint32_t)lane);
         lane_sponge_store(sponge, sp, L);
     }
+}
+__global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restrict__ partials, uint32_t nblocks, uint32_t ns,
+                                                       WordSponge *__restrict__ sponge, uint64_t *__restrict__ out_rp,
+                                                       uint64_t *__restrict__ out_ch, uint64_t *__restrict__ d_challenge,
+                                                       uint64_t *__restrict__ lanes, FieldParams P, TailDerive dv = {}) {
+    round_tail_body(partials, nblocks, ns, sponge, out_rp, out_ch, d_challenge, lanes, P, dv);
+}
+// batched form (zk_sumcheck_prove_batch): grid (1, proofs), the B transcript steps of a round side by side
+struct TailSlot {
+    const uint64_t *partials;
+    WordSponge *sponge;
+    uint64_t *out_rp, *out_ch, *d_challenge;
+    TailDerive dv;
+};
+__global__ __launch_bounds__(kBlock) void k_round_tail_b(BatchOf<TailSlot> b, uint32_t nblocks, uint32_t ns, FieldParams P) {
+    const TailSlot &a = b.a[blockIdx.y];
+    round_tail_body(a.partials, nblocks, ns, a.sponge, a.out_rp, a.out_ch, a.d_challenge, nullptr, P, a.dv);
 }
 
 // ---- finisher: all remaining rounds of the prover in ONE launch, once the tables are small ---------------------------
@@ -802,13 +818,23 @@ __global__ __launch_bounds__(kBlock) void k_finish_terms(FactorPtrs fp, TermSpec
 // the prover's initial sponge state, passed by value in the kernel arguments
 // zero2 (optional): two uint64 words cleared by the same launch (the pipelined rounds' last-block-done counters: a 16-byte
 // hipMemsetAsync is a launch of its own on the stream)
-__global__ void k_store_sponge(WordSponge w, WordSponge *__restrict__ dst, uint64_t *__restrict__ zero2) {
+ZK_D void store_sponge_body(const WordSponge &w, WordSponge *__restrict__ dst, uint64_t *__restrict__ zero2) {
     if (threadIdx.x < 25) dst->s[threadIdx.x] = w.s[threadIdx.x];
     if (threadIdx.x == 0) {
         dst->pos = w.pos;
         dst->pad_ = 0;
     }
     if (zero2 && threadIdx.x >= 32 && threadIdx.x < 34) zero2[threadIdx.x - 32] = 0;
+}
+__global__ void k_store_sponge(WordSponge w, WordSponge *__restrict__ dst, uint64_t *__restrict__ zero2) { store_sponge_body(w, dst, zero2); }
+struct SpongeSlot {
+    WordSponge w;
+    WordSponge *dst;
+    uint64_t *zero2;
+};
+__global__ void k_store_sponge_b(BatchOf<SpongeSlot> b) {
+    const SpongeSlot &a = b.a[blockIdx.y];
+    store_sponge_body(a.w, a.dst, a.zero2);
 }
 
 // Sharded prover, after the all-reduce: lanes hold sums over ranks of 32-bit digits.  Carry-propagate, reduce mod p

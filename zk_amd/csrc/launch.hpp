@@ -3,9 +3,76 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstring>
+#include <functional>
+#include <type_traits>
+#include <vector>
+
 #include "common.cuh"
 
 namespace zk {
+
+// ---- batched proving (zk_sumcheck_prove_batch): record, then merge ------------------------------------------------------------------
+// The host schedule of a proof (capi.hip: prover_step and everything under it) decides kernel, grid and arguments per launch.  A batch
+// runs that SAME code once per proof with a recorder installed (thread-local): every launch site on the prover path hands its launch to
+// batch_record() instead of launching.  Proofs of one shape and size produce identical launch sequences that differ in their pointers
+// only, so launch i of all proofs becomes ONE launch of the kernel's batched twin (blockIdx.y = proof; the per-proof pointers travel as
+// an array of slots in the kernel arguments).  A step with no batched twin -- or whose shared arguments differ between proofs -- is
+// replayed proof by proof through the recorded single-proof closures: slower, never wrong.
+enum BatchKernel : int { BK_STORE_SPONGE = 1, BK_ROUND_KD, BK_ROUND0_DOT29, BK_ROUND_QUAD, BK_TAIL, BK_PIPE, BK_FINISH_PIPE, BK_OTHER };
+struct BatchRecord {
+    int kernel;
+    uint32_t shape;      // template selector of the kernel (its own encoding)
+    uint32_t grid, block;
+    size_t lds;
+    uint64_t s[4];       // arguments shared by the proofs (sizes, counts, flags): the merge requires them equal
+    std::function<hipError_t()> single;   // this proof's launch on its own
+    alignas(16) unsigned char slot[384];  // this proof's slot of the batched twin's argument array
+};
+struct BatchRecorder {
+    int n = 0;           // proofs in the batch
+    int cur = 0;         // proof being recorded
+    hipStream_t stream = nullptr;
+    const FieldParams *P = nullptr;
+    std::vector<BatchRecord> recs[kMaxBatch];
+    uint64_t merged = 0, replayed = 0;   // launches issued batched / proof by proof (reported by zk_sumcheck_prove_batch)
+};
+extern thread_local BatchRecorder *g_batch;
+template <class Slot, class F>
+inline bool batch_record(int kernel, uint32_t shape, uint32_t grid, uint32_t block, size_t lds, uint64_t s0, uint64_t s1, uint64_t s2, uint64_t s3,
+                         const Slot &slot, F &&single) {
+    BatchRecorder *r = g_batch;
+    if (!r) return false;
+    static_assert(sizeof(Slot) <= sizeof(BatchRecord::slot), "slot does not fit a batch record");
+    static_assert(std::is_trivially_copyable<Slot>::value, "slots are plain data");
+    r->recs[r->cur].emplace_back();
+    BatchRecord &rec = r->recs[r->cur].back();
+    rec.kernel = kernel;
+    rec.shape = shape;
+    rec.grid = grid;
+    rec.block = block;
+    rec.lds = lds;
+    rec.s[0] = s0, rec.s[1] = s1, rec.s[2] = s2, rec.s[3] = s3;
+    rec.single = std::function<hipError_t()>(std::forward<F>(single));
+    std::memcpy(rec.slot, &slot, sizeof(Slot));
+    return true;
+}
+// a launch with no batched twin: recorded for replay only
+template <class F>
+inline bool batch_record_other(F &&single) {
+    struct Nothing {
+        int x;
+    } none = {0};
+    return batch_record(BK_OTHER, 0, 0, 0, 0, 0, 0, 0, 0, none, std::forward<F>(single));
+}
+// the batched twins, one dispatcher per translation unit (kLaunchUnsupported: no twin for this shape -> replay)
+int batch_launch_rounds(const BatchRecorder &r, size_t idx);   // rounds.hip: BK_ROUND_KD, BK_ROUND0_DOT29, BK_ROUND_QUAD
+int batch_launch_pipe(const BatchRecorder &r, size_t idx);     // pipe.hip:   BK_PIPE, BK_FINISH_PIPE
+template <class Slot>
+inline void batch_gather(const BatchRecorder &r, size_t idx, BatchOf<Slot> &out) {
+    std::memset(&out, 0, sizeof out);
+    for (int b = 0; b < r.n; ++b) std::memcpy(&out.a[b], r.recs[b][idx].slot, sizeof(Slot));
+}
 
 struct RoundLaunchCtx {
     hipStream_t stream;

@@ -1,4 +1,5 @@
 // pipe.hip -- instantiations + launch logic of the pipelined rounds (pipe_kernels.cuh).
+#include <cstddef>
 #include <cstdlib>
 
 #include "launch.hpp"
@@ -43,13 +44,26 @@ uint32_t pipe_work_blocks(int k, uint32_t D, int extra, uint64_t q) {
 #define ZK_PIPE_SC1_HANDOFF 0
 #endif
 static constexpr int sc1_handoff() { return ZK_PIPE_SC1_HANDOFF; }
+constexpr uint32_t pipe_shape_id(int K, int D, int EXTRA, bool FOLD) { return (uint32_t)K | ((uint32_t)D << 4) | ((uint32_t)EXTRA << 8) | ((uint32_t)FOLD << 9); }
 template <int K, int D, int EXTRA>
 static void launch_shape(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t g) {
     constexpr int kThreads = pipe_block_threads<K, D, EXTRA>();
-    if (pl.fold)
-        k_round_pipe<K, D, EXTRA, true><<<g + 1, kThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail, sc1_handoff());
-    else
-        k_round_pipe<K, D, EXTRA, false><<<g + 1, kThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail, sc1_handoff());
+    const FieldParams *P = lc.P;
+    hipStream_t st = lc.stream;
+    const PipeLaunch l = pl;
+    auto single = [=]() {
+        if (l.fold)
+            k_round_pipe<K, D, EXTRA, true><<<g + 1, kThreads, 0, st>>>(fp, l.q, l.emit, *P, l.chal_fold, l.e_partials, l.done_counter, l.tail, sc1_handoff());
+        else
+            k_round_pipe<K, D, EXTRA, false><<<g + 1, kThreads, 0, st>>>(fp, l.q, l.emit, *P, l.chal_fold, l.e_partials, l.done_counter, l.tail, sc1_handoff());
+        return hipGetLastError();
+    };
+    // (the shared arguments of the batched twin: pairs, emit, and what the transcript blocks do -- mode, block count, values per block)
+    if (batch_record(BK_PIPE, pipe_shape_id(K, D, EXTRA, pl.fold), g + 1, kThreads, 0, pl.q, (uint64_t)pl.emit,
+                     ((uint64_t)(uint32_t)pl.tail.mode << 32) | pl.tail.nblocks, pl.tail.n_in,
+                     PipeSlot{factor_ptrs4(fp), pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail}, single))
+        return;
+    (void)single();
 }
 
 // k_round_mid: one pair index per quad and pass.  As many blocks as one pass needs, up to the cap (the launch ends with ONE block
@@ -62,10 +76,17 @@ static uint32_t mid_work_blocks(uint64_t q) {
 }
 template <int K, int D, int EXTRA>
 static void launch_mid_shape(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t g) {
-    if (pl.fold)
-        k_round_mid<K, D, EXTRA, true><<<g + 1, kMidThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail, pl.mid_total ? 1 : 0);
-    else
-        k_round_mid<K, D, EXTRA, false><<<g + 1, kMidThreads, 0, lc.stream>>>(fp, pl.q, pl.emit, *lc.P, pl.chal_fold, pl.e_partials, pl.done_counter, pl.tail, pl.mid_total ? 1 : 0);
+    const FieldParams *P = lc.P;
+    hipStream_t st = lc.stream;
+    const PipeLaunch l = pl;
+    auto single = [=]() {
+        if (l.fold)
+            k_round_mid<K, D, EXTRA, true><<<g + 1, kMidThreads, 0, st>>>(fp, l.q, l.emit, *P, l.chal_fold, l.e_partials, l.done_counter, l.tail, l.mid_total ? 1 : 0);
+        else
+            k_round_mid<K, D, EXTRA, false><<<g + 1, kMidThreads, 0, st>>>(fp, l.q, l.emit, *P, l.chal_fold, l.e_partials, l.done_counter, l.tail, l.mid_total ? 1 : 0);
+        return hipGetLastError();
+    };
+    if (!batch_record_other(single)) (void)single();   // (off by default; no batched twin)
 }
 static int launch_round_mid(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t *out_work_blocks) {
     if (pl.q > mid_max_pairs()) return kLaunchUnsupported;
@@ -107,14 +128,32 @@ int launch_round_pipe(const RoundLaunchCtx &lc, const FactorPtrs &fp, const Pipe
 size_t finish_pipe_lds_bytes(int k, int extra, uint32_t m_in) {
     return (size_t)(k + extra) * ((size_t)32 << (m_in - 1)) + kFinMiscBytes;
 }
+struct FinishRec {   // what a finisher launch records for a batch: its slot, then the (field-wide) constants the batched twin takes once
+    FinishSlot slot;
+    PipeConsts pc;
+};
 template <int K, int D, int EXTRA>
 static hipError_t launch_fin_shape(const RoundLaunchCtx &lc, const FactorPtrs &fp, const FinishPipeLaunch &fl) {
     const size_t lds = finish_pipe_lds_bytes(K, EXTRA, fl.m_in);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_finish_pipe<K, D, EXTRA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_finish_pipe<K, D, EXTRA><<<1, kFinishPipeThreads, lds, lc.stream>>>(fp, fl.m_in, fl.entry, fl.e_partials, fl.e_blocks, *lc.P, fl.pc, fl.chal_in,
-                                                                         fl.chal_last, fl.sponge, fl.out_rp, fl.out_ch, fl.out_final, fl.dbg, fl.pub);
-    return hipGetLastError();
+    const FieldParams *P = lc.P;
+    hipStream_t st = lc.stream;
+    const FinishPipeLaunch l = fl;
+    auto single = [=]() {
+        k_finish_pipe<K, D, EXTRA><<<1, kFinishPipeThreads, lds, st>>>(fp, l.m_in, l.entry, l.e_partials, l.e_blocks, *P, l.pc, l.chal_in, l.chal_last, l.sponge,
+                                                                      l.out_rp, l.out_ch, l.out_final, l.dbg, l.pub);
+        return hipGetLastError();
+    };
+    if (g_batch) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_finish_pipe_b<K, D, EXTRA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    if (batch_record(BK_FINISH_PIPE, pipe_shape_id(K, D, EXTRA, false), 1, kFinishPipeThreads, lds, fl.m_in, (uint64_t)fl.entry, fl.e_blocks, 0,
+                     FinishRec{FinishSlot{factor_ptrs4(fp), fl.e_partials, fl.chal_in, fl.chal_last, fl.sponge, fl.out_rp, fl.out_ch, fl.out_final, fl.pub}, fl.pc},
+                     single))
+        return hipSuccess;
+    return single();
 }
 int launch_finish_pipe(const RoundLaunchCtx &lc, const FactorPtrs &fp, const FinishPipeLaunch &fl) {
     if (!pipe_shape_ok(fl.k, fl.D, fl.extra) || fl.m_in < 3 || fl.m_in > (uint32_t)finish_pipe_vars(fl.k + fl.extra) + 1) return kLaunchUnsupported;
@@ -131,5 +170,40 @@ int launch_finish_pipe(const RoundLaunchCtx &lc, const FactorPtrs &fp, const Fin
     return e == hipSuccess ? kLaunchOk : kLaunchHipError;
 }
 uint32_t finish_pipe_max_vars(int n_factors) { return (uint32_t)finish_pipe_vars(n_factors); }
+
+// ---- batched twins (zk_sumcheck_prove_batch): grid (x, proofs); shapes (2, 2) and (3, 3) without an extra term ------------------------
+int batch_launch_pipe(const BatchRecorder &r, size_t idx) {
+    const BatchRecord &r0 = r.recs[0][idx];
+    const dim3 grid(r0.grid, (uint32_t)r.n);
+    const FieldParams &P = *r.P;
+    if (r0.kernel == BK_PIPE) {
+        BatchOf<PipeSlot> slots;
+        batch_gather(r, idx, slots);
+        const uint64_t q = r0.s[0];
+        const int emit = (int)r0.s[1];
+        switch (r0.shape) {
+            case pipe_shape_id(2, 2, 0, true): k_round_pipe_b<2, 2, 0, true><<<grid, r0.block, 0, r.stream>>>(slots, q, emit, P, sc1_handoff()); break;
+            case pipe_shape_id(2, 2, 0, false): k_round_pipe_b<2, 2, 0, false><<<grid, r0.block, 0, r.stream>>>(slots, q, emit, P, sc1_handoff()); break;
+            case pipe_shape_id(3, 3, 0, true): k_round_pipe_b<3, 3, 0, true><<<grid, r0.block, 0, r.stream>>>(slots, q, emit, P, sc1_handoff()); break;
+            case pipe_shape_id(3, 3, 0, false): k_round_pipe_b<3, 3, 0, false><<<grid, r0.block, 0, r.stream>>>(slots, q, emit, P, sc1_handoff()); break;
+            default: return kLaunchUnsupported;
+        }
+    } else if (r0.kernel == BK_FINISH_PIPE) {
+        BatchOf<FinishSlot> slots;
+        batch_gather(r, idx, slots);
+        PipeConsts pc;   // every proof's launch carried the same constants (one field per batch): proof 0's copy
+        std::memcpy(&pc, r0.slot + offsetof(FinishRec, pc), sizeof pc);
+        const uint32_t m_in = (uint32_t)r0.s[0], e_blocks = (uint32_t)r0.s[2];
+        const int entry = (int)r0.s[1];
+        switch (r0.shape) {
+            case pipe_shape_id(2, 2, 0, false): k_finish_pipe_b<2, 2, 0><<<grid, r0.block, r0.lds, r.stream>>>(slots, m_in, entry, e_blocks, P, pc); break;
+            case pipe_shape_id(3, 3, 0, false): k_finish_pipe_b<3, 3, 0><<<grid, r0.block, r0.lds, r.stream>>>(slots, m_in, entry, e_blocks, P, pc); break;
+            default: return kLaunchUnsupported;
+        }
+    } else {
+        return kLaunchUnsupported;
+    }
+    return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchHipError;
+}
 
 }  // namespace zk

@@ -456,10 +456,8 @@ constexpr int pipe_block_threads() {
     return kPipeThreads;   // one wave per SIMD: a work wave is a latency-bound chain, four of them on a SIMD run 4x slower each
 }
 template <int K, int D, int EXTRA, bool FOLD>
-__global__ __launch_bounds__((pipe_block_threads<K, D, EXTRA>())) void k_round_pipe(FactorPtrs fp, uint64_t q, int emit, FieldParams P,
-                                                                                  const uint64_t *__restrict__ chal_fold,
-                                                                                  uint64_t *__restrict__ e_partials, uint32_t *done_counter,
-                                                                                  PipeTailArgs ta, int sc1_handoff) {
+ZK_D void round_pipe_body(const FactorPtrs &fp, uint64_t q, int emit, const FieldParams &P, const uint64_t *__restrict__ chal_fold,
+                          uint64_t *__restrict__ e_partials, uint32_t *done_counter, const PipeTailArgs &ta, int sc1_handoff) {
     using S = PipeShape<K, D, EXTRA>;
     using C = HexCfg<K, D, EXTRA, false>;
     constexpr int kThreads = pipe_block_threads<K, D, EXTRA>(), kPipeRows = kThreads / 16, kWaves = kThreads / 64;
@@ -542,6 +540,28 @@ __global__ __launch_bounds__((pipe_block_threads<K, D, EXTRA>())) void k_round_p
     }
     if (threadIdx.x == 0) *done_counter = 0;   // ready for the next launch that uses this buffer
     if (threadIdx.x < 64) dbg_stamp(wdbg, 4);
+}
+template <int K, int D, int EXTRA, bool FOLD>
+__global__ __launch_bounds__((pipe_block_threads<K, D, EXTRA>())) void k_round_pipe(FactorPtrs fp, uint64_t q, int emit, FieldParams P,
+                                                                                  const uint64_t *__restrict__ chal_fold,
+                                                                                  uint64_t *__restrict__ e_partials, uint32_t *done_counter,
+                                                                                  PipeTailArgs ta, int sc1_handoff) {
+    round_pipe_body<K, D, EXTRA, FOLD>(fp, q, emit, P, chal_fold, e_partials, done_counter, ta, sc1_handoff);
+}
+// batched form (zk_sumcheck_prove_batch): grid (1 + work blocks, proofs) -- B transcript blocks and B sets of work blocks in one launch
+struct PipeSlot {
+    FactorPtrs4 fp;
+    const uint64_t *chal_fold;
+    uint64_t *e_partials;
+    uint32_t *done_counter;
+    PipeTailArgs ta;
+};
+template <int K, int D, int EXTRA, bool FOLD>
+__global__ __launch_bounds__((pipe_block_threads<K, D, EXTRA>())) void k_round_pipe_b(BatchOf<PipeSlot> b, uint64_t q, int emit, FieldParams P,
+                                                                                    int sc1_handoff) {
+    const PipeSlot &a = b.a[blockIdx.y];
+    const FactorPtrs fp = factor_ptrs_of(a.fp);
+    round_pipe_body<K, D, EXTRA, FOLD>(fp, q, emit, P, a.chal_fold, a.e_partials, a.done_counter, a.ta, sc1_handoff);
 }
 
 // ---- the same launch for MIDDLE rounds: four lanes per pair index, one NODE per lane -------------------------------------------
@@ -821,10 +841,9 @@ ZK_D void fin_gather_e(Fe (*ew)[16], uint32_t nactive, Fe *red, Fe (&e)[K + 1], 
 }
 
 template <int K, int D, int EXTRA>
-__global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs fp, uint32_t m_in, int entry, const uint64_t *__restrict__ e_partials,
-                                                                    uint32_t e_blocks, FieldParams P, PipeConsts pc, const uint64_t *__restrict__ chal_in,
-                                                                    uint64_t *__restrict__ chal_last, WordSponge *gsponge, uint64_t *out_rp,
-                                                                    uint64_t *out_ch, uint64_t *out_final, uint64_t *dbg, FinishPublish pub) {
+ZK_D void finish_pipe_body(const FactorPtrs &fp, uint32_t m_in, int entry, const uint64_t *__restrict__ e_partials, uint32_t e_blocks, const FieldParams &P,
+                           const PipeConsts &pc, const uint64_t *__restrict__ chal_in, uint64_t *__restrict__ chal_last, WordSponge *gsponge,
+                           uint64_t *out_rp, uint64_t *out_ch, uint64_t *out_final, uint64_t *dbg, const FinishPublish &pub) {
     constexpr int NF = K + EXTRA, NS = D + 1, NR = K + 1, NE = NS * NR;
     extern __shared__ __attribute__((aligned(32))) unsigned char fp_smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1067,6 +1086,29 @@ __global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs f
             if (lane == 0) *pub.flag = pub.seq;
         }
     }
+}
+template <int K, int D, int EXTRA>
+__global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe(FactorPtrs fp, uint32_t m_in, int entry, const uint64_t *__restrict__ e_partials,
+                                                                    uint32_t e_blocks, FieldParams P, PipeConsts pc, const uint64_t *__restrict__ chal_in,
+                                                                    uint64_t *__restrict__ chal_last, WordSponge *gsponge, uint64_t *out_rp,
+                                                                    uint64_t *out_ch, uint64_t *out_final, uint64_t *dbg, FinishPublish pub) {
+    finish_pipe_body<K, D, EXTRA>(fp, m_in, entry, e_partials, e_blocks, P, pc, chal_in, chal_last, gsponge, out_rp, out_ch, out_final, dbg, pub);
+}
+// batched form: grid (1, proofs), one finisher workgroup per proof (each on its own CU: the dynamic LDS is per workgroup)
+struct FinishSlot {
+    FactorPtrs4 fp;
+    const uint64_t *e_partials, *chal_in;
+    uint64_t *chal_last;
+    WordSponge *sponge;
+    uint64_t *out_rp, *out_ch, *out_final;
+    FinishPublish pub;
+};
+template <int K, int D, int EXTRA>
+__global__ __launch_bounds__(kFinishPipeThreads) void k_finish_pipe_b(BatchOf<FinishSlot> b, uint32_t m_in, int entry, uint32_t e_blocks, FieldParams P,
+                                                                      PipeConsts pc) {
+    const FinishSlot &a = b.a[blockIdx.y];
+    const FactorPtrs fp = factor_ptrs_of(a.fp);
+    finish_pipe_body<K, D, EXTRA>(fp, m_in, entry, a.e_partials, e_blocks, P, pc, a.chal_in, a.chal_last, a.sponge, a.out_rp, a.out_ch, a.out_final, nullptr, a.pub);
 }
 
 }  // namespace zk

@@ -197,8 +197,8 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, u
 #define ZK_KD_MIN_BLOCKS(K, EXTRA, FUSED, SKIP1) (((K) + (EXTRA) <= 2 || ((K) == 3 && (EXTRA) == 0) || ((EXTRA) == 1 && (FUSED) && (SKIP1))) ? 2 : 1)
 #endif
 template <int K, int D, bool FUSED, int EXTRA = 0, bool SKIP1 = false, bool LEAD = false>
-__global__ __launch_bounds__(kBlock, ZK_KD_MIN_BLOCKS(K, EXTRA, FUSED, SKIP1)) void k_round_kd(FactorPtrs fp, uint64_t q, FieldParams P,
-                                                        const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials, ClaimJob cj = {}) {
+ZK_D void round_kd_body(const FactorPtrs &fp, uint64_t q, const FieldParams &P, const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials,
+                        const ClaimJob &cj) {
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
     // SKIP1 with a claim job: the LAST workgroup of the grid is not a work block -- its first wave evaluates S_prev(r_prev) for the
     // tail (common.cuh ClaimJob) while the others stream the table
@@ -258,6 +258,24 @@ __global__ __launch_bounds__(kBlock, ZK_KD_MIN_BLOCKS(K, EXTRA, FUSED, SKIP1)) v
             if (!(SKIP1 && t == 1)) R.sum[t] = fe_add(R.sum[t], R.sum_b[t], P);
     }
     block_reduce_store<NS, SKIP1>(R.sum, partials, P);
+}
+template <int K, int D, bool FUSED, int EXTRA = 0, bool SKIP1 = false, bool LEAD = false>
+__global__ __launch_bounds__(kBlock, ZK_KD_MIN_BLOCKS(K, EXTRA, FUSED, SKIP1)) void k_round_kd(FactorPtrs fp, uint64_t q, FieldParams P,
+                                                        const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials, ClaimJob cj = {}) {
+    round_kd_body<K, D, FUSED, EXTRA, SKIP1, LEAD>(fp, q, P, rptr, partials, cj);
+}
+// per-proof arguments of a batched round launch (k_round_kd_b, k_round0_dot29_b, k_round_quad_b: grid (work blocks [+ claim], proofs))
+struct RoundSlot {
+    FactorPtrs4 fp;
+    const uint64_t *rptr;
+    uint64_t *partials;
+    ClaimJob cj;
+};
+template <int K, int D, bool FUSED, int EXTRA = 0, bool SKIP1 = false, bool LEAD = false>
+__global__ __launch_bounds__(kBlock, ZK_KD_MIN_BLOCKS(K, EXTRA, FUSED, SKIP1)) void k_round_kd_b(BatchOf<RoundSlot> b, uint64_t q, FieldParams P) {
+    const RoundSlot &a = b.a[blockIdx.y];
+    const FactorPtrs fp = factor_ptrs_of(a.fp);
+    round_kd_body<K, D, FUSED, EXTRA, SKIP1, LEAD>(fp, q, P, a.rptr, a.partials, a.cj);
 }
 
 // ---- round 0 (sums only) of the two-table degree-2 shapes on carry-free 29-bit columns (round 4) ---------------------------------
@@ -399,7 +417,7 @@ ZK_D void dot29_to_wide(const uint64_t (&c)[17], WideAcc &w) {
         if (i >= wi) w.v[i] = 0;
 }
 template <int EXTRA>
-__global__ __launch_bounds__(kBlock, 2) void k_round0_dot29(FactorPtrs fp, uint64_t q, FieldParams P, uint64_t *__restrict__ partials) {
+ZK_D void round0_dot29_body(const FactorPtrs &fp, uint64_t q, const FieldParams &P, uint64_t *__restrict__ partials) {
     constexpr int NT = 2 + EXTRA;
     uint64_t c0[17], c1[17], cL[17];
 #pragma unroll
@@ -476,6 +494,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_round0_dot29(FactorPtrs fp, uint6
     }
     block_reduce_store<3>(sum, partials, P);
 }
+template <int EXTRA>
+__global__ __launch_bounds__(kBlock, 2) void k_round0_dot29(FactorPtrs fp, uint64_t q, FieldParams P, uint64_t *__restrict__ partials) {
+    round0_dot29_body<EXTRA>(fp, q, P, partials);
+}
+template <int EXTRA>
+__global__ __launch_bounds__(kBlock, 2) void k_round0_dot29_b(BatchOf<RoundSlot> b, uint64_t q, FieldParams P) {
+    const RoundSlot &a = b.a[blockIdx.y];
+    const FactorPtrs fp = factor_ptrs_of(a.fp);
+    round0_dot29_body<EXTRA>(fp, q, P, a.partials);
+}
 
 // ---- small fused rounds: one FACTOR per lane, one EVALUATION POINT per lane, four lanes per pair index -----------------
 // Between ~2^10 and ~2^15 pairs a round is pure latency: k_round_kd gives a lane the whole pair index (7 dependent-ish
@@ -484,8 +512,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_round0_dot29(FactorPtrs fp, uint6
 // with DPP quad_perm broadcasts, and lane t forms the product for evaluation point t (k - 1 multiplies).  Same arithmetic
 // per pair index, spread over 4x the lanes: the per-lane chain drops to ~1100-1400 instructions.  K + EXTRA <= 4, D <= 3.
 template <int K, int D, int EXTRA>
-__global__ __launch_bounds__(kBlock) void k_round_quad(FactorPtrs fp, uint64_t q, FieldParams P, const uint64_t *__restrict__ rptr,
-                                                       uint64_t *__restrict__ partials) {
+ZK_D void round_quad_body(const FactorPtrs &fp, uint64_t q, const FieldParams &P, const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials) {
     constexpr int NF = K + EXTRA, NS = D + 1;
     static_assert(NF <= 4 && NS <= 4, "four lanes per pair index");
     __shared__ uint32_t red[kBlock / 64][4][8];
@@ -585,6 +612,17 @@ __global__ __launch_bounds__(kBlock) void k_round_quad(FactorPtrs fp, uint64_t q
         }
         fe_store(partials, (uint64_t)blockIdx.x * NS + threadIdx.x, tot);
     }
+}
+template <int K, int D, int EXTRA>
+__global__ __launch_bounds__(kBlock) void k_round_quad(FactorPtrs fp, uint64_t q, FieldParams P, const uint64_t *__restrict__ rptr,
+                                                       uint64_t *__restrict__ partials) {
+    round_quad_body<K, D, EXTRA>(fp, q, P, rptr, partials);
+}
+template <int K, int D, int EXTRA>
+__global__ __launch_bounds__(kBlock) void k_round_quad_b(BatchOf<RoundSlot> b, uint64_t q, FieldParams P) {
+    const RoundSlot &a = b.a[blockIdx.y];
+    const FactorPtrs fp = factor_ptrs_of(a.fp);
+    round_quad_body<K, D, EXTRA>(fp, q, P, a.rptr, a.partials);
 }
 
 // Generic-degree fallback: one evaluation point t per launch (any D up to 255, any k <= kMaxFactors).

@@ -37,8 +37,18 @@ static uint32_t launch_quad(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint
     uint64_t g = (q + 63) / 64;
     const uint64_t cap = (q + 64ull * kMaxLazy - 1) / (64ull * kMaxLazy);
     if (g > 2048) g = cap > 2048 ? cap : 2048;
-    k_round_quad<K, D, EXTRA><<<(uint32_t)g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
-    return (uint32_t)g;
+    const FieldParams *P = lc.P;
+    hipStream_t st = lc.stream;
+    uint64_t *part = lc.d_partials;
+    const uint32_t grid = (uint32_t)g;
+    auto single = [=]() {
+        k_round_quad<K, D, EXTRA><<<grid, kBlock, 0, st>>>(fp, q, *P, d_r, part);
+        return hipGetLastError();
+    };
+    if (!batch_record(BK_ROUND_QUAD, (uint32_t)K | ((uint32_t)D << 4) | ((uint32_t)EXTRA << 9), grid, kBlock, 0, q, 0, 0, 0,
+                      RoundSlot{factor_ptrs4(fp), d_r, part, ClaimJob{}}, single))
+        (void)single();
+    return grid;
 }
 // the product-plus-term shape (a GKR layer: three tables, 2300-2700 instructions per pair index) is better off with ONE wave per SIMD
 // and twice the pairs per thread below 2^17 pairs: 7.57 -> 7.50 ms on the depth-8 x 2^20 driver (profiles/r04_round_min_blocks_ab.log);
@@ -63,15 +73,55 @@ static inline uint32_t capped_grid(uint64_t q) {
 // a SKIP1 kernel launched with a claim job carries one workgroup more than its work grid (round_kernels.cuh)
 static inline uint32_t claim_blocks(const RoundLaunchCtx &lc) { return lc.claim.out ? 1u : 0u; }
 
+thread_local BatchRecorder *g_batch = nullptr;
+
+// every launch of a round kernel goes through one of these: launch now, or -- inside zk_sumcheck_prove_batch -- hand the launch to the
+// recorder (launch.hpp) to be merged with the other proofs' launches of the same step
+constexpr uint32_t kd_shape(int K, int D, bool FUSED, int EXTRA, bool SKIP1, bool LEAD) {
+    return (uint32_t)K | ((uint32_t)D << 4) | ((uint32_t)FUSED << 8) | ((uint32_t)EXTRA << 9) | ((uint32_t)SKIP1 << 10) | ((uint32_t)LEAD << 11);
+}
+template <int K, int D, bool FUSED, int EXTRA = 0, bool SKIP1 = false, bool LEAD = false>
+static void go_kd(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, const uint64_t *d_r, uint32_t grid, const ClaimJob &cj = {}) {
+    const FieldParams *P = lc.P;
+    hipStream_t st = lc.stream;
+    uint64_t *part = lc.d_partials;
+    auto single = [=]() {
+        k_round_kd<K, D, FUSED, EXTRA, SKIP1, LEAD><<<grid, kBlock, 0, st>>>(fp, q, *P, d_r, part, cj);
+        return hipGetLastError();
+    };
+    if (batch_record(BK_ROUND_KD, kd_shape(K, D, FUSED, EXTRA, SKIP1, LEAD), grid, kBlock, 0, q, 0, 0, 0, RoundSlot{factor_ptrs4(fp), d_r, part, cj}, single))
+        return;
+    (void)single();
+}
+template <int EXTRA>
+static void go_round0_dot29(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, uint32_t grid) {
+    const FieldParams *P = lc.P;
+    hipStream_t st = lc.stream;
+    uint64_t *part = lc.d_partials;
+    auto single = [=]() {
+        k_round0_dot29<EXTRA><<<grid, kBlock, 0, st>>>(fp, q, *P, part);
+        return hipGetLastError();
+    };
+    if (batch_record(BK_ROUND0_DOT29, (uint32_t)EXTRA, grid, kBlock, 0, q, 0, 0, 0, RoundSlot{factor_ptrs4(fp), nullptr, part, ClaimJob{}}, single)) return;
+    (void)single();
+}
+
 template <int K, int D>
 static void launch_kd(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, bool fused, const uint64_t *d_r, uint32_t g) {
-    if (fused) k_round_kd<K, D, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
-    else k_round_kd<K, D, false><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+    if (fused) go_kd<K, D, true>(lc, fp, q, d_r, g);
+    else go_kd<K, D, false>(lc, fp, q, d_r, g);
 }
 template <int D>
 static void launch_generic(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, bool fused, const uint64_t *d_r, uint32_t g) {
-    if (fused) k_round<D, true><<<g, kBlock, 0, lc.stream>>>(fp, k, q, *lc.P, d_r, lc.d_partials);
-    else k_round<D, false><<<g, kBlock, 0, lc.stream>>>(fp, k, q, *lc.P, d_r, lc.d_partials);
+    const FieldParams *P = lc.P;
+    hipStream_t st = lc.stream;
+    uint64_t *part = lc.d_partials;
+    auto single = [=]() {
+        if (fused) k_round<D, true><<<g, kBlock, 0, st>>>(fp, k, q, *P, d_r, part);
+        else k_round<D, false><<<g, kBlock, 0, st>>>(fp, k, q, *P, d_r, part);
+        return hipGetLastError();
+    };
+    if (!batch_record_other(single)) (void)single();   // (runtime-k shapes have no batched twin: a batch replays them proof by proof)
 }
 
 int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused,
@@ -86,13 +136,13 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
         const int shl = k * 10 + (int)D;
         bool done = true;
         if (!fused) {
-            if (shl == 22 && round0_dot29()) k_round0_dot29<0><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, lc.d_partials);
-            else if (shl == 22) k_round_kd<2, 2, false, 0, false, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
-            else k_round_kd<3, 3, false, 0, false, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+            if (shl == 22 && round0_dot29()) go_round0_dot29<0>(lc, fp, q, g);
+            else if (shl == 22) go_kd<2, 2, false, 0, false, true>(lc, fp, q, d_r, g);
+            else go_kd<3, 3, false, 0, false, true>(lc, fp, q, d_r, g);
             if (skip1) *skip1 = false;
         } else if (skip1 && *skip1) {
-            if (shl == 22) k_round_kd<2, 2, true, 0, true, true><<<g + claim_blocks(lc), kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.claim);
-            else k_round_kd<3, 3, true, 0, true, true><<<g + claim_blocks(lc), kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.claim);
+            if (shl == 22) go_kd<2, 2, true, 0, true, true>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
+            else go_kd<3, 3, true, 0, true, true>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
         } else {
             done = false;
         }
@@ -119,8 +169,8 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
     if (skip1 && *skip1) {   // the variants without the t = 1 products exist for the GKR-style shapes, fused only
         const bool fits1 = (uint64_t)g * (D + 1) <= lc.capacity_elems;
         const int shape1 = (fits1 && fused) ? k * 10 + (int)D : 0;
-        if (shape1 == 22) k_round_kd<2, 2, true, 0, true><<<g + claim_blocks(lc), kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.claim);
-        else if (shape1 == 33) k_round_kd<3, 3, true, 0, true><<<g + claim_blocks(lc), kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.claim);
+        if (shape1 == 22) go_kd<2, 2, true, 0, true>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
+        else if (shape1 == 33) go_kd<3, 3, true, 0, true>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
         else *skip1 = false;
         if (*skip1) {
             if (hipGetLastError() != hipSuccess) return kLaunchHipError;
@@ -165,11 +215,11 @@ int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, ui
         if (!fused) {
             // (the carry-free round-0 kernel with a third table has no registers left for the second prefetch buffer and measures
             // 0.1-0.4 % SLOWER on the GKR driver: profiles/r04_round0_dot29_ab.log; ZK_ROUND0_DOT29=2 selects it for A/B runs)
-            if (round0_dot29_extra()) k_round0_dot29<1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, lc.d_partials);
-            else k_round_kd<2, 2, false, 1, false, true><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+            if (round0_dot29_extra()) go_round0_dot29<1>(lc, fp, q, g);
+            else go_kd<2, 2, false, 1, false, true>(lc, fp, q, d_r, g);
             if (skip1) *skip1 = false;
         } else {
-            k_round_kd<2, 2, true, 1, true, true><<<g + claim_blocks(lc), kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.claim);
+            go_kd<2, 2, true, 1, true, true>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
         }
         if (hipGetLastError() != hipSuccess) return kLaunchHipError;
         *out_grid = g;
@@ -185,12 +235,12 @@ int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, ui
     }
     if (skip1 && *skip1 && !(shape == 22 && fused)) *skip1 = false;
     if (shape == 22) {
-        if (fused && skip1 && *skip1) k_round_kd<2, 2, true, 1, true><<<g + claim_blocks(lc), kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials, lc.claim);
-        else if (fused) k_round_kd<2, 2, true, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
-        else k_round_kd<2, 2, false, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        if (fused && skip1 && *skip1) go_kd<2, 2, true, 1, true>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
+        else if (fused) go_kd<2, 2, true, 1>(lc, fp, q, d_r, g);
+        else go_kd<2, 2, false, 1>(lc, fp, q, d_r, g);
     } else if (shape == 33) {
-        if (fused) k_round_kd<3, 3, true, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
-        else k_round_kd<3, 3, false, 1><<<g, kBlock, 0, lc.stream>>>(fp, q, *lc.P, d_r, lc.d_partials);
+        if (fused) go_kd<3, 3, true, 1>(lc, fp, q, d_r, g);
+        else go_kd<3, 3, false, 1>(lc, fp, q, d_r, g);
     } else {
         return kLaunchUnsupported;
     }
@@ -201,10 +251,58 @@ int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, ui
 
 int launch_round_single_t(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, const Fe &tval, uint32_t *out_grid) {
     const uint32_t g = capped_grid(q);
-    k_round_single_t<<<g, kBlock, 0, lc.stream>>>(fp, k, q, *lc.P, tval, lc.d_partials);
+    {
+        const FieldParams *P = lc.P;
+        hipStream_t st = lc.stream;
+        uint64_t *part = lc.d_partials;
+        auto single = [=]() {
+            k_round_single_t<<<g, kBlock, 0, st>>>(fp, k, q, *P, tval, part);
+            return hipGetLastError();
+        };
+        if (!batch_record_other(single)) (void)single();
+    }
     if (hipGetLastError() != hipSuccess) return kLaunchHipError;
     *out_grid = g;
     return kLaunchOk;
+}
+
+// ---- batched twins (zk_sumcheck_prove_batch): launch idx of every proof of the batch as ONE launch, grid (x, proofs) ------------------
+// Instantiated for the shapes the configs use -- products of two or three tables with D = K, no extra term -- on every kernel the
+// shipped thresholds select for them; anything else returns kLaunchUnsupported and is replayed proof by proof.
+int batch_launch_rounds(const BatchRecorder &r, size_t idx) {
+    const BatchRecord &r0 = r.recs[0][idx];
+    BatchOf<RoundSlot> slots;
+    batch_gather(r, idx, slots);
+    const dim3 grid(r0.grid, (uint32_t)r.n);
+    const uint64_t q = r0.s[0];
+    const FieldParams &P = *r.P;
+#define ZK_KD_B(K, D, F, E, S, L)                                                                  \
+    case kd_shape(K, D, F, E, S, L):                                                               \
+        k_round_kd_b<K, D, F, E, S, L><<<grid, kBlock, 0, r.stream>>>(slots, q, P);               \
+        break;
+    if (r0.kernel == BK_ROUND_KD) {
+        switch (r0.shape) {
+            ZK_KD_B(2, 2, true, 0, true, true)     // the big fused rounds (SKIP1 + LEAD)
+            ZK_KD_B(3, 3, true, 0, true, true)
+            ZK_KD_B(3, 3, false, 0, false, true)   // round 0 of three tables (LEAD)
+            ZK_KD_B(2, 2, true, 0, false, false)   // plain fused / sums-only rounds (small sizes, thresholds moved by the tests)
+            ZK_KD_B(3, 3, true, 0, false, false)
+            ZK_KD_B(2, 2, false, 0, false, false)
+            ZK_KD_B(3, 3, false, 0, false, false)
+            default: return kLaunchUnsupported;
+        }
+    } else if (r0.kernel == BK_ROUND0_DOT29) {
+        if (r0.shape != 0) return kLaunchUnsupported;
+        k_round0_dot29_b<0><<<grid, kBlock, 0, r.stream>>>(slots, q, P);
+    } else if (r0.kernel == BK_ROUND_QUAD) {
+        if (r0.shape == (2u | (2u << 4))) k_round_quad_b<2, 2, 0><<<grid, kBlock, 0, r.stream>>>(slots, q, P);
+        else if (r0.shape == (3u | (3u << 4))) k_round_quad_b<3, 3, 0><<<grid, kBlock, 0, r.stream>>>(slots, q, P);
+        else return kLaunchUnsupported;
+    } else {
+        return kLaunchUnsupported;
+    }
+#undef ZK_KD_B
+    return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchHipError;
 }
 
 }  // namespace zk
