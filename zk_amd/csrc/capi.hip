@@ -2180,6 +2180,11 @@ static int32_t batch_flush(zk_ctx *c, BatchRecorder &r) {
                 g_hip_err = "batched prover: a merged launch failed";
                 rc = ZK_ERR_HIP;
             } else {
+                static const bool dbg = env_flag("ZK_BATCH_DEBUG");
+                if (dbg)
+                    fprintf(stderr, "[batch] step %zu replayed: kernel %d shape 0x%x grid %u block %u lds %zu s = %llu %llu %llu %llu (%s)\n", i, r0.kernel,
+                            r0.shape, r0.grid, r0.block, r0.lds, (unsigned long long)r0.s[0], (unsigned long long)r0.s[1], (unsigned long long)r0.s[2],
+                            (unsigned long long)r0.s[3], same ? "no batched twin" : "shared arguments differ between the proofs");
                 for (int b = 0; b < r.n; ++b) replay(b, i);
             }
         }
