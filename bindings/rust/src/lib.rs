@@ -49,6 +49,8 @@ pub struct zk_transcript { _opaque: [u8; 0] }
 pub struct zk_circuit { _opaque: [u8; 0] }
 
 const ZK_ERR_EMPTY_PRODUCT: i32 = -3;
+const ZK_ERR_ARITY_MISMATCH: i32 = -4;
+const ZK_ERR_BAD_ARG: i32 = -20;
 const ZK_ERR_PANIC_INDEX: i32 = -5;
 const ZK_ERR_FFT_NOT_POW2: i32 = -6;
 const ZK_ERR_FFT_NO_ROOT: i32 = -7;
@@ -84,6 +86,8 @@ extern "C" {
     fn zk_transcript_sample_n_field_elements(t: *mut zk_transcript, field: i32, n: u64, out: *mut u64) -> i32;
     fn zk_sumcheck_prove(ctx: *mut zk_ctx, factors: *const *mut zk_mle, k: u64, max_var_degree: u32, sum: *const u64,
                          absorb_table: i32, consume: i32, out_round_polys: *mut u64, out_challenges: *mut u64) -> i32;
+    fn zk_sumcheck_prove_batch(ctx: *mut zk_ctx, n_proofs: u64, factors: *const *mut zk_mle, k: u64, max_var_degree: u32, sums: *const u64,
+                               consume: i32, out_round_polys: *mut u64, out_challenges: *mut u64) -> i32;
     fn zk_sumcheck_verify_partial(field: i32, n_rounds: u64, max_var_degree: u32, sum: *const u64, round_polys: *const u64,
                                   out_subclaim_sum: *mut u64, out_challenges: *mut u64) -> i32;
     fn zk_sumcheck_verify(ctx: *mut zk_ctx, factors: *const *const zk_mle, k: u64, n_round_polys: u64, max_var_degree: u32,
@@ -370,6 +374,25 @@ impl<const MAX_VAR_DEGREE: u8, F: GpuField> SumcheckProver<MAX_VAR_DEGREE, F> {
     /// prover.rs:24-30
     pub fn prove_partial(poly: ProductPoly<F>, sum: F) -> Result<(SumcheckProof<F>, Vec<F>), &'static str> {
         Self::run(poly, sum, 0)
+    }
+    /// `polys.len()` independent `prove_partial` calls (same factor count and arity) proved side by side: one kernel launch per
+    /// round for all of them (zk_sumcheck_prove_batch).  Element i equals `prove_partial(polys[i], sums[i])`, bit for bit.
+    pub fn prove_partial_batch(polys: Vec<ProductPoly<F>>, sums: Vec<F>) -> Result<Vec<(SumcheckProof<F>, Vec<F>)>, &'static str> {
+        if polys.len() != sums.len() { return Err(err(ZK_ERR_BAD_ARG)); }
+        if polys.is_empty() { return Ok(Vec::new()); }
+        let (b, k, n, ns) = (polys.len(), polys[0].handles().len(), polys[0].n_vars(), MAX_VAR_DEGREE as usize + 1);
+        let mut h: Vec<*mut zk_mle> = Vec::with_capacity(b * k);
+        for p in &polys {
+            let hp = p.handles();
+            if hp.len() != k { return Err(err(ZK_ERR_ARITY_MISMATCH)); }
+            h.extend(hp.iter().map(|x| *x as *mut zk_mle));
+        }
+        let (mut rp, mut ch) = (vec![F::zero(); b * n * ns + 1], vec![F::zero(); b * n + 1]);
+        let rc = unsafe { zk_sumcheck_prove_batch(polys[0].ctx_raw(), b as u64, h.as_ptr(), k as u64, MAX_VAR_DEGREE as u32, limbs(&sums), 0,
+                                                  limbs_mut(&mut rp), limbs_mut(&mut ch)) };
+        if rc != 0 { return Err(err(rc)); }
+        Ok((0..b).map(|i| (SumcheckProof { sum: sums[i], round_polys: rp[i * n * ns..(i + 1) * n * ns].chunks(ns).map(|c| c.to_vec()).collect() },
+                           ch[i * n..(i + 1) * n].to_vec())).collect())
     }
 }
 

@@ -132,6 +132,27 @@ TEST(test_index_pair_clone_eq_sample_n) {
     ASSERT_EQ(fft_internal<F>(a, w), fft<F>(a));
 }
 
+// three independent prove_partial calls of sumcheck/src/lib.rs:64-112's polynomials proved side by side (zk_sumcheck_prove_batch): each
+// equals the single call, and each sub-claim is the product at the challenge point
+TEST(test_prove_partial_batch_equals_single_calls) {
+    std::vector<ProductPoly<F>> polys;
+    std::vector<Fr> sums = {Fr::from(5), Fr::from(5), Fr::from(7)};   // (the third: a wrong claim is proved all the same)
+    for (int i = 0; i < 3; ++i) {
+        auto p1 = MultiLinearPolynomial<F>::new_(2, frs({3, 3, 5, 5})).unwrap();
+        auto p2 = MultiLinearPolynomial<F>::new_(2, frs({0, 0, 0, 1})).unwrap();
+        polys.push_back(ProductPoly<F>::new_({p1, p2}).unwrap());
+    }
+    auto got = SumcheckProver<2, F>::prove_partial_batch(polys, sums).unwrap();
+    ASSERT_EQ(got.size(), (size_t)3);
+    for (int i = 0; i < 3; ++i) {
+        auto one = SumcheckProver<2, F>::prove_partial(polys[i], sums[i]).unwrap();
+        ASSERT(got[i].first.round_polys == one.first.round_polys);
+        ASSERT_EQ(got[i].second, one.second);
+    }
+    auto subclaim = SumcheckVerifier<F>::verify_partial(got[0].first).expect("proof is invalid");
+    ASSERT_EQ(polys[0].evaluate(subclaim.challenges).unwrap(), subclaim.sum);
+}
+
 int main() {
     try {
         run_test_new_multilinear_poly();
@@ -146,10 +167,11 @@ int main() {
         run_test_invalid_sum();
         run_test_fft();
         run_test_index_pair_clone_eq_sample_n();
+        run_test_prove_partial_batch_equals_single_calls();
     } catch (const std::exception &e) {
         std::printf("EXCEPTION: %s\n", e.what());
         return 2;
     }
-    std::printf(failures ? "FAILED (%d)\n" : "ok: 12 reference tests passed%.0d\n", failures);
+    std::printf(failures ? "FAILED (%d)\n" : "ok: 12 reference tests + 1 batch test passed%.0d\n", failures);
     return failures ? 1 : 0;
 }

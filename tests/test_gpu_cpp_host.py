@@ -15,7 +15,7 @@ def test_cpp_reference_kats_on_gpu():
         subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
     r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "ok: 12 reference tests passed" in r.stdout
+    assert "ok: 12 reference tests + 1 batch test passed" in r.stdout
 
 
 @pytest.mark.gpu

@@ -250,6 +250,39 @@ public:
     static Result<std::pair<SumcheckProof<F>, std::vector<Fe<F>>>> prove_partial(const ProductPoly<F> &poly, Fe<F> sum) {   // :24-30
         return run(poly, sum, 0);
     }
+    // polys.size() independent prove_partial calls (one ProductPoly each, same factor count and arity) proved side by side:
+    // zk_sumcheck_prove_batch, one launch per round for all of them; element i equals prove_partial(polys[i], sums[i])
+    static Result<std::vector<std::pair<SumcheckProof<F>, std::vector<Fe<F>>>>> prove_partial_batch(const std::vector<ProductPoly<F>> &polys,
+                                                                                                  const std::vector<Fe<F>> &sums) {
+        using Out = std::vector<std::pair<SumcheckProof<F>, std::vector<Fe<F>>>>;
+        if (polys.size() != sums.size()) return Result<Out>(ZK_ERR_BAD_ARG);
+        if (polys.empty()) return Out{};
+        const size_t B = polys.size(), k = polys[0].polys_.size(), n = polys[0].n_vars(), ns = (size_t)MAX_VAR_DEGREE + 1;
+        std::vector<zk_mle *> h;
+        std::vector<uint64_t> s;
+        for (size_t b = 0; b < B; ++b) {
+            if (polys[b].polys_.size() != k) return Result<Out>(ZK_ERR_ARITY_MISMATCH);
+            for (auto &p : polys[b].polys_) h.push_back(p.raw());
+            s.insert(s.end(), sums[b].l.begin(), sums[b].l.end());
+        }
+        std::vector<uint64_t> rp(4 * B * n * ns + 4), ch(4 * B * n + 4);
+        const int32_t rc = zk_sumcheck_prove_batch(context<F>(), B, h.data(), k, MAX_VAR_DEGREE, s.data(), /*consume=*/0, rp.data(), ch.data());
+        if (rc != ZK_OK) return Result<Out>(rc);
+        Out out;
+        for (size_t b = 0; b < B; ++b) {
+            SumcheckProof<F> proof{sums[b], {}};
+            std::vector<Fe<F>> challenges(n);
+            for (size_t r = 0; r < n; ++r) {
+                std::vector<Fe<F>> row(ns);
+                for (size_t t = 0; t < ns; ++t)
+                    for (int i = 0; i < 4; ++i) row[t].l[i] = rp[4 * ((b * n + r) * ns + t) + i];
+                proof.round_polys.push_back(row);
+                for (int i = 0; i < 4; ++i) challenges[r].l[i] = ch[4 * (b * n + r) + i];
+            }
+            out.emplace_back(proof, challenges);
+        }
+        return out;
+    }
 };
 
 template <class F>
