@@ -637,6 +637,7 @@ def main():
                    "n_vars": N_VARS, "field": "bn254_fr", "elements_per_gpu": 1 << local_vars,
                    "shard": "index mod n_gpus (no collective in the fold)"},
         "timed_region_s": dt,
+        "library": __import__("zk_amd._lib", fromlist=["lib_info"]).lib_info(),
         "parity_gate": gate if gate is not None else "not run (--no-parity-gate or N > 1: see sharded_proof_* there)",
         "clock_prewarm": {"ms": args.prewarm_ms, "untimed_launches": prewarm_launches},
         "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -699,10 +700,11 @@ def main():
             for n in (18, 19, 20, 21):
                 tn = zk_amd.MultiLinearPolynomial.random(ctx, n, 0x5EED0E00 + n, 0)
                 pt = tr2.sample_n_field_elements(field, n)
-                for _ in range(10):
-                    tn.evaluate(pt)   # warm
-                ms = sorted(zk_amd.bench_evaluate(tn, pt, 11))      # std::chrono around zk_mle_evaluate inside the library
-                extra[f"evaluate_us_n{n}"] = ms[5] * 1e3
+                tn.evaluate(pt)   # warm: ONE call (profiles/r06_eval_r04_vs_head_ab.log: ten warm-up calls make the n = 21 median 1.5-2 us
+                                  # slower on the round-4 library and on this one alike -- the round-5 driver "regression" was this row's warm-up)
+                ms = sorted(zk_amd.bench_evaluate(tn, pt, 21))      # std::chrono around zk_mle_evaluate inside the library
+                extra[f"evaluate_us_n{n}"] = ms[10] * 1e3
+                extra[f"evaluate_us_n{n}_min"] = ms[0] * 1e3
                 ts = []
                 for _ in range(11):
                     ctx.synchronize()
@@ -717,8 +719,7 @@ def main():
                 for n in sizes:
                     tn = zk_amd.MultiLinearPolynomial.random(cx, n, 0x5EED0E00 + n, 0)
                     pt = tr2.sample_n_field_elements(fld, n)
-                    for _ in range(10):
-                        tn.evaluate(pt)   # warm
+                    tn.evaluate(pt)   # warm (one call, as above)
                     ms = sorted(zk_amd.bench_evaluate(tn, pt, 21))
                     extra[f"evaluate_us_n{n}_{tag}"] = ms[10] * 1e3
                     extra[f"evaluate_us_n{n}_{tag}_min"] = ms[0] * 1e3

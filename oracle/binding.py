@@ -12,6 +12,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ZK_ORACLE_LIB: another build of the same source (the sanitizer build of `make -C oracle asan`, tools/run_sanitized.sh)
 _LIB_PATH = os.environ.get("ZK_ORACLE_LIB") or os.path.join(_HERE, "libzk_oracle.so")
+if os.path.realpath(_LIB_PATH) != os.path.realpath(os.path.join(_HERE, "libzk_oracle.so")):
+    import sys as _sys
+
+    _root = os.path.realpath(os.path.dirname(_HERE))
+    if not os.path.realpath(_LIB_PATH).startswith(_root + os.sep):
+        raise ImportError(f"ZK_ORACLE_LIB={_LIB_PATH} is outside {_root}: refused (the override is for builds of this tree only)")
+    print(f"oracle: ZK_ORACLE_LIB override active: loading {os.path.realpath(_LIB_PATH)}", file=_sys.stderr, flush=True)
 
 BN254_FR, BLS12_381_FR, BLS12_377_FR = 0, 1, 2
 

@@ -11,8 +11,19 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ZK_AMD_LIB: another build of the SAME sources (the host-sanitizer build of `make -C zk_amd/csrc asan`, tools/run_sanitized.sh; the
 # A/B scripts under tools/); never a different implementation -- there is no fallback path
-LIB_PATH = os.environ.get("ZK_AMD_LIB") or os.path.join(_HERE, "libzk_amd.so")
+_DEFAULT_LIB = os.path.join(_HERE, "libzk_amd.so")
+LIB_PATH = os.environ.get("ZK_AMD_LIB") or _DEFAULT_LIB
+LIB_OVERRIDDEN = os.path.realpath(LIB_PATH) != os.path.realpath(_DEFAULT_LIB)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "zk_amd.h")
+if LIB_OVERRIDDEN:
+    # an override is for builds of THIS tree (sanitizer build, A/B copies under ab_tmp/): anything else is refused, and the redirect is
+    # never silent -- a stale variable would otherwise make the tests and bench.py measure a different build than the sources
+    import sys as _sys
+
+    _root = os.path.realpath(os.path.dirname(_HERE))
+    if not os.path.realpath(LIB_PATH).startswith(_root + os.sep):
+        raise ImportError(f"ZK_AMD_LIB={LIB_PATH} is outside {_root}: refused (the override is for builds of this tree only)")
+    print(f"zk_amd: ZK_AMD_LIB override active: loading {os.path.realpath(LIB_PATH)}", file=_sys.stderr, flush=True)
 
 c = ctypes
 u64p = c.POINTER(c.c_uint64)
@@ -173,6 +184,13 @@ _sig = {
     "zk_bench_copy": [c.c_void_p, c.c_uint64, c.c_int32, c.POINTER(c.c_double)],
 }
 for _name, _args in _sig.items():
+    if LIB_OVERRIDDEN and not hasattr(lib, _name):
+        continue   # an older A/B build without this entry point: calling it raises AttributeError; the shipped library must have them all
     _f = getattr(lib, _name)
     _f.argtypes = _args
     _f.restype = c.c_int32
+
+
+def lib_info():
+    """which shared object this process computes with (bench.py records it in its JSON line)"""
+    return {"path": os.path.realpath(LIB_PATH), "overridden_by_ZK_AMD_LIB": bool(LIB_OVERRIDDEN), "abi": int(lib.zk_abi_version())}

@@ -307,7 +307,18 @@ class CoeffMultilinearPolynomial:
     computed on the GPU and left resident as a MultiLinearPolynomial)."""
 
     def __init__(self, field, n_vars, coefficients):
-        self.field, self._n_vars, self.coefficients = field, n_vars, coefficients   # {key: element}, key bit v <-> variable v
+        # {key: element}, key bit v <-> variable v.  The term map is IMMUTABLE (the reference's BTreeMap is a private field,
+        # coefficient_form.rs:27-30): a private copy, exposed read-only, flattened once into the two arrays the library takes
+        import types
+
+        self.field, self._n_vars = field, n_vars
+        self._terms = {int(k): np.array(v, dtype=np.uint64).reshape(4) for k, v in dict(coefficients).items()}
+        self.coefficients = types.MappingProxyType(self._terms)
+        keys = np.array(sorted(self._terms), dtype=np.uint64)
+        coeffs = np.stack([self._terms[int(k)] for k in keys]) if len(keys) else np.zeros((0, 4), dtype=np.uint64)
+        for v in self._terms.values():
+            v.setflags(write=False)
+        self._flat = (keys, np.ascontiguousarray(coeffs, dtype=np.uint64))
 
     @classmethod
     def new(cls, field, number_of_variables, terms):
@@ -331,11 +342,7 @@ class CoeffMultilinearPolynomial:
         return self._n_vars
 
     def to_evaluation_form(self, ctx):
-        if getattr(self, "_flat", None) is None or self._flat[2] != len(self.coefficients):   # the term list as two arrays, built once
-            keys = np.array(sorted(self.coefficients), dtype=np.uint64)
-            coeffs = (np.stack([self.coefficients[int(k)] for k in keys]) if len(keys) else np.zeros((0, 4), dtype=np.uint64))
-            self._flat = (keys, np.ascontiguousarray(coeffs, dtype=np.uint64), len(self.coefficients))
-        keys, coeffs, _ = self._flat
+        keys, coeffs = self._flat
         h = c.c_void_p()
         check(lib.zk_coeff_to_evaluation(ctx._h, self._n_vars, _p(keys), _p(coeffs), len(keys), c.byref(h)))
         return MultiLinearPolynomial(ctx, h)
