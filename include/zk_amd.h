@@ -390,6 +390,11 @@ int32_t zk_bench_copy(zk_ctx *ctx, uint64_t bytes, int32_t reps, double *out_gbp
    ZK_CLAIM_IN_ROUND       1         0 .. 1       0: the tails evaluate the SKIP1 claim S_prev(r_prev) themselves instead of reading it from the round kernel's claim workgroup
    ZK_PIPE_MID_TOTAL       0         0 .. 1       1: k_round_mid's last workgroup adds the block partials up; 0: the next launch's transcript block does
    ZK_SHARD_SKIP1          1         0 .. 1       0: the sharded prover's round kernels form every sum (no S(1) / S(D) derivation behind the all-reduce)
+   ZK_SHARD_OVERLAP        0         0 .. 1       1: zk_shard_prover_run keeps the per-round all-reduce off the critical path (three-stream schedule on the
+                                                  pending-challenge sums; same proof, bit for bit)
+   ZK_SHARD_OVERLAP_MAX_PAIRS 2^17   1 .. 2^40    ... for rounds with at most this many pairs per shard (larger ones: the serial steps)
+   ZK_SHARD_FAKE_ALLREDUCE_US 0      0 .. 1000    measurement aid: every all-reduce of the sharded loop is followed by a spin of this many microseconds
+                                                  on its stream (a one-rank communicator standing in for a node's latency)
    ZK_PIPE_DEBUG / ZK_HOST_DEBUG  off  flag       phase stamps of the pipelined rounds / host enqueue + wait times on stderr
    ZK_BATCH_DEBUG                 off  flag       zk_sumcheck_prove_batch: report on stderr every launch replayed proof by proof   */
 

@@ -64,6 +64,9 @@ struct zk_ctx {
     uint8_t *h_absorb[2];   // pinned staging of absorb_tables (prove / verify), kept across calls
     size_t h_absorb_bytes;
     hipEvent_t ev_absorb[2];
+    hipStream_t aux_stream[2];          // the sharded prover's overlapped schedule (comm_host.inc): collective stream, transcript stream
+    std::vector<hipEvent_t> ev_ring;    // ... and its cross-stream edges
+    size_t ev_next;
 };
 struct zk_mle {
     zk_ctx *ctx;
@@ -338,6 +341,8 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     c->h_absorb[0] = c->h_absorb[1] = nullptr;
     c->h_absorb_bytes = 0;
     c->ev_absorb[0] = c->ev_absorb[1] = nullptr;
+    c->aux_stream[0] = c->aux_stream[1] = nullptr;
+    c->ev_next = 0;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -378,6 +383,12 @@ extern "C" int32_t zk_ctx_destroy(zk_ctx *c) {
     }
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
+    for (int i = 0; i < 2; ++i)
+        if (c->aux_stream[i]) {
+            (void)hipStreamSynchronize(c->aux_stream[i]);
+            (void)hipStreamDestroy(c->aux_stream[i]);
+        }
+    for (hipEvent_t e : c->ev_ring) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->own_stream);
     delete c;
     return ZK_OK;

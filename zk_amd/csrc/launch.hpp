@@ -122,6 +122,11 @@ uint32_t pipe_rows_per_block(int k, uint32_t D, int extra);
 uint32_t pipe_work_blocks(int k, uint32_t D, int extra, uint64_t q);
 uint64_t mid_max_pairs();   // pair indices one k_round_mid launch can take (grid cap x unreduced products per lane)
 int launch_round_pipe(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t *out_work_blocks);
+// the transcript block alone (one workgroup on lc.stream): closes a round whose E totals arrive as all-reduced digit lanes (ta.lanes_in) --
+// the sharded prover's overlapped schedule runs it on its own stream beside the work launches
+int launch_pipe_tail_only(const RoundLaunchCtx &lc, int k, uint32_t D, int extra, const PipeTailArgs &ta);
+// ZK_SHARD_FAKE_ALLREDUCE_US: `us` microseconds of one spinning wave on `stream`
+int launch_spin_us(hipStream_t stream, uint32_t us);
 // the pipelined finisher (k_finish_pipe): every remaining round in one launch; entry = kFinEntry* of pipe_kernels.cuh
 // (0 fresh tables, 1 tables with *chal_in pending, 2 the same with the E partials of the first round ready)
 struct FinishPipeLaunch {

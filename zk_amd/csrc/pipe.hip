@@ -105,6 +105,29 @@ static int launch_round_mid(const RoundLaunchCtx &lc, const FactorPtrs &fp, cons
     return kLaunchOk;
 }
 
+template <int K, int D, int EXTRA>
+static void launch_tail_only_shape(const RoundLaunchCtx &lc, const PipeTailArgs &ta) {
+    const FactorPtrs none = {};
+    k_round_mid<K, D, EXTRA, false><<<1, kMidThreads, 0, lc.stream>>>(none, 0, 0, *lc.P, nullptr, nullptr, nullptr, ta, 0);
+}
+int launch_pipe_tail_only(const RoundLaunchCtx &lc, int k, uint32_t D, int extra, const PipeTailArgs &ta) {
+    if (!pipe_shape_ok(k, D, extra) || ta.mode < 0) return kLaunchUnsupported;
+    switch (k * 100 + (int)D * 10 + extra) {
+        case 110: launch_tail_only_shape<1, 1, 0>(lc, ta); break;
+        case 120: launch_tail_only_shape<1, 2, 0>(lc, ta); break;
+        case 220: launch_tail_only_shape<2, 2, 0>(lc, ta); break;
+        case 230: launch_tail_only_shape<2, 3, 0>(lc, ta); break;
+        case 330: launch_tail_only_shape<3, 3, 0>(lc, ta); break;
+        case 221: launch_tail_only_shape<2, 2, 1>(lc, ta); break;
+        default: return kLaunchUnsupported;
+    }
+    return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchHipError;
+}
+int launch_spin_us(hipStream_t stream, uint32_t us) {
+    k_spin_us<<<1, 1, 0, stream>>>(us);
+    return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchHipError;
+}
+
 int launch_round_pipe(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t *out_work_blocks) {
     if (!pipe_shape_ok(pl.k, pl.D, pl.extra)) return kLaunchUnsupported;
     if (pl.mid) return launch_round_mid(lc, fp, pl, out_work_blocks);

@@ -357,7 +357,26 @@ ZK_D void pipe_tail_block(const PipeTailArgs &ta, const FieldParams &P) {
     if (wave0) dbg_stamp(ta.dbg, 0);
     if (wave0) sp = lane_sponge_load(ta.sponge, L);   // in flight while the partials are reduced
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (ta.nblocks == 1) {   // already reduced (the last work block of the launch before did it)
+    if (ta.lanes_in) {       // sharded, overlapped schedule: the totals of all ranks as digit sums -> carry, mod p (k_lanes_transcript's ladder)
+        if (wave >= 2) return;
+        if (wave0 && lane < 16 && lane < ta.n_in) {
+            uint32_t v[9];
+            uint64_t carry = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                carry += ta.lanes_in[8 * lane + i];
+                v[i] = (uint32_t)carry;
+                carry >>= 32;
+            }
+            v[8] = (uint32_t)carry;
+            if (ta.log_world <= 3) ladder9<4>(v, P);
+            else ladder9<16>(v, P);
+            Fe r;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r.v[i] = v[i];
+            red[lane] = r;
+        }
+    } else if (ta.nblocks == 1) {   // already reduced (the last work block of the launch before did it)
         if (wave >= 2) return;
         if (wave0 && lane < 16 && lane < ta.n_in) red[lane] = fe_load(ta.partials, lane);
     } else {
@@ -751,8 +770,20 @@ __global__ __launch_bounds__(kMidThreads) void k_round_mid(FactorPtrs fp, uint64
     if (!is_last) return;
     __threadfence();
     pipe_reduce_partials(e_partials + NE * 4, nwork, NE, lred, lstage, P);
-    if (threadIdx.x < (uint32_t)NE) fe_store(e_partials, threadIdx.x, lred[threadIdx.x]);
+    if (threadIdx.x < (uint32_t)NE) {
+        fe_store(e_partials, threadIdx.x, lred[threadIdx.x]);
+        if (ta.lanes_out) {   // sharded, overlapped schedule: this rank's totals as zero-extended 32-bit digits for the all-reduce
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ta.lanes_out[8 * threadIdx.x + i] = (uint64_t)lred[threadIdx.x].v[i];
+        }
+    }
     if (threadIdx.x == 0) *done_counter = 0;   // ready for the next launch that uses this buffer
+}
+// ZK_SHARD_FAKE_ALLREDUCE_US: a stand-in for the latency of a multi-rank all-reduce on a one-rank communicator (spins on the 100 MHz clock)
+__global__ void k_spin_us(uint32_t us) {
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < (uint64_t)us * 100) {
+    }
 }
 
 // ---- the pipelined finisher: all remaining rounds in ONE 1024-thread workgroup --------------------------------------------
