@@ -385,14 +385,9 @@ int32_t zk_bench_copy(zk_ctx *ctx, uint64_t bytes, int32_t reps, double *out_gbp
    ZK_ZETA_GLOBAL          off       flag         to_evaluation_form by global passes of three index bits (round 4's path)
    ZK_NTT_FULL_TABLE_MAX_LOG 24      0 .. 24      largest inter-pass twiddle table (log2 entries) kept in HBM; smaller: composed per element (slower, less traffic)
    ZK_TO_BYTES_THREADS     affinity  1 .. 4       host threads copying to_bytes chunks to the caller (default: CPUs allowed, at most 4)
-   ZK_PIPE_MID_MAX_PAIRS   0         0 .. 2^40    rounds above ZK_PIPE_MAX_PAIRS up to this size take the pipelined schedule on k_round_mid (off: slower)
    ZK_PUBLISH_IN_FINISHER  1         0 .. 1       0: the proof block always goes to pinned host memory by a launch of its own (k_publish_host)
    ZK_CLAIM_IN_ROUND       1         0 .. 1       0: the tails evaluate the SKIP1 claim S_prev(r_prev) themselves instead of reading it from the round kernel's claim workgroup
-   ZK_PIPE_MID_TOTAL       0         0 .. 1       1: k_round_mid's last workgroup adds the block partials up; 0: the next launch's transcript block does
    ZK_SHARD_SKIP1          1         0 .. 1       0: the sharded prover's round kernels form every sum (no S(1) / S(D) derivation behind the all-reduce)
-   ZK_SHARD_OVERLAP        0         0 .. 1       1: zk_shard_prover_run keeps the per-round all-reduce off the critical path (three-stream schedule on the
-                                                  pending-challenge sums; same proof, bit for bit)
-   ZK_SHARD_OVERLAP_MAX_PAIRS 2^17   1 .. 2^40    ... for rounds with at most this many pairs per shard (larger ones: the serial steps)
    ZK_SHARD_FAKE_ALLREDUCE_US 0      0 .. 1000    measurement aid: every all-reduce of the sharded loop is followed by a spin of this many microseconds
                                                   on its stream (a one-rank communicator standing in for a node's latency)
    ZK_PIPE_DEBUG / ZK_HOST_DEBUG  off  flag       phase stamps of the pipelined rounds / host enqueue + wait times on stderr

@@ -756,21 +756,13 @@ SKIP1_RUNS = {
     "round0_wide": dict(ZK_ROUND0_DOT29="0", ZK_LEAD_MIN_PAIRS="1", ZK_CHECK_SIZES="3,9,14"),
     # ... and the carry-free round-0 kernel for the product-plus-term shape as well (k_round0_dot29<1>, not selected by default)
     "round0_dot29_terms": dict(ZK_ROUND0_DOT29="2", ZK_LEAD_MIN_PAIRS="1", ZK_CHECK_SIZES="3,9,13,14"),
-    # k_round_mid (four lanes per pair index) instead of the sixteen-lane rows in EVERY pipelined round, small ones included ...
-    "mid_every_pipelined_round": dict(ZK_PIPE_MAX_PAIRS="1", ZK_CHECK_SIZES="3,4,7,10,12,14,16,18"),
-    # ... entered right after LEAD + SKIP1 rounds, up to 2^17 pairs (several passes per quad), no quad kernel in between
-    # (one field: n = 19 is the size whose first pipelined round needs two passes per quad)
-    "mid_to_2p17_after_lead_skip1": dict(ZK_PIPE_MAX_PAIRS="1", ZK_PIPE_MID_MAX_PAIRS="131072", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1",
-                                         ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="11,13,15,17,19", ZK_CHECK_FIELDS="1"),
     # SKIP1 + LEAD everywhere with the claim evaluated by the TAILS (round 4's form; shipped: the round kernel's claim workgroup), with
     # and without the pipeline behind them (k_round_tail / the deferred tail of the first pipelined launch)
     "claim_in_tails": dict(ZK_CLAIM_IN_ROUND="0", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="3,7,11,13",
                            ZK_CHECK_FIELDS="2"),
-    # ... and switched off (round 4's schedule: hex rows up to 2^12 pairs, classic rounds above)
-    "mid_off": dict(ZK_PIPE_MID_MAX_PAIRS="0", ZK_CHECK_SIZES="14,16,18"),
 }
 _SWEEP_ENV_KEYS = ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES", "ZK_LEAD_MIN_PAIRS", "ZK_ROUND0_DOT29",
-                   "ZK_PIPE_MID_MAX_PAIRS", "ZK_CHECK_FIELDS", "ZK_CLAIM_IN_ROUND")
+                   "ZK_CHECK_FIELDS", "ZK_CLAIM_IN_ROUND")
 
 
 @pytest.fixture(scope="module")

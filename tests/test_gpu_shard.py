@@ -115,61 +115,6 @@ def test_shard_rounds_derive_behind_the_allreduce(shard_sweeps, name):
     assert r.returncode == 0 and "shard skip ok" in r.stdout, str(SHARD_RUNS[name]) + r.stdout + r.stderr
 
 
-OVERLAP_RUNS = {
-    # the three-stream schedule at the shipped size limit (rounds of at most 2^17 pairs), RCCL at one rank
-    "overlap_default_limit": dict(ZK_SHARD_OVERLAP="1"),
-    # every round k_round_mid can take (2^20 pairs), with an injected 7-us all-reduce: work, collective and transcript really overlap
-    "overlap_all_sizes_fake_latency": dict(ZK_SHARD_OVERLAP="1", ZK_SHARD_OVERLAP_MAX_PAIRS="1048576", ZK_SHARD_FAKE_ALLREDUCE_US="7", ZK_CHECK_FIELDS="3"),
-    # only the small rounds, entered from SKIP1 + LEAD classic rounds forced on at every size
-    "overlap_small_after_skip1_lead": dict(ZK_SHARD_OVERLAP="1", ZK_SHARD_OVERLAP_MAX_PAIRS="256", ZK_SKIP1_MIN_PAIRS="1", ZK_LEAD_MIN_PAIRS="1",
-                                           ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_FIELDS="1"),
-}
-
-
-@pytest.fixture(scope="module")
-def overlap_sweeps():
-    import os
-    import subprocess
-    import sys
-    from concurrent.futures import ThreadPoolExecutor
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    drop = ("ZK_SHARD_OVERLAP", "ZK_SHARD_OVERLAP_MAX_PAIRS", "ZK_SHARD_FAKE_ALLREDUCE_US", "ZK_SKIP1_MIN_PAIRS", "ZK_LEAD_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS",
-            "ZK_CHECK_FIELDS")
-    base = {k: v for k, v in os.environ.items() if k not in drop}
-
-    def child(extra):
-        return subprocess.run([sys.executable, os.path.join(root, "tests", "shard_overlap_check.py")], env=dict(base, **extra), capture_output=True,
-                              text=True, timeout=900)
-
-    pool = ThreadPoolExecutor(max_workers=3)
-    futures = {name: pool.submit(child, extra) for name, extra in OVERLAP_RUNS.items()}
-    yield futures
-    pool.shutdown(wait=True)
-
-
-@pytest.mark.parametrize("name", list(OVERLAP_RUNS))
-def test_overlapped_exchange_schedule_bit_exact(overlap_sweeps, name):
-    """ZK_SHARD_OVERLAP=1: zk_shard_prover_run with the per-round all-reduce off the critical path (work / collective / transcript streams,
-    pending-challenge sums exchanged one round ahead).  Same proof as the plain prover and the oracle, bit for bit
-    (tests/shard_overlap_check.py; sumcheck/src/prover.rs:44-68)."""
-    r = overlap_sweeps[name].result()
-    assert r.returncode == 0 and "shard overlap ok" in r.stdout, str(OVERLAP_RUNS[name]) + r.stdout + r.stderr
-
-
-def test_overlapped_exchange_schedule_across_processes():
-    """... and with real ranks: 2 and 4 OS processes on one GPU over the host transport (tests/test_gpu_multiproc.py run in a child pytest with
-    ZK_SHARD_OVERLAP=1; driver "lib" = zk_shard_prover_run), every rank holding the oracle's proof of the unsharded tables."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_multiproc.py"), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
-                       env=dict(os.environ, ZK_SHARD_OVERLAP="1", ZK_SHARD_OVERLAP_MAX_PAIRS="65536"), capture_output=True, text=True, timeout=900, cwd=root)
-    assert r.returncode == 0 and "passed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-
-
 def test_interleaved_shard_provers_and_plain_proofs_on_one_context():
     """The claim S_prev(r_prev) a SKIP1 round kernel parks for k_lanes_transcript stays live from round_begin to round_finish, i.e.
     across API calls: it belongs to the prover (ProverScratch), not to the context.  Two DIFFERENT sharded proofs (one rank each,

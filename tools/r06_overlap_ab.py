@@ -1,4 +1,6 @@
-"""the sharded loop with the all-reduce off the critical path (ZK_SHARD_OVERLAP=1: three streams, pending-challenge sums
+"""[HISTORICAL -- applies to commit 9312777: the ZK_SHARD_OVERLAP schedule lost to the serial loop up to A = 40 us and was removed
+together with k_round_mid; logs: profiles/r06_shard_overlap_ab.log, profiles/r06_shard_overlap_trace.log]
+VERDICT r05 item 5: the sharded loop with the all-reduce off the critical path (ZK_SHARD_OVERLAP=1: three streams, pending-challenge sums
 exchanged one round ahead) against the serial loop, at ONE rank through RCCL with an injected all-reduce latency A
 (ZK_SHARD_FAKE_ALLREDUCE_US: a spin kernel on the collective's stream after every all-reduce) standing in for A_8.
   n = 24, gather_below 13: the verdict's case (11 exchanging rounds, tables 2^24 .. 2^14)

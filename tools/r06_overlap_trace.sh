@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: measures the three-stream overlapped schedule (ZK_SHARD_OVERLAP) as it existed at commit 9312777; it lost to the serial loop up to A = 40 us
+# and was removed together with k_round_mid (profiles/r06_shard_overlap_ab.log, r06_shard_overlap_trace.log).  Check that commit out to re-run.
 # kernel timeline of the one-rank sharded prover (RCCL), overlapped schedule with an injected 15-us all-reduce: start / end of every kernel of the
 # last proof relative to its first launch, with the stream (queue) it ran on
 set -u

@@ -64,9 +64,6 @@ struct zk_ctx {
     uint8_t *h_absorb[2];   // pinned staging of absorb_tables (prove / verify), kept across calls
     size_t h_absorb_bytes;
     hipEvent_t ev_absorb[2];
-    hipStream_t aux_stream[2];          // the sharded prover's overlapped schedule (comm_host.inc): collective stream, transcript stream
-    std::vector<hipEvent_t> ev_ring;    // ... and its cross-stream edges
-    size_t ev_next;
 };
 struct zk_mle {
     zk_ctx *ctx;
@@ -341,8 +338,6 @@ extern "C" int32_t zk_ctx_create(int32_t field, int32_t device, zk_ctx **out) {
     c->h_absorb[0] = c->h_absorb[1] = nullptr;
     c->h_absorb_bytes = 0;
     c->ev_absorb[0] = c->ev_absorb[1] = nullptr;
-    c->aux_stream[0] = c->aux_stream[1] = nullptr;
-    c->ev_next = 0;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -383,12 +378,6 @@ extern "C" int32_t zk_ctx_destroy(zk_ctx *c) {
     }
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
-    for (int i = 0; i < 2; ++i)
-        if (c->aux_stream[i]) {
-            (void)hipStreamSynchronize(c->aux_stream[i]);
-            (void)hipStreamDestroy(c->aux_stream[i]);
-        }
-    for (hipEvent_t e : c->ev_ring) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->own_stream);
     delete c;
     return ZK_OK;
@@ -1104,7 +1093,7 @@ extern "C" int32_t zk_product_evaluate(zk_ctx *c, const zk_mle *const *f, uint64
 // Per-prover device scratch: the word sponge, the current challenge, and the proof being assembled.  Nothing in the
 // round loop waits on the host: k_round (+fold) -> k_round_tail (reduce + transcript) -> k_round (+fold) -> ...
 constexpr size_t kChalWords = kChallengeBytes / 8;                                   // one challenge record, in u64
-constexpr size_t kEpartBytes = (size_t)((kMidMaxWorkBlocks > kPipeMaxWorkBlocks ? kMidMaxWorkBlocks : kPipeMaxWorkBlocks) + 2) * 16 * 32;         // E partials of one pipelined round (+ total + counter)
+constexpr size_t kEpartBytes = (size_t)(kPipeMaxWorkBlocks + 2) * 16 * 32;         // E partials of one pipelined round (+ total + counter)
 constexpr size_t kChalBlockBytes = 2 * kChallengeBytes + 32;   // two challenge records + the claim element
 struct ProverScratch {
     WordSponge *d_sponge;
@@ -1501,7 +1490,7 @@ struct RoundState {
     // round - 1, before its challenge was known); `cur` still awaits that fold (pending_fold is true)
     bool pipe_active;
     uint32_t pipe_blocks;             // work blocks that wrote them
-    bool pipe_total;                  // slot 0 of their buffer holds the total (k_round_pipe, k_round_mid with a totalling last block);
+    bool pipe_total;                  // slot 0 of their buffer holds the total (k_round_pipe: the block that finishes last adds them up);
                                       // false: the next launch's transcript block (or the finisher) adds the pipe_blocks partials up
     FinishPublish pub;                // flag != null: the pipelined finisher, being the call's last launch, publishes the proof block itself
     bool published;                   // ... and has been enqueued with that job
@@ -1630,28 +1619,7 @@ static uint64_t pipe_max_pairs() {
     }();
     return v;
 }
-// Above pipe_max_pairs() and up to this many pairs the same schedule can run on k_round_mid (four lanes per pair index instead of
-// a sixteen-lane row): ZK_PIPE_MID_MAX_PAIRS.  DEFAULT 0 = no such rounds: measured on MI355X (profiles/r05_mid_rounds_ab.log) a
-// k_round_mid launch takes 11.4 / 15.5 / 22.8 us at 2^13 / 2^14 / 2^15 pairs (17.5 / 22 / 36 us in its first version) against
-// 16.4 / 18.3 / 21.6 us for the classic round kernel + k_round_tail it replaces, and end to end the provers tie (n = 20 0.328-0.330
-// vs 0.326-0.332 ms).  The kernel stays (bit-exact under the whole prover grid, tests/test_gpu_parity.py) as the measured answer to
-// "pipeline the middle rounds".
-static uint64_t pipe_mid_max_pairs() {
-    static const uint64_t v = [] {
-        uint64_t x = env_u64("ZK_PIPE_MID_MAX_PAIRS", 0, 0, (uint64_t)1 << 40);
-        if (!pipe_max_pairs()) return (uint64_t)0;   // ZK_PIPE_MAX_PAIRS=0 switches every pipelined round off (1: k_round_mid takes them all)
-        return x > mid_max_pairs() ? mid_max_pairs() : x;
-    }();
-    return v;
-}
-// ZK_PIPE_MID_TOTAL=1: k_round_mid's last block adds the block partials up (fence + counter + reduction at the end of the launch);
-// default 0: the next launch's transcript block does
-static bool mid_totals() {
-    static const bool v = env_u64("ZK_PIPE_MID_TOTAL", 0, 0, 1) != 0;
-    return v;
-}
-static inline uint64_t pipe_limit_pairs() { return std::max(pipe_max_pairs(), pipe_mid_max_pairs()); }
-static inline bool pipe_use_mid(uint64_t q) { return q > pipe_max_pairs(); }
+static inline uint64_t pipe_limit_pairs() { return pipe_max_pairs(); }
 static bool pipe_shape(const RoundState &st, int *k, int *extra) {
     if (st.terms.n_terms == 1) {
         *k = st.terms.term_k[0];
@@ -1785,8 +1753,6 @@ static int32_t pipe_enter(RoundState &st, const DeferredTail &dt) {
     pl.fold = false;
     pl.emit = 1;
     pl.q = (uint64_t)1 << (st.vars_left - 2);   // vars_left = variables of this round's table (after its fold)
-    pl.mid = pipe_use_mid(pl.q);
-    pl.mid_total = pl.mid && mid_totals();
     pl.chal_fold = nullptr;
     pl.e_partials = epart_of_round(st, st.round + 1);
     pl.done_counter = epart_counter(st, st.round + 1);
@@ -1808,7 +1774,7 @@ static int32_t pipe_enter(RoundState &st, const DeferredTail &dt) {
     }
     st.pipe_active = true;
     st.pipe_blocks = g;
-    st.pipe_total = !pl.mid || pl.mid_total;
+    st.pipe_total = true;
     return ZK_OK;
 }
 // Pipelined state at round s = st.round: cur = table of round s-1 (vars_left variables), its challenge r_{s-1} pending, E_s
@@ -1828,8 +1794,6 @@ static int32_t pipe_step(RoundState &st) {
     pl.emit = stay ? 1 : 0;
     pl.q = m >= 3 ? (uint64_t)1 << (m - 3) : 0;
     if (pl.q == 0) return ZK_ERR_BAD_ARG;        // cannot happen: the finisher takes tables this small
-    pl.mid = pipe_use_mid(pl.q);
-    pl.mid_total = pl.mid && mid_totals();
     pl.chal_fold = chal_prev(st);
     pl.e_partials = epart_of_round(st, st.round + 1);
     pl.done_counter = epart_counter(st, st.round + 1);
@@ -1854,7 +1818,7 @@ static int32_t pipe_step(RoundState &st) {
     st.vars_left = m - 1;                        // cur = table of round s, r_s pending
     st.pipe_active = stay;
     st.pipe_blocks = g;
-    st.pipe_total = !pl.mid || pl.mid_total;
+    st.pipe_total = true;
     ++st.round;
     return ZK_OK;
 }

@@ -842,12 +842,9 @@ __global__ void k_store_sponge_b(BatchOf<SpongeSlot> b) {
 // dv: the round kernels left out the t = 1 sums (prev_rp != null: S(1) = S_prev(r_prev) - S(0), the identity holds for the GLOBAL
 // sums) and / or put the leading coefficient in slot D (lead: the slot is linear in the shards, so its all-reduced value is the
 // global leading coefficient) -- the same derivations k_round_tail makes on one GPU, made here on the all-reduced values.
-// canon (optional): the record also gets the prepared CANONICAL form of the challenge (common.cuh kChalCanonWord) -- a pipelined transcript
-// block closes the NEXT round with it (the sharded prover's overlapped schedule); k266 = the limbs of 2^266 mod p (PipeConsts)
 __global__ __launch_bounds__(128) void k_lanes_transcript(const uint64_t *__restrict__ lanes, uint32_t ns, WordSponge *__restrict__ sponge,
                                                           uint64_t *__restrict__ out_rp, uint64_t *__restrict__ out_ch,
-                                                          uint64_t *__restrict__ d_challenge, FieldParams P, TailDerive dv, int canon = 0,
-                                                          Mul29 k266 = {}) {
+                                                          uint64_t *__restrict__ d_challenge, FieldParams P, TailDerive dv) {
     __shared__ Fe fin[256];
     __shared__ Fe claim_s;
     if (blockIdx.x != 0 || threadIdx.x >= 128) return;   // two waves, wave-uniform control flow
@@ -917,23 +914,7 @@ __global__ __launch_bounds__(128) void k_lanes_transcript(const uint64_t *__rest
     lane_absorb_elems(sp, L, fin, ns, P);
     Mul29 ch29;
     Fe ch;
-    const Fe x = lane_squeeze_x(sp, L);
-    if (canon) {
-        // three forms from ONE multiplication with per-lane multipliers: lane 0 prepared (R^2 2^5), lane 16 Montgomery (R^2), lane 32 the
-        // prepared canonical form (2^266: x * 2^5 mod p)
-        Mul29 kk;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) kk.l[i] = L.lane == 16 ? P.r2_29[i] : (L.lane == 32 ? k266.l[i] : P.r2s_29[i]);
-        ch = fe_mul29(x, kk, P);
-        split29(ch.v, ch29.l);
-        if (L.lane == 32) {
-            uint32_t *rec = reinterpret_cast<uint32_t *>(d_challenge) + kChalCanonWord;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) rec[i] = ch29.l[i];
-        }
-    } else {
-        challenge_forms(x, (uint32_t)L.lane, P, ch29, ch);
-    }
+    challenge_forms(lane_squeeze_x(sp, L), (uint32_t)L.lane, P, ch29, ch);
     publish_challenge_forms(d_challenge, out_ch, ch, ch29, (uint32_t)L.lane);
     lane_sponge_store(sponge, sp, L);
 }

@@ -99,7 +99,6 @@ int launch_round_single_t(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k,
 
 // ---- pipelined rounds (pipe_kernels.cuh / pipe.hip): sums of round s as a polynomial in the pending challenge -------------
 constexpr uint32_t kPipeMaxWorkBlocks = 256;   // k_round_pipe (hex rows)
-constexpr uint32_t kMidMaxWorkBlocks = 512;    // k_round_mid (quads): also the capacity of an E-partial buffer
 }  // namespace zk
 #include "pipe_args.hpp"
 namespace zk {
@@ -107,8 +106,6 @@ struct PipeLaunch {
     int k, extra;             // shape: k-factor product (+ one single-factor term)
     uint32_t D;
     bool fold;                // work blocks first fold fp.in (8q elements) -> fp.out (4q) at *chal_fold
-    bool mid;                 // k_round_mid (four lanes per pair index) instead of k_round_pipe's sixteen-lane rows
-    bool mid_total;           // ... whose last block adds the block partials up (slot 0); false: the next launch's transcript block does
     int emit;                 // 1: write the E partials of the round with q pairs; 0: fold only (leaving the pipeline)
     uint64_t q;               // pairs of the round whose E is prepared
     const uint64_t *chal_fold;
@@ -120,11 +117,7 @@ bool pipe_shape_ok(int k, uint32_t D, int extra);
 uint32_t pipe_values_per_block(int k, uint32_t D);
 uint32_t pipe_rows_per_block(int k, uint32_t D, int extra);
 uint32_t pipe_work_blocks(int k, uint32_t D, int extra, uint64_t q);
-uint64_t mid_max_pairs();   // pair indices one k_round_mid launch can take (grid cap x unreduced products per lane)
 int launch_round_pipe(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t *out_work_blocks);
-// the transcript block alone (one workgroup on lc.stream): closes a round whose E totals arrive as all-reduced digit lanes (ta.lanes_in) --
-// the sharded prover's overlapped schedule runs it on its own stream beside the work launches
-int launch_pipe_tail_only(const RoundLaunchCtx &lc, int k, uint32_t D, int extra, const PipeTailArgs &ta);
 // ZK_SHARD_FAKE_ALLREDUCE_US: `us` microseconds of one spinning wave on `stream`
 int launch_spin_us(hipStream_t stream, uint32_t us);
 // the pipelined finisher (k_finish_pipe): every remaining round in one launch; entry = kFinEntry* of pipe_kernels.cuh

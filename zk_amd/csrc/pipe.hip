@@ -66,63 +66,6 @@ static void launch_shape(const RoundLaunchCtx &lc, const FactorPtrs &fp, const P
     (void)single();
 }
 
-// k_round_mid: one pair index per quad and pass.  As many blocks as one pass needs, up to the cap (the launch ends with ONE block
-// adding all the block partials up: ~1 us per 128 of them), then more passes (at most kMaxLazy: unreduced products per lane).
-uint64_t mid_max_pairs() { return (uint64_t)kMidMaxWorkBlocks * kMidQuads * kMaxLazy; }
-static uint32_t mid_work_blocks(uint64_t q) {
-    uint64_t g = (q + kMidQuads - 1) / kMidQuads;
-    if (g > kMidMaxWorkBlocks) g = kMidMaxWorkBlocks;
-    return (uint32_t)(g ? g : 1);
-}
-template <int K, int D, int EXTRA>
-static void launch_mid_shape(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t g) {
-    const FieldParams *P = lc.P;
-    hipStream_t st = lc.stream;
-    const PipeLaunch l = pl;
-    auto single = [=]() {
-        if (l.fold)
-            k_round_mid<K, D, EXTRA, true><<<g + 1, kMidThreads, 0, st>>>(fp, l.q, l.emit, *P, l.chal_fold, l.e_partials, l.done_counter, l.tail, l.mid_total ? 1 : 0);
-        else
-            k_round_mid<K, D, EXTRA, false><<<g + 1, kMidThreads, 0, st>>>(fp, l.q, l.emit, *P, l.chal_fold, l.e_partials, l.done_counter, l.tail, l.mid_total ? 1 : 0);
-        return hipGetLastError();
-    };
-    if (!batch_record_other(single)) (void)single();   // (off by default; no batched twin)
-}
-static int launch_round_mid(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t *out_work_blocks) {
-    if (pl.q > mid_max_pairs()) return kLaunchUnsupported;
-    const uint32_t g = mid_work_blocks(pl.q);
-    switch (pl.k * 100 + (int)pl.D * 10 + pl.extra) {
-        case 110: launch_mid_shape<1, 1, 0>(lc, fp, pl, g); break;
-        case 120: launch_mid_shape<1, 2, 0>(lc, fp, pl, g); break;
-        case 220: launch_mid_shape<2, 2, 0>(lc, fp, pl, g); break;
-        case 230: launch_mid_shape<2, 3, 0>(lc, fp, pl, g); break;
-        case 330: launch_mid_shape<3, 3, 0>(lc, fp, pl, g); break;
-        case 221: launch_mid_shape<2, 2, 1>(lc, fp, pl, g); break;
-        default: return kLaunchUnsupported;
-    }
-    if (hipGetLastError() != hipSuccess) return kLaunchHipError;
-    *out_work_blocks = g;
-    return kLaunchOk;
-}
-
-template <int K, int D, int EXTRA>
-static void launch_tail_only_shape(const RoundLaunchCtx &lc, const PipeTailArgs &ta) {
-    const FactorPtrs none = {};
-    k_round_mid<K, D, EXTRA, false><<<1, kMidThreads, 0, lc.stream>>>(none, 0, 0, *lc.P, nullptr, nullptr, nullptr, ta, 0);
-}
-int launch_pipe_tail_only(const RoundLaunchCtx &lc, int k, uint32_t D, int extra, const PipeTailArgs &ta) {
-    if (!pipe_shape_ok(k, D, extra) || ta.mode < 0) return kLaunchUnsupported;
-    switch (k * 100 + (int)D * 10 + extra) {
-        case 110: launch_tail_only_shape<1, 1, 0>(lc, ta); break;
-        case 120: launch_tail_only_shape<1, 2, 0>(lc, ta); break;
-        case 220: launch_tail_only_shape<2, 2, 0>(lc, ta); break;
-        case 230: launch_tail_only_shape<2, 3, 0>(lc, ta); break;
-        case 330: launch_tail_only_shape<3, 3, 0>(lc, ta); break;
-        case 221: launch_tail_only_shape<2, 2, 1>(lc, ta); break;
-        default: return kLaunchUnsupported;
-    }
-    return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchHipError;
-}
 int launch_spin_us(hipStream_t stream, uint32_t us) {
     k_spin_us<<<1, 1, 0, stream>>>(us);
     return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchHipError;
@@ -130,7 +73,6 @@ int launch_spin_us(hipStream_t stream, uint32_t us) {
 
 int launch_round_pipe(const RoundLaunchCtx &lc, const FactorPtrs &fp, const PipeLaunch &pl, uint32_t *out_work_blocks) {
     if (!pipe_shape_ok(pl.k, pl.D, pl.extra)) return kLaunchUnsupported;
-    if (pl.mid) return launch_round_mid(lc, fp, pl, out_work_blocks);
     const uint32_t g = pipe_work_blocks(pl.k, pl.D, pl.extra, pl.q);
     switch (pl.k * 100 + (int)pl.D * 10 + pl.extra) {
         case 110: launch_shape<1, 1, 0>(lc, fp, pl, g); break;

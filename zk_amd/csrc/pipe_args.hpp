@@ -33,10 +33,6 @@ struct PipeTailArgs {
     PipeConsts pc;
     TailDerive dv;              // mode 0 after a SKIP1 round kernel
     uint64_t *dbg;              // optional: 100 MHz timestamps of the phases (ZK_PIPE_DEBUG), 32 slots per launch
-    // sharded prover, overlapped schedule (comm_host.inc): the E totals cross the ranks as digit lanes.
-    const uint64_t *lanes_in;   // transcript block: n_in values as 8 uint64 digit sums each (all-reduced) instead of `partials` (mode 1)
-    uint64_t *lanes_out;        // work-only launch (mode < 0, k_round_mid with totals): the last block also writes its totals as digit lanes
-    uint32_t log_world;         // lanes_in: each value is below 2^log_world * p
 };
 
 }  // namespace zk

@@ -357,26 +357,7 @@ ZK_D void pipe_tail_block(const PipeTailArgs &ta, const FieldParams &P) {
     if (wave0) dbg_stamp(ta.dbg, 0);
     if (wave0) sp = lane_sponge_load(ta.sponge, L);   // in flight while the partials are reduced
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (ta.lanes_in) {       // sharded, overlapped schedule: the totals of all ranks as digit sums -> carry, mod p (k_lanes_transcript's ladder)
-        if (wave >= 2) return;
-        if (wave0 && lane < 16 && lane < ta.n_in) {
-            uint32_t v[9];
-            uint64_t carry = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                carry += ta.lanes_in[8 * lane + i];
-                v[i] = (uint32_t)carry;
-                carry >>= 32;
-            }
-            v[8] = (uint32_t)carry;
-            if (ta.log_world <= 3) ladder9<4>(v, P);
-            else ladder9<16>(v, P);
-            Fe r;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) r.v[i] = v[i];
-            red[lane] = r;
-        }
-    } else if (ta.nblocks == 1) {   // already reduced (the last work block of the launch before did it)
+    if (ta.nblocks == 1) {   // already reduced (the last work block of the launch before did it)
         if (wave >= 2) return;
         if (wave0 && lane < 16 && lane < ta.n_in) red[lane] = fe_load(ta.partials, lane);
     } else {
@@ -583,202 +564,6 @@ __global__ __launch_bounds__((pipe_block_threads<K, D, EXTRA>())) void k_round_p
     round_pipe_body<K, D, EXTRA, FOLD>(fp, q, emit, P, a.chal_fold, a.e_partials, a.done_counter, a.ta, sc1_handoff);
 }
 
-// ---- the same launch for MIDDLE rounds: four lanes per pair index, one NODE per lane -------------------------------------------
-// k_round_pipe's "hex" rows give a pair index sixteen lanes and three LDS exchanges: right for rounds that are pure latency (a few
-// thousand pair indices), ~6x the instructions of a throughput kernel above that.  k_round_mid covers the rounds in between
-// (ZK_PIPE_MAX_PAIRS < pairs <= ZK_PIPE_MID_MAX_PAIRS) with the quad layout of k_round_quad:
-//   A  lane c of the quad folds value c of EVERY factor (a_c = T[j + c q] folded with T[j + (c+4) q]: NF multiplications), stores it
-//      (the table of the next round) and hands it to the other three lanes by DPP quad_perm broadcasts -- no LDS;
-//   B  lane c is NODE c (0, inf, 1, -1): from a_0..a_3 of a factor it selects the factor's value at its node for t = 0 and t = 1
-//      (u | w-u | w | 2u-w of the pairs (a_0, a_2) and (a_1, a_3), by bit masks: the node is lane-dependent) and steps on to
-//      t = 2..D by adding their difference (every node value is linear in t); the product over the factors follows as in
-//      k_round_kd (K - 1 multiplications per t, the last one accumulated unreduced).  K = 2 leaves lane 3 without a node: its
-//      masks are zero and it accumulates zeros.
-// Same E partials, same last-block total, same transcript block (pipe_tail_block) as k_round_pipe, so the host schedule and the
-// finisher do not care which of the two prepared a round.  Exact field arithmetic: same canonical E values as the hex rows.
-constexpr int kMidThreads = kPipeThreads;   // (block 0 is the transcript block: pipe_tail_block is written for 256 threads)
-constexpr int kMidQuads = kMidThreads / 4;
-struct NodeMasks {
-    uint32_t u, v, w, x;   // all-ones for the one combination this lane's node takes
-};
-template <bool WITH_INF, bool WITH_MINUS>
-ZK_D Fe node_value(const Fe &p, const Fe &q, const NodeMasks &m, const FieldParams &P) {   // p: challenge 0, q: challenge 1
-    Fe o;
-    if constexpr (!WITH_INF && !WITH_MINUS) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o.v[i] = (p.v[i] & m.u) | (q.v[i] & m.w);
-        return o;
-    }
-    const Fe d = fe_sub(q, p, P);
-    if constexpr (!WITH_MINUS) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o.v[i] = (p.v[i] & m.u) | (WITH_INF ? (d.v[i] & m.v) : 0u) | (q.v[i] & m.w);
-    } else {
-        const Fe x = fe_sub(p, d, P);   // 2p - q
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o.v[i] = (p.v[i] & m.u) | (WITH_INF ? (d.v[i] & m.v) : 0u) | (q.v[i] & m.w) | (x.v[i] & m.x);
-    }
-    return o;
-}
-// Element store that leaves no dirty line in the XCD's L2 (global_store_dwordx4 sc0 sc1: write-through).  k_round_mid ends every
-// work block with an agent-scope release (buffer_wbl2: "write back this L2's dirty lines"), and with plain stores that write-back
-// had the block's 16 KB of freshly folded table to push out first -- 17-39 us per launch instead of 8-12
-// (MI355X_MICROARCH.md: release ~1.7 us clean, ~6.5 us with 16 KB dirtied per block; publish-large).
-ZK_D void fe_store_wt(uint64_t *base, uint64_t idx, const Fe &r) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM)
-    u32x4_t *q = reinterpret_cast<u32x4_t *>(base + 4 * idx);
-    const u32x4_t lo = {r.v[0], r.v[1], r.v[2], r.v[3]}, hi = {r.v[4], r.v[5], r.v[6], r.v[7]};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1" ::"v"(q), "v"(lo), "v"(hi) : "memory");
-#else
-    fe_store(base, idx, r);
-#endif
-}
-template <int F, int K, int D, int EXTRA, bool FOLD>
-ZK_D void mid_factor(const FactorPtrs &fp, const Fe &x, const Fe &y, uint64_t j, uint64_t q, bool live, uint32_t c, const Mul29 &r, const NodeMasks &m,
-                     Fe (&prod)[D + 1], WideAcc (&acc)[D + 1], Fe (&sum)[D + 1], const FieldParams &P) {
-    constexpr int NS = D + 1;
-    // ---- A: this lane's value of factor F (x, y: its two table elements, loaded by the caller for ALL factors before any arithmetic)
-    Fe a = x;
-    if constexpr (FOLD) {
-        a = fe_sub(x, fe_mul29(fe_sub(x, y, P), r, P), P);   // evaluation_form.rs:68
-        if (live) fe_store_wt(fp.out[F], j + (uint64_t)c * q, a);
-    }
-    const Fe a0 = quad_bcast<0>(a), a1 = quad_bcast<1>(a), a2 = quad_bcast<2>(a), a3 = quad_bcast<3>(a);
-    // ---- B: the factor's value at this lane's node, t = 0 and t = 1, then linear in t
-    constexpr bool kExtraTerm = F == K;   // the single-factor term: linear in the challenge, no r^K part
-    Fe v0, v1;
-    if constexpr (kExtraTerm) {
-        v0 = node_value<false, (K == 3)>(a0, a2, m, P);
-        v1 = node_value<false, (K == 3)>(a1, a3, m, P);
-    } else {
-        v0 = node_value<true, (K == 3)>(a0, a2, m, P);
-        v1 = node_value<true, (K == 3)>(a1, a3, m, P);
-    }
-    const Fe diff = fe_sub(v1, v0, P);
-    Fe v = v0;
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-        if (t == 1) v = v1;
-        else if (t > 1) v = fe_add(v, diff, P);
-        if constexpr (kExtraTerm || K == 1) sum[t] = fe_add(sum[t], v, P);
-        else if constexpr (F == 0) prod[t] = v;
-        else if constexpr (F < K - 1) prod[t] = fe_mul(prod[t], v, P);
-        else wide_mac(acc[t], prod[t].v, v.v);
-    }
-}
-// grid: block 0 = transcript block, blocks 1.. = work (at most kMaxLazy pair indices per quad: the host sizes the grid)
-template <int K, int D, int EXTRA, bool FOLD>
-__global__ __launch_bounds__(kMidThreads) void k_round_mid(FactorPtrs fp, uint64_t q, int emit, FieldParams P, const uint64_t *__restrict__ chal_fold,
-                                                           uint64_t *__restrict__ e_partials, uint32_t *done_counter, PipeTailArgs ta, int total) {
-    using S = PipeShape<K, D, EXTRA>;
-    constexpr int NS = S::NS, NR = S::NR, NE = S::NE, kWaves = kMidThreads / 64;
-    if (blockIdx.x == 0) {
-        if (ta.mode >= 0) pipe_tail_block<K, D>(ta, P);   // (mode < 0: a work-only launch -- the sharded prover closes rounds on another stream)
-        return;
-    }
-    __shared__ Fe redw[kWaves][16];
-    __shared__ uint32_t is_last;
-    __shared__ Fe lred[16];
-    __shared__ Fe lstage[4][16];
-    const uint32_t wb = blockIdx.x - 1, nwork = gridDim.x - 1;
-    Mul29 r = {};
-    if (FOLD) r = load_challenge29(chal_fold);
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 3;
-    NodeMasks m;
-    m.u = c == (uint32_t)kPipeNodeZero ? 0xffffffffu : 0u;
-    m.v = c == (uint32_t)kPipeNodeInf ? 0xffffffffu : 0u;
-    m.w = (c == (uint32_t)kPipeNodeOne && K >= 2) ? 0xffffffffu : 0u;
-    m.x = (c == (uint32_t)kPipeNodeMinus && K == 3) ? 0xffffffffu : 0u;
-    Fe prod[NS], sum[NS];
-    WideAcc acc[NS];
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-        prod[t] = fe_zero();
-        sum[t] = fe_zero();
-        wide_zero(acc[t]);
-    }
-    const uint64_t stride = (uint64_t)nwork * kMidQuads;
-    for (uint64_t j0 = (uint64_t)wb * kMidQuads; j0 < q; j0 += stride) {   // j0 is block-uniform
-        const uint64_t j = j0 + (threadIdx.x >> 2);
-        const bool live = j < q;
-        if (emit) {
-            Fe x[S::NF], y[S::NF];   // every load of this pair index is issued before any arithmetic: one memory round trip per pass
-#pragma unroll
-            for (int f = 0; f < S::NF; ++f) {
-                x[f] = fe_zero();
-                y[f] = fe_zero();
-                if (live) {
-                    x[f] = fe_load(fp.in[f], j + (uint64_t)c * q);
-                    if constexpr (FOLD) y[f] = fe_load(fp.in[f], j + (uint64_t)(c + 4) * q);
-                }
-            }
-            mid_factor<0, K, D, EXTRA, FOLD>(fp, x[0], y[0], j, q, live, c, r, m, prod, acc, sum, P);
-            if constexpr (K + EXTRA > 1) mid_factor<1, K, D, EXTRA, FOLD>(fp, x[1], y[1], j, q, live, c, r, m, prod, acc, sum, P);
-            if constexpr (K + EXTRA > 2) mid_factor<2, K, D, EXTRA, FOLD>(fp, x[2], y[2], j, q, live, c, r, m, prod, acc, sum, P);
-            if constexpr (K + EXTRA > 3) mid_factor<3, K, D, EXTRA, FOLD>(fp, x[3], y[3], j, q, live, c, r, m, prod, acc, sum, P);
-        } else if (FOLD && live) {   // the launch that leaves the pipeline: fold only
-#pragma unroll
-            for (int f = 0; f < S::NF; ++f) {
-                const Fe x = fe_load(fp.in[f], j + (uint64_t)c * q), y = fe_load(fp.in[f], j + (uint64_t)(c + 4) * q);
-                fe_store_wt(fp.out[f], j + (uint64_t)c * q, fe_sub(x, fe_mul29(fe_sub(x, y, P), r, P), P));
-            }
-        }
-    }
-    if (!emit) return;
-    // per lane: E(t; node c) of its pair indices.  Sum over the sixteen quads of the wave keeping the four nodes apart.
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-        Fe e = sum[t];
-        if constexpr (K >= 2) e = fe_add(redc_wide(acc[t], P), sum[t], P);
-        Fe a, b;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const auto x = __builtin_amdgcn_permlane32_swap(e.v[i], e.v[i], false, false);
-            a.v[i] = x[0];
-            b.v[i] = x[1];
-        }
-        e = fe_add(a, b, P);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const auto x = __builtin_amdgcn_permlane16_swap(e.v[i], e.v[i], false, false);
-            a.v[i] = x[0];
-            b.v[i] = x[1];
-        }
-        e = fe_add(a, b, P);
-        e = fe_add(e, fe_dpp<0x128>(e), P);   // row_ror:8
-        e = fe_add(e, fe_dpp<0x12C>(e), P);   // row_ror:12 -> every lane: the total of its node
-        if (lane < 4 && lane < (uint32_t)NR) redw[wave][t * NR + lane] = e;
-    }
-    __syncthreads();
-    if (threadIdx.x < (uint32_t)NE) {
-        Fe tot = redw[0][threadIdx.x];
-#pragma unroll
-        for (int w = 1; w < kWaves; ++w) tot = fe_add(tot, redw[w][threadIdx.x], P);
-        fe_store(e_partials, (uint64_t)(wb + 1) * NE + threadIdx.x, tot);   // slot 0 is the total
-    }
-    // total == 0: the per-block partials are the launch's result -- the NEXT launch's transcript block adds them up (it has the time: in
-    // these rounds the work blocks, not the transcript block, decide when a launch ends), and this one ends without fence, counter or a
-    // last block's reduction (~4 us of its chain)
-    if (!total) return;
-    // the block that finishes last adds the partials up (as k_round_pipe: release / acquire at agent scope)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        is_last = atomicAdd(done_counter, 1u) == nwork - 1 ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    pipe_reduce_partials(e_partials + NE * 4, nwork, NE, lred, lstage, P);
-    if (threadIdx.x < (uint32_t)NE) {
-        fe_store(e_partials, threadIdx.x, lred[threadIdx.x]);
-        if (ta.lanes_out) {   // sharded, overlapped schedule: this rank's totals as zero-extended 32-bit digits for the all-reduce
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ta.lanes_out[8 * threadIdx.x + i] = (uint64_t)lred[threadIdx.x].v[i];
-        }
-    }
-    if (threadIdx.x == 0) *done_counter = 0;   // ready for the next launch that uses this buffer
-}
 // ZK_SHARD_FAKE_ALLREDUCE_US: a stand-in for the latency of a multi-rank all-reduce on a one-rank communicator (spins on the 100 MHz clock)
 __global__ void k_spin_us(uint32_t us) {
     const uint64_t t0 = wall_clock64();
