@@ -804,6 +804,22 @@ def main():
                 "k_zeta_first (11 index bits per 2^11-entry LDS tile, built from the sorted term list: the table is written, never read) + "
                 "k_zeta_tile x 2 (7 and 6 index bits, one read and one write each); algorithmic bytes = the table written once (32 * 2^24); "
                 "the three passes move 5 x that (PMC: profiles/r05_zeta_ab_and_pmc.log)")
+            # ... and with 2^16 terms (a list this long is uploaded as given and ordered on the device: zeta_sort.hip)
+            keys16 = np.unique(rng_c.integers(0, 1 << n, 1 << 16, dtype=np.uint64))
+            co16 = zk_amd.MultiLinearPolynomial.random(ctx, 16, 0xC0EF16, 0).evaluation_slice()[:len(keys16)]
+            cf16 = zk_amd.CoeffMultilinearPolynomial.new_with_coefficient(field, n, {int(k_): c_ for k_, c_ in zip(keys16, co16)})
+            cf16.to_evaluation_form(ctx).free()
+            ts = []
+            for _ in range(5):
+                ctx.synchronize()
+                t1 = time.perf_counter()
+                ev_t = cf16.to_evaluation_form(ctx)
+                ctx.synchronize()
+                ts.append(time.perf_counter() - t1)
+                ev_t.free()
+            row("coeff_to_evaluation_2p24_64k_terms", sorted(ts)[2], 32 << n,
+                f"{len(keys16)} terms uploaded as given (2.6 MB from pageable host memory), ordered on the device (k_term_indices + rocPRIM radix sort), then the "
+                "same three passes; round 5: 3.53 ms with the list sorted and merged on the host")
             extra["rows_2p24"] = rows
             # config[3]: GKR-shaped load -- no gkr crate exists in the reference; what it would call is
             # prove_partial on one ProductPoly per layer: depth 8, width 2^20, product of 3 MLEs, degree 3

@@ -383,6 +383,7 @@ int32_t zk_bench_copy(zk_ctx *ctx, uint64_t bytes, int32_t reps, double *out_gbp
    ZK_EVAL_STREAM_LEAVE    8 / 9     7 .. 12      variables the streaming launch leaves (log2 of its grid): 8 at 21 variables, 9 above
    ZK_EVAL_WEIGHT          3         0 .. 3       bit 0 / bit 1: k_eval_low / k_eval_stream weight their outputs (no second bulk launch)
    ZK_ZETA_GLOBAL          off       flag         to_evaluation_form by global passes of three index bits (round 4's path)
+   ZK_ZETA_DEVICE_SORT_MIN 4096      0 .. 2^40    to_evaluation_form: term lists at least this long are ordered on the device (0: always)
    ZK_NTT_FULL_TABLE_MAX_LOG 24      0 .. 24      largest inter-pass twiddle table (log2 entries) kept in HBM; smaller: composed per element (slower, less traffic)
    ZK_TO_BYTES_THREADS     affinity  1 .. 4       host threads copying to_bytes chunks to the caller (default: CPUs allowed, at most 4)
    ZK_PUBLISH_IN_FINISHER  1         0 .. 1       0: the proof block always goes to pinned host memory by a launch of its own (k_publish_host)

@@ -302,6 +302,68 @@ def test_to_evaluation_form_tiled_equals_global_passes():
     assert outs[0] == outs[1]
 
 
+def _raw_coeff_to_evaluation(c, n_vars, keys, coeffs):
+    """zk_coeff_to_evaluation on the caller's arrays as they are (duplicate keys included: the library sums them as the reference's BTreeMap does)"""
+    from zk_amd._lib import c as C, check, lib, u64p
+
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    h = C.c_void_p()
+    check(lib.zk_coeff_to_evaluation(c._h, n_vars, keys.ctypes.data_as(u64p), coeffs.ctypes.data_as(u64p), len(keys), C.byref(h)))
+    return MLE(c, h)
+
+
+_LONG_LIST_CHILD = r"""
+import sys, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+import zk_amd
+from zk_amd._lib import c as C, check, lib, u64p
+f = zk_amd.BN254_FR
+ctx = zk_amd.Context(f, 0)
+for n, m in ((20, 1 << 16), (24, 1 << 16), (13, 1 << 14)):
+    rng = np.random.default_rng(1000 + n)
+    keys = rng.integers(0, 1 << n, m, dtype=np.uint64)          # unsorted, with repeats
+    co = zk_amd.MultiLinearPolynomial.random(ctx, 16, 77 + n, 0).evaluation_slice()[:m]
+    h = C.c_void_p()
+    check(lib.zk_coeff_to_evaluation(ctx._h, n, keys.ctypes.data_as(u64p), co.ctypes.data_as(u64p), m, C.byref(h)))
+    t = zk_amd.MultiLinearPolynomial(ctx, h)
+    print("DIGEST", n, hashlib.sha256(t.evaluation_slice().tobytes()).hexdigest())
+    t.free()
+"""
+
+
+def test_to_evaluation_form_long_term_lists_ordered_on_the_device():
+    """coefficient_form.rs:340-347 with a LONG term list: from 4096 terms the list is uploaded as given and ordered on the device
+    (zeta_sort.hip; the first pass sums runs of equal keys itself -- BTreeMap semantics, :164-171).  (a) 6000 terms over 2^12 keys (many
+    repeats) against the oracle's direct definition; (b) 2^14 .. 2^16 unsorted terms with repeats at n = 13 / 20 / 24: the device-ordered
+    table equals the host-ordered one bit for bit (child processes, ZK_ZETA_DEVICE_SORT_MIN moved either way)."""
+    for field in FIELDS:
+        c = ctx_for(field)
+        n, m = 12, 6000
+        rng = np.random.default_rng(12000 + field)
+        keys = rng.integers(0, 1 << n, m, dtype=np.uint64)
+        coeffs = orc.fill_random(field, 12345 + field, m)
+        got = _raw_coeff_to_evaluation(c, n, keys, coeffs)
+        assert np.array_equal(got.evaluation_slice(), orc.coeff_to_evaluation(field, n, keys, coeffs)), field
+        got.free()
+    outs = []
+    for env in ({"ZK_ZETA_DEVICE_SORT_MIN": "0"}, {"ZK_ZETA_DEVICE_SORT_MIN": str(1 << 40)}, {}):
+        r = subprocess.run([sys.executable, "-c", _LONG_LIST_CHILD % ROOT], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")])
+    assert len(outs[0]) == 3 and outs[0] == outs[1] == outs[2]
+
+
+def test_to_evaluation_form_every_arity_with_the_device_sort_forced():
+    """the every-arity / term-class grid above with EVERY list ordered on the device (ZK_ZETA_DEVICE_SORT_MIN=0, child pytest): empty
+    tiles, tile heads, one-tile lists and the constant term through k_term_indices + rocPRIM's radix sort + the permuted first pass"""
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_to_evaluation_form_every_arity_and_term_class or test_ref_to_evaluation_form_kat_and_random"],
+                       env=dict(os.environ, ZK_ZETA_DEVICE_SORT_MIN="0"), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "passed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 # ------------------------------------------------------------------ product / round sums vs oracle
 @pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k", [1, 2, 3, 5])

@@ -936,6 +936,65 @@ extern "C" int32_t zk_coeff_to_evaluation(zk_ctx *c, uint64_t n_vars, const uint
         return ZK_ERR_BAD_ARG;
     }
 }
+// lists longer than this are ordered on the device (zeta_sort.hip): the host's sort + merge + upload of 2^16 terms took 3.5 ms, six
+// times the transform; ZK_ZETA_DEVICE_SORT_MIN overrides (0 = always on the device, tests)
+static uint64_t zeta_device_sort_min() {
+    static const uint64_t v = env_u64("ZK_ZETA_DEVICE_SORT_MIN", 4096, 0, (uint64_t)1 << 40);
+    return v;
+}
+namespace zk {
+int zeta_sort_terms(hipStream_t stream, const uint64_t *d_keys, uint64_t n, uint32_t n_vars, uint64_t *d_idx_unsorted, uint32_t *d_pos_unsorted,
+                    uint64_t *d_idx_sorted, uint32_t *d_perm, void *temp, size_t *temp_bytes);
+}
+// the tiled passes over a table whose first pass has been given its term list
+static int32_t zeta_tiled_passes(zk_ctx *c, zk_mle *t, uint64_t n_vars, const uint64_t *d_keys, const uint64_t *d_coeffs, uint64_t m, const uint32_t *d_perm) {
+    ZKCHK(zeta_lds_opt_in(c));
+    const uint32_t tile_log = n_vars < kZetaTileLog ? (uint32_t)n_vars : kZetaTileLog;
+    k_zeta_first<<<(uint32_t)(1ull << (n_vars - tile_log)), kBlock, kZetaLdsBytes, c->stream>>>(t->d, d_keys, d_coeffs, m, tile_log, c->fi->P, d_perm);
+    HIPCHK(hipGetLastError());
+    const uint32_t rem = (uint32_t)n_vars - tile_log, n_pass = (rem + 7) / 8;
+    uint32_t pos = tile_log;
+    for (uint32_t p = 0; p < n_pass; ++p) {
+        const uint32_t L = rem / n_pass + (p < rem % n_pass ? 1u : 0u);
+        k_zeta_tile<<<(uint32_t)(1ull << (n_vars - kZetaTileLog)), kBlock, kZetaLdsBytes, c->stream>>>(t->d, pos, L, c->fi->P);
+        HIPCHK(hipGetLastError());
+        pos += L;
+    }
+    return ZK_OK;
+}
+// long term lists: upload as given, order on the device, sum duplicate keys inside the first pass
+static int32_t coeff_to_evaluation_device_sort(zk_ctx *c, uint64_t n_vars, const uint64_t *keys, const uint64_t *coeffs, uint64_t n_terms, zk_mle **out) {
+    zk_mle *t = nullptr;
+    ZKCHK(mle_alloc(c, n_vars, &t));
+    // one device block: [keys | idx unsorted | idx sorted | coeffs | pos unsorted | perm | sort scratch]
+    size_t temp_bytes = 0;
+    if (zeta_sort_terms(c->stream, nullptr, n_terms, (uint32_t)n_vars, nullptr, nullptr, nullptr, nullptr, nullptr, &temp_bytes) != 0) {
+        mle_release(t);
+        return ZK_ERR_HIP;
+    }
+    const size_t w8 = (size_t)n_terms * 8, w4 = ((size_t)n_terms * 4 + 7) & ~(size_t)7;
+    const size_t total = 3 * w8 + 4 * w8 + 2 * w4 + ((temp_bytes + 255) & ~(size_t)255) + 256;
+    uint8_t *blk = nullptr;
+    int32_t rc = pool_alloc(c, total, (void **)&blk);
+    if (rc == ZK_OK) {
+        uint64_t *d_keys = reinterpret_cast<uint64_t *>(blk), *d_idx_u = d_keys + n_terms, *d_idx_s = d_idx_u + n_terms, *d_coeffs = d_idx_s + n_terms;
+        uint32_t *d_pos_u = reinterpret_cast<uint32_t *>(blk + 7 * w8), *d_perm = reinterpret_cast<uint32_t *>(blk + 7 * w8 + w4);
+        void *temp = blk + 7 * w8 + 2 * w4;
+        if (hipMemcpyAsync(d_keys, keys, w8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(d_coeffs, coeffs, 4 * w8, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+            rc = ZK_ERR_HIP;
+        if (rc == ZK_OK && zeta_sort_terms(c->stream, d_keys, n_terms, (uint32_t)n_vars, d_idx_u, d_pos_u, d_idx_s, d_perm, temp, &temp_bytes) != 0) rc = ZK_ERR_HIP;
+        if (rc == ZK_OK) rc = zeta_tiled_passes(c, t, n_vars, d_idx_s, d_coeffs, n_terms, d_perm);
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == ZK_OK) rc = ZK_ERR_HIP;   // the caller's arrays were read by the copies
+    if (blk) pool_free(c, blk, total);
+    if (rc != ZK_OK) {
+        mle_release(t);
+        return rc;
+    }
+    *out = t;
+    return ZK_OK;
+}
 static int32_t coeff_to_evaluation_impl(zk_ctx *c, uint64_t n_vars, const uint64_t *keys, const uint64_t *coeffs, uint64_t n_terms,
                                         zk_mle **out) {
     if (!c || !out || (n_terms && (!keys || !coeffs))) return ZK_ERR_BAD_ARG;
@@ -943,6 +1002,9 @@ static int32_t coeff_to_evaluation_impl(zk_ctx *c, uint64_t n_vars, const uint64
     for (uint64_t t = 0; t < n_terms; ++t)
         if (keys[t] >> n_vars) return ZK_ERR_COEFF_RANGE;                            // coefficient_form.rs:183-186
     ZKCHK(use_device(c));
+    static const bool global_passes_flag = env_flag("ZK_ZETA_GLOBAL");
+    if (!global_passes_flag && n_terms && n_terms >= zeta_device_sort_min() && n_terms < ((uint64_t)1 << 32))
+        return coeff_to_evaluation_device_sort(c, n_vars, keys, coeffs, n_terms, out);
     // BTreeMap semantics: one entry per key, duplicate terms summed (coefficient_form.rs:164-171).  Keyed by the TABLE INDEX of the
     // term (key bit v <-> variable v <-> index bit n-1-v: the bit-reversed key), so the list comes out sorted by index, which is
     // what k_zeta_first's per-tile binary search needs.

@@ -78,11 +78,13 @@ ZK_D void zeta_levels(unsigned char *smem, uint32_t lb, uint32_t L, uint32_t til
 }
 
 // pass 1: the 2^tile_log consecutive entries [tile * 2^tile_log, ...) from the sorted term list, all tile_log low index bits
-// (tile_log = min(n_vars, 11)).  idx: table indices of the terms, ascending, unique (the host merges duplicate keys as the
-// reference's BTreeMap does, coefficient_form.rs:164-171); coeffs: their coefficients, same order.
+// (tile_log = min(n_vars, 11)).  idx: table indices of the terms, ascending; coeffs: their coefficients -- in the same order (perm == null)
+// or, for a list ordered on the device (zeta_sort.hip), in the CALLER's order with perm[t] = position of sorted term t.  Equal indices
+// may repeat: a run is added up by the thread of its first term (BTreeMap semantics: duplicate terms are summed, coefficient_form.rs:164-171;
+// the host path merges them beforehand, so its lists are unique).
 __global__ __launch_bounds__(kBlock) void k_zeta_first(uint64_t *__restrict__ table, const uint64_t *__restrict__ idx,
                                                        const uint64_t *__restrict__ coeffs, uint64_t n_terms, uint32_t tile_log,
-                                                       FieldParams P) {
+                                                       FieldParams P, const uint32_t *__restrict__ perm = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint64_t range[2];
     uint4 *plo = reinterpret_cast<uint4 *>(smem), *phi = reinterpret_cast<uint4 *>(smem + kZetaPlaneBytes);
@@ -112,8 +114,11 @@ __global__ __launch_bounds__(kBlock) void k_zeta_first(uint64_t *__restrict__ ta
     }
     __syncthreads();
     for (uint64_t t = t0 + tid; t < t1; t += kBlock) {
-        const uint32_t sl = zeta_slot((uint32_t)(idx[t] - first));
-        const Fe v = fe_load(coeffs, t);
+        const uint64_t my = idx[t];
+        if (t > t0 && idx[t - 1] == my) continue;   // not the first of its run: the run's first thread adds it
+        const uint32_t sl = zeta_slot((uint32_t)(my - first));
+        Fe v = fe_load(coeffs, perm ? perm[t] : t);
+        for (uint64_t u = t + 1; u < t1 && idx[u] == my; ++u) v = fe_add(v, fe_load(coeffs, perm ? perm[u] : u), P);
         plo[sl] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
         phi[sl] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
     }
