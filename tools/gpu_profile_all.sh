@@ -17,6 +17,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ntt -- python3 /tmp/ntt_run.py > $OUT/ntt.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/gkr -- python3 tools/prof_gkr.py 20 8 > $OUT/gkr.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sumcheck_k3_n20 -- python3 tools/prof_k3.py 20 > $OUT/sumcheck_k3_n20.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/batch8_k3_n20 -- python3 tools/prof_batch.py 20 3 > $OUT/batch8_k3_n20.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/evaluate -- python3 tools/prof_evaluate.py > $OUT/evaluate.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fold -- python3 tools/pmc_fold.py 24 200 > $OUT/fold.log 2>&1 || exit 1
-grep -h "^n \|^k3 \|ntt ms\|prove ms\|verify ms\|^evaluate" $OUT/*.log
+grep -h "^n \|^k3 \|ntt ms\|prove ms\|verify ms\|^evaluate\|^k=" $OUT/*.log

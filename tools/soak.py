@@ -22,8 +22,33 @@ while time.time() < t_end:
     f = rng.randrange(3)
     c = ctxs[f]
     p = zk_amd.modulus(f)
-    kind = rng.choice(["prove", "prove", "terms", "evaluate", "fold", "gkr", "gkr_wide", "evaluate_big", "prod_reduce", "to_bytes", "coeff", "shard"])
-    if kind == "prove":
+    kind = rng.choice(["prove", "prove", "terms", "evaluate", "fold", "gkr", "gkr_wide", "evaluate_big", "prod_reduce", "to_bytes", "coeff", "shard",
+                       "batch", "batch", "prove_absorb"])
+    if kind == "batch":   # zk_sumcheck_prove_batch: B independent proofs side by side (round 6), each against the oracle's own proof
+        k, D = rng.choice([(2, 2), (2, 2), (3, 3), (3, 3), (1, 1), (2, 3), (4, 4)])
+        n = rng.choice([1, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17] if k <= 3 else [1, 4, 9, 11])
+        B = rng.choice([2, 3, 5, 8, 9])
+        cases = []
+        for _ in range(B):
+            tabs = [orc.fill_random(f, rng.randrange(1 << 30), 1 << n) for _ in range(k)]
+            s = orc.fill_random(f, rng.randrange(1 << 30), 1)[0]
+            cases.append((tabs, s, orc.sumcheck_prove(f, n, tabs, D, s, False)))
+        polys = [ProductPoly.new([MLE.new(c, n, t) for t in tabs]) for tabs, _, _ in cases]
+        got = SumcheckProver(D).prove_partial_batch(polys, np.stack([s for _, s, _ in cases]), consume=rng.random() < 0.5)
+        for (proof, ch), (_, _, (want_rp, want_ch)) in zip(got, cases):
+            assert np.array_equal(proof.round_polys, want_rp) and np.array_equal(ch, want_ch), ("batch", f, k, D, n, B)
+    elif kind == "prove_absorb":   # prove (tables absorbed, prover.rs:15-20) where the chunked serialiser runs: 1, 2 and 4 chunks per table
+        k, D = rng.choice([(1, 1), (2, 2), (2, 2), (3, 3)])
+        n = rng.choice([18, 19, 20, 21])
+        tabs = [orc.fill_random(f, rng.randrange(1 << 30), 1 << n) for _ in range(k)]
+        s = orc.fill_random(f, rng.randrange(1 << 30), 1)[0]
+        want_rp, _ = orc.sumcheck_prove(f, n, tabs, D, s, True)
+        pp = ProductPoly.new([MLE.new(c, n, t) for t in tabs])
+        proof = SumcheckProver(D).prove(pp, s, consume=rng.random() < 0.5)
+        assert np.array_equal(proof.round_polys, want_rp), ("prove_absorb", f, k, D, n)
+        for q in pp.polynomials:
+            q.free()
+    elif kind == "prove":
         k = rng.choice([1, 2, 2, 3, 3, 4, 5, 8])
         D = rng.choice([max(1, k), k, k + 1, rng.randrange(1, 7)])
         n = rng.choice([1, 2, 3, 5, 8, 10, 11, 12, 13, 14, 15, 16, 17] if k <= 3 else [1, 4, 9, 11, 13])
