@@ -738,7 +738,7 @@ def main():
                                            "call_us": ev24, "frac_of_the_whole_call": (32 << 24) / (ev24 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                                            "timing": "device_us: HIP events on the launch stream around 40 back-to-back evaluates (both launches of each, "
                                                      "zk_bench_evaluate_device); call_us: std::chrono around one zk_mle_evaluate incl. launch and completion",
-                                           "profile": "profiles/r04_evaluate_kernel_stats_and_pmc.log (rocprofv3: the streaming kernel alone, VALU and "
+                                           "profile": "profiles/r06_evaluate_kernel_stats_and_pmc.log (rocprofv3: the evaluate kernels, VALU and "
                                                       "FETCH_SIZE counters)"}
             # the (a)-rows that had no number: prod_reduce (product_poly.rs:66-74), partial_evaluate at general positions
             # (evaluation_form.rs:40-80), to_bytes (:97-103), to_evaluation_form (coefficient_form.rs:340-347) -- device-resident

@@ -5,7 +5,7 @@
   python3 tools/gen_design_tables.py --write    # rewrite it in DESIGN.md (between the BEGIN / END GENERATED markers)
   python3 tools/gen_design_tables.py --check    # exit 1 when DESIGN.md's block differs from what the artefacts say
 
-Sources (ROUND = r05; tests/test_design_tables.py runs --check in the CPU suite):
+Sources (ROUND = r06; tests/test_design_tables.py runs --check in the CPU suite):
   profiles/<ROUND>_bench_final.json                 the bench line of `python3 bench.py` on one MI355X
   profiles/<ROUND>_bench_fold_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the bench command (k_fold_msb's average)
   profiles/<ROUND>_bench_fold_under_rocprof.json    the bench line printed by that profiled run (its own HIP-event average)
@@ -19,7 +19,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = "r05"
+ROUND = "r06"
 BEGIN = "<!-- BEGIN GENERATED: tools/gen_design_tables.py (do not edit by hand) -->"
 END = "<!-- END GENERATED -->"
 PEAK = 8000.0   # GB/s, MI355X_MICROARCH.md
@@ -59,7 +59,8 @@ def build():
     L = [BEGIN, ""]
     src = f"`profiles/{ROUND}_bench_final.json`"
     L += [f"Generated from {src}, `{ROUND}_bench_fold_kernel_stats.csv`, `{ROUND}_prover_ntt_gkr_kernel_stats.md`, `{ROUND}_world1_rccl_final.json` "
-          "(one MI355X each; box-to-box spread ≈ 3 %).", ""]
+          "(the builder's boxes, one MI355X each).  The driver's own record of the round before is printed beside them further down: every "
+          "box is a different machine, and the same library has measured up to 7 % apart on two of them.", ""]
     L += ["| Quantity | Value | Of the roof |", "|---|---|---|"]
     L.append(f"| **`k_fold_msb`, 2^24 → 2^23 BN254 Fr** (the metric; {b['steps']} timed launches, HIP events on the launch stream) | "
              f"{rf['kernel_ms'] * 1e3:.1f} µs mean, {rf['kernel_ms_median'] * 1e3:.1f} median, {rf['kernel_ms_min'] * 1e3:.1f} min; "
@@ -87,6 +88,13 @@ def build():
     L.append(f"| eight layers of `prove_partial` on 3 factors of 2^20, D = 3 / GKR driver depth 8 × 2^20 (random add/mul wiring) | "
              f"{ex['gkr_shaped_depth8_width2p20_k3_d3_ms']:.2f} ms / prove **{ex['gkr_depth8_width2p20_addmul_prove_ms']:.2f} ms**, verify "
              f"{ex['gkr_depth8_width2p20_addmul_verify_ms']:.2f} ms, proof {ex['gkr_proof_bytes']} B | latency-bound |")
+    if ex.get("gkr_shaped_depth8_width2p20_k3_d3_concurrent_ms"):
+        L.append(f"| the same eight INDEPENDENT proofs in flight at once (`zk_sumcheck_prove_batch`: one launch per round for all eight; every proof bit-identical "
+                 f"to its back-to-back twin, gated) | k = 3: **{ex['gkr_shaped_depth8_width2p20_k3_d3_concurrent_ms']:.2f} ms** (back to back "
+                 f"{ex['gkr_shaped_depth8_width2p20_k3_d3_ms']:.2f}); k = 2: **{ex['eight_independent_proofs_n20_k2_d2_concurrent_ms']:.2f} ms** (back to back "
+                 f"{ex['eight_independent_proofs_n20_k2_d2_back_to_back_ms']:.2f}) | "
+                 f"{frac(8 * 3 * 96 * 2 ** 20, ex['gkr_shaped_depth8_width2p20_k3_d3_concurrent_ms'] * 1e3):.2f}; "
+                 f"{frac(8 * 2 * 96 * 2 ** 20, ex['eight_independent_proofs_n20_k2_d2_concurrent_ms'] * 1e3):.2f} (B·k·96·2^n B) |")
     rn = b["roofline_ntt"]
     L.append(f"| NTT 2^24 forward / inverse (3 passes, `zk_bench_ntt`) | **{ex['ntt_2p24_ms']:.3f}** / {ex['intt_2p24_ms']:.3f} ms | "
              f"{rn['frac']:.2f} of the measured {rn['peak']:.3e} modmul/s; {rn['hbm_frac_one_pass_bytes']:.3f} of HBM on the one-pass bytes (P = 3 caps it at 0.33) |")
@@ -107,6 +115,8 @@ def build():
         if "coeff_to_evaluation_2p24_1k_terms" in rows:
             z = rows["coeff_to_evaluation_2p24_1k_terms"]
             tail += f"; `to_evaluation_form` (1 k terms): {z['us'] / 1e3:.2f} ms"
+            if "coeff_to_evaluation_2p24_64k_terms" in rows:
+                tail += f", (64 k terms, ordered on the device): {rows['coeff_to_evaluation_2p24_64k_terms']['us'] / 1e3:.2f} ms"
         if "to_bytes_2p24" in rows:
             z = rows["to_bytes_2p24"]
             tail += f"; `to_bytes`: {z['ms_fresh_destination']:.1f} ms into a fresh destination, {z['ms_mapped_destination']:.1f} ms into a mapped one"
@@ -130,6 +140,37 @@ def build():
         L.append(f"| sharded prover through RCCL {wx.get('rccl_version', '')} at ONE rank (`torch.distributed.run --nproc-per-node 1`), n = 24 | {per}; plain prover in the same run "
                  f"{plain:.3f} ms | best +{(best / plain - 1) * 100:.1f} % over plain; all-reduce of 24 lanes {wx['allreduce_24_lanes_latency_us']:.1f} µs back to back |")
     L.append("")
+    # the driver's last record (a different box): the same keys side by side, so the spread between machines is on the page
+    drv_path = os.path.join(ROOT, f"BENCH_r{int(ROUND[1:]) - 1:02d}.json")
+    if os.path.exists(drv_path):
+        try:
+            drv = json.load(open(drv_path))["parsed"]
+            dx = drv.get("extra", {})
+            if not dx:   # the driver keeps the head of the line only: read what it kept
+                dx = {}
+            tail_txt = json.load(open(drv_path))["run"]["stdout_tail"]
+
+            def grab(key):
+                m = re.search(r'"%s": ([0-9.eE+-]+)' % re.escape(key), tail_txt)
+                return float(m.group(1)) if m else None
+            pairs = [("`k_fold_msb` µs", drv["roofline"]["kernel_ms"] * 1e3, rf["kernel_ms"] * 1e3),
+                     ("`prove_partial` n = 20 ms", grab("sumcheck_prove_partial_ms_n20_k2_d2"), pw["n20_k2_d2"]),
+                     ("`prove_partial` n = 24 ms", grab("sumcheck_prove_partial_ms_n24_k2_d2"), pw["n24_k2_d2"]),
+                     ("8 × (k = 3) back to back ms", grab("gkr_shaped_depth8_width2p20_k3_d3_ms"), ex["gkr_shaped_depth8_width2p20_k3_d3_ms"]),
+                     ("GKR prove ms", grab("gkr_depth8_width2p20_addmul_prove_ms"), ex["gkr_depth8_width2p20_addmul_prove_ms"]),
+                     ("NTT 2^24 ms", grab("ntt_2p24_ms"), ex["ntt_2p24_ms"]),
+                     ("`evaluate` n = 21 µs", grab("evaluate_us_n21"), ex["evaluate_us_n21"]),
+                     ("`evaluate` 2^24 device µs", grab("evaluate_device_us_n24_bn254"), re_["device_us"]),
+                     ("copy GB/s", grab("copy_gbps_1GiB"), ex["copy_gbps_1GiB"])]
+            L += [f"The driver's record of the round before (`BENCH_r{int(ROUND[1:]) - 1:02d}.json`, its own box, that round's library) beside this round's builder-box numbers -- "
+                  "rows whose code did not change between the two show what a change of machine alone does:", "",
+                  "| quantity | driver, round before | builder box, this round | ratio |", "|---|---|---|---|"]
+            for name, a, c in pairs:
+                if a and c:
+                    L.append(f"| {name} | {a:.4g} | {c:.4g} | {c / a:.3f} |")
+            L.append("")
+        except Exception as e:   # noqa: BLE001 -- an unreadable driver record must not break the generator
+            L += [f"(driver record {os.path.basename(drv_path)} unreadable: {e})", ""]
     if os.path.exists(P("prover_ntt_gkr_kernel_stats.md")):
         ks = kernel_rows(P("prover_ntt_gkr_kernel_stats.md"))
         L += [f"Kernels that carry the time (rocprofv3 kernel trace, `profiles/{ROUND}_prover_ntt_gkr_kernel_stats.md`; bytes = algorithmic bytes of the launch):", "",
@@ -147,6 +188,9 @@ def build():
         row("sumcheck_n20", "k_round_pipe<2, 2, 0, true>", "n = 20: pipelined rounds, ≤ 2^12 pairs")
         row("sumcheck_n20", "k_round_tail", "n = 20: classic tails")
         row("sumcheck_n20", "k_finish_pipe<2, 2, 0>", "n = 20: the last 8 rounds in one launch")
+        row("batch8_k3_n20", "k_round_kd_b<3, 3, true, 0, true, true>", "batched fused rounds of B = 2 / 4 / 8 proofs, k = 3, n = 20: grid (x, B)")
+        row("batch8_k3_n20", "k_round_pipe_b<3, 3, 0, true>", "batched pipelined rounds: B transcript blocks + B sets of work blocks per launch")
+        row("batch8_k3_n20", "k_finish_pipe_b<3, 3, 0>", "batched finisher: B workgroups, the last rounds of all proofs")
         row("evaluate", "k_eval_stream", "evaluate at 21 and 24 variables; largest: 2^24 elements read", 32 * 2 ** 24, "max")
         row("ntt", "k_ntt_pass<8, false>", "2^24 points, passes 0 and 1: 2 × 2^24 × 32 B each", 2 * 32 * 2 ** 24)
         row("ntt", "k_ntt_pass<8, true>", "2^24 points, last pass", 2 * 32 * 2 ** 24)
