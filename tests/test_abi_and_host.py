@@ -169,6 +169,24 @@ def test_argument_validation_without_gpu():
     assert _lib.lib.zk_ctx_create(9, 0, ctypes.byref(ctypes.c_void_p())) == -21
 
 
+def test_batch_argument_validation_without_gpu():
+    """zk_sumcheck_prove_batch / zk_batch_last_stats reject bad arguments before anything touches a device"""
+    import ctypes as c
+
+    import numpy as np
+
+    lib = _lib.lib
+    s = np.zeros(4, dtype=np.uint64)
+    out = np.zeros(4, dtype=np.uint64)
+    sp, op = s.ctypes.data_as(_lib.u64p), out.ctypes.data_as(_lib.u64p)
+    assert lib.zk_sumcheck_prove_batch(None, 1, None, 2, 2, sp, 0, op, op) == -20          # no context, no handles
+    handles = (c.c_void_p * 2)()
+    assert lib.zk_sumcheck_prove_batch(None, 0, c.cast(handles, _lib.vpp), 2, 2, sp, 0, op, op) == -20
+    assert lib.zk_batch_last_stats(None, None) == -20
+    a, b = c.c_uint64(7), c.c_uint64(7)
+    assert lib.zk_batch_last_stats(c.byref(a), c.byref(b)) == 0 and (a.value, b.value) == (0, 0)   # nothing batched on this thread yet
+
+
 def test_verifier_round_count_is_never_an_allocation_size():
     """A hostile round count must come back as a status, never as an exception across the C ABI: the uniform-degree entry
     points used to size a std::vector by n_rounds + 1 before looking at the proof (UINT64_MAX wrapped it to 0)."""
