@@ -90,3 +90,49 @@ def test_two_contexts_interleaved_on_one_caller_stream():
         c.use_own_stream()
     for c, w, s in zip(ctxs, loads, states):
         _one_pass(c, w, s)
+
+
+def test_two_threads_batching_on_their_own_contexts():
+    """zk_sumcheck_prove_batch keeps its launch recorder per THREAD (launch.hpp: thread_local): two host threads, a context each, batch
+    different proofs at the same time -- every proof equals the oracle's, and each thread's zk_batch_last_stats is its own."""
+    fields = [zk_amd.BN254_FR, zk_amd.BLS12_381_FR]
+    shapes = [(2, 2, 13, 5), (3, 3, 12, 3)]   # (k, D, n, B)
+    work = []
+    for f, (k, D, n, B) in zip(fields, shapes):
+        cases = []
+        for b in range(B):
+            tabs = [orc.fill_random(f, 9500 + 16 * b + j, 1 << n) for j in range(k)]
+            s = orc.sum_elems(f, orc.prod_reduce(f, n, tabs))
+            cases.append((tabs, s, orc.sumcheck_prove(f, n, tabs, D, s, False)))
+        work.append(cases)
+    errors, stats = [], [None, None]
+    start = threading.Barrier(2)
+
+    def run(i):
+        try:
+            f, (k, D, n, B) = fields[i], shapes[i]
+            ctx = zk_amd.Context(f, 0)
+            polys = [ProductPoly.new([MLE.new(ctx, n, t) for t in tabs]) for tabs, _, _ in work[i]]
+            sums = np.stack([s for _, s, _ in work[i]])
+            SumcheckProver(D).prove_partial_batch(polys, sums)   # first call allocates
+            start.wait()
+            for _ in range(40):
+                got = SumcheckProver(D).prove_partial_batch(polys, sums)
+                for (proof, ch), (_, _, (want_rp, want_ch)) in zip(got, work[i]):
+                    assert np.array_equal(proof.round_polys, want_rp) and np.array_equal(ch, want_ch), "batched proof"
+            stats[i] = zk_amd.batch_last_stats()
+        except BaseException as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append((i, repr(e)))
+            try:
+                start.abort()
+            except Exception:
+                pass
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=180)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in ts)
+    assert stats[0] is not None and stats[1] is not None and stats[0][0] > 0 and stats[1][0] > 0 and stats[0][1] == 0 and stats[1][1] == 0, stats

@@ -115,6 +115,10 @@ __global__ __launch_bounds__(kBlock) void k_round(FactorPtrs fp, int k, uint64_t
 //  * factor indices are template parameters (round_factor<F>), so every array index is static and nothing spills.
 // EXTRA = 1 adds a second, single-factor term to the sum (table index K): S_t = sum_x (prod_{f<K} P_f(t,x) + P_K(t,x)) --
 // the GKR layer polynomial W*H + B in ONE pass instead of a second launch per round (zk_sumcheck_prove_terms, terms {K, 1}).
+// the inner products of a K >= 3 term: table x table.  A/B build switch (-DZK_KD_INNER_MUL=fe_mul_tt: the carry-free form)
+#ifndef ZK_KD_INNER_MUL
+#define ZK_KD_INNER_MUL fe_mul
+#endif
 template <int K, int D, bool FUSED, int EXTRA = 0>
 struct RoundRegs {
     static constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
@@ -178,7 +182,7 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, u
         if (F == K) R.sum_b[t] = fe_add(R.sum_b[t], v, P);            // the extra single-factor term
         else if (K == 1) R.sum[t] = fe_add(R.sum[t], v, P);
         else if (F == 0) R.prod[t] = v;
-        else if (F < K - 1) R.prod[t] = fe_mul(R.prod[t], v, P);
+        else if (F < K - 1) R.prod[t] = ZK_KD_INNER_MUL(R.prod[t], v, P);   // (K >= 3: the products in front of the last, unreduced one)
         else wide_mac(R.acc[t], R.prod[t].v, v.v);
     }
 }
@@ -569,7 +573,7 @@ ZK_D void round_quad_body(const FactorPtrs &fp, uint64_t q, const FieldParams &P
         } else {
             Fe prod = w[0];
 #pragma unroll
-            for (int g = 1; g + 1 < K; ++g) prod = fe_mul(prod, w[g], P);
+            for (int g = 1; g + 1 < K; ++g) prod = ZK_KD_INNER_MUL(prod, w[g], P);
             wide_mac(acc, prod.v, w[K - 1].v);
         }
         if constexpr (EXTRA) sum = fe_add(sum, w[K], P);
