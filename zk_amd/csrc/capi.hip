@@ -2168,7 +2168,7 @@ extern "C" int32_t zk_sumcheck_prove_host(zk_ctx *c, const uint64_t *const *tabl
 // transcript steps of a round run next to each other instead of one after the other, and the number of launches does not grow with B.
 // Every proof is bit-identical to the one zk_sumcheck_prove returns for the same inputs (same kernels' bodies, same arithmetic).
 static thread_local uint64_t g_batch_merged = 0, g_batch_replayed = 0;
-static int32_t batch_flush(zk_ctx *c, BatchRecorder &r) {
+static int32_t batch_flush(BatchRecorder &r) {
     int32_t rc = ZK_OK;
     const size_t len = r.recs[0].size();
     bool same_len = true;
@@ -2227,7 +2227,6 @@ static int32_t batch_flush(zk_ctx *c, BatchRecorder &r) {
         }
     }
     for (int b = 0; b < r.n; ++b) r.recs[b].clear();
-    (void)c;
     return rc;
 }
 // up to kMaxBatch proofs; f = B * k handles (proof-major), sums = B * 4 words, outputs proof-major
@@ -2279,14 +2278,14 @@ static int32_t prove_batch_group(zk_ctx *c, int B, zk_mle *const *f, uint64_t k,
             if (publish_in_finisher)
                 s.pub = FinishPublish{s.ps.d_rp, reinterpret_cast<uint64_t *>(stage + block * (size_t)b), (uint32_t)(block / 8), c->h_flag + 16 * b, seq[b]};
         }
-        if (rc == ZK_OK) rc = batch_flush(c, rec);
+        if (rc == ZK_OK) rc = batch_flush(rec);
         while (rc == ZK_OK && st[0].round < n) {              // prover.rs:44-68: one step of every proof, then the merged launches
             for (int b = 0; b < B && rc == ZK_OK; ++b) {
                 rec.cur = b;
                 bool fin = false;
                 rc = prover_step(st[(size_t)b], &fin);
             }
-            if (rc == ZK_OK) rc = batch_flush(c, rec);
+            if (rc == ZK_OK) rc = batch_flush(rec);
         }
         for (int b = 0; b < B && rc == ZK_OK; ++b) {
             rec.cur = b;
@@ -2305,7 +2304,7 @@ static int32_t prove_batch_group(zk_ctx *c, int B, zk_mle *const *f, uint64_t k,
                 });
             }
         }
-        if (rc == ZK_OK) rc = batch_flush(c, rec);
+        if (rc == ZK_OK) rc = batch_flush(rec);
     }
     g_batch_merged = rec.merged;
     g_batch_replayed = rec.replayed;
@@ -2323,8 +2322,25 @@ static int32_t prove_batch_group(zk_ctx *c, int B, zk_mle *const *f, uint64_t k,
     for (int b = 0; b < inited; ++b) round_state_release(st[(size_t)b]);
     return rc;
 }
+static int32_t prove_batch_impl(zk_ctx *c, uint64_t n_proofs, zk_mle *const *f, uint64_t k, uint32_t D, const uint64_t *sums, int32_t consume,
+                                uint64_t *out_rp, uint64_t *out_ch);
+// the recorder keeps its launches in host containers: an allocation failure is a status, never an exception across the C ABI
 extern "C" int32_t zk_sumcheck_prove_batch(zk_ctx *c, uint64_t n_proofs, zk_mle *const *f, uint64_t k, uint32_t D, const uint64_t *sums, int32_t consume,
                                            uint64_t *out_rp, uint64_t *out_ch) {
+    try {
+        return prove_batch_impl(c, n_proofs, f, k, D, sums, consume, out_rp, out_ch);
+    } catch (const std::bad_alloc &) {
+        g_batch = nullptr;
+        if (c) (void)stream_wait(c->stream);
+        return ZK_ERR_ALLOC;
+    } catch (...) {
+        g_batch = nullptr;
+        if (c) (void)stream_wait(c->stream);
+        return ZK_ERR_BAD_ARG;
+    }
+}
+static int32_t prove_batch_impl(zk_ctx *c, uint64_t n_proofs, zk_mle *const *f, uint64_t k, uint32_t D, const uint64_t *sums, int32_t consume,
+                                uint64_t *out_rp, uint64_t *out_ch) {
     if (!c || !f || !sums) return ZK_ERR_BAD_ARG;
     if (n_proofs == 0) return ZK_OK;
     if (k == 0) return ZK_ERR_EMPTY_PRODUCT;
