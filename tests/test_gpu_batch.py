@@ -125,3 +125,28 @@ def test_config4_eight_layers_n20_batched_bit_exact(k, D):
     for pp in polys:
         for q in pp.polynomials:
             q.free()
+
+
+@pytest.mark.parametrize("k,D,n,B", [(2, 2, 24, 2), (3, 3, 22, 3), (2, 2, 21, 8)])
+def test_batch_at_the_big_round_sizes_equals_the_single_proofs(k, D, n, B):
+    """the batched twins on grids the n <= 20 cases do not reach (round 0 over 2^24 elements per table, fused rounds of 2^22 pairs: 512-2048
+    work blocks per proof): every batched proof equals the single-proof prover's, whose n = 24 / n = 20 proofs the parity tests compare
+    with the oracle (tests/test_gpu_parity.py::test_config3_n24_prover_and_fold_bit_exact)."""
+    field = zk_amd.BN254_FR
+    c = ctx_for(field)
+    polys = [ProductPoly.new([MLE.random(c, n, 0x7700 + 16 * b + f, 0) for f in range(k)]) for b in range(B)]
+    sums = []
+    for pp in polys:
+        s = pp.round_sums(1)
+        sums.append(orc.add(field, s[0], s[1]))
+    single = [SumcheckProver(D).prove_partial(pp, s) for pp, s in zip(polys, sums)]
+    got = SumcheckProver(D).prove_partial_batch(polys, np.stack(sums))
+    merged, replayed = zk_amd.batch_last_stats()
+    assert merged > 0 and replayed == 0, (merged, replayed)
+    for b, ((p1, c1), (p2, c2)) in enumerate(zip(single, got)):
+        assert np.array_equal(p1.round_polys, p2.round_polys) and np.array_equal(c1, c2), b
+    sub = zk_amd.SumcheckVerifier.verify_partial(field, got[-1][0])     # true claimed sums: the proofs verify
+    assert np.array_equal(polys[-1].evaluate(sub.challenges), sub.sum)
+    for pp in polys:
+        for q in pp.polynomials:
+            q.free()
