@@ -118,6 +118,12 @@ def parity_gate(ctx, field, table, out, r):
     return gate, cache
 
 
+def gate_set(result, key, ok):
+    """record one more parity check of a published row (rows measured outside parity_gate() are checked where their inputs live)"""
+    if isinstance(result.get("parity_gate"), dict):
+        result["parity_gate"][key] = bool(ok)
+
+
 def cpu_baseline(field, cache=None):
     """CPU restatement (oracle) of the same path on bounded samples, rank 0 at N = 1 only.  Faithful rows are single
     threaded (the reference is); the "optimised" rows use every core of the box's share.  The prover rows at n = 20 / 24 are
@@ -729,6 +735,9 @@ def main():
             t24 = zk_amd.MultiLinearPolynomial.random(ctx, 24, 0x5EED0E00 + 24, 0)
             pt24 = tr2.sample_n_field_elements(field, 24)
             dev24 = zk_amd.bench_evaluate_device(t24, pt24, 40) * 1e3    # us: HIP events around 40 back-to-back evaluates, no host wait
+            if not args.no_parity_gate:   # the timed 2^24 evaluate against the oracle's n folds (evaluation_form.rs:83-89) on the same table and point
+                from oracle import binding as orc
+                gate_set(result, "evaluate_n24", np.array_equal(t24.evaluate(pt24), orc.mle_evaluate(field, 24, t24.evaluation_slice(), pt24)))
             t24.free()
             extra["evaluate_device_us_n24_bn254"] = dev24
             result["roofline_evaluate"] = {"bound": "hbm", "workload": "MultiLinearPolynomial::evaluate, 2^24 BN254-Fr elements: k_eval_stream over the low "
@@ -768,6 +777,33 @@ def main():
                 pk.prod_reduce_device().free()
                 row(f"prod_reduce_k{k}_2p24", timed(lambda: pk.prod_reduce_device()), (k + 1) * (32 << n), f"k_prod_reduce_run: {k} tables read, one written ({k - 1} carry-free table x table multiplications per element, fe_mul_tt)")
             asg = tr2.sample_n_field_elements(field, 1)
+            if not args.no_parity_gate:
+                # the timed rows against the oracle on the SAME 2^24 tables: prod_reduce k = 2 on every element, k = 3 on 64 runs of 1024
+                # elements (the device generator is the oracle's, so a run of the inputs is regenerated, not downloaded), the three
+                # general-position folds on every output
+                from oracle import binding as orc
+                host0 = tabs[0].evaluation_slice()
+                host1 = tabs[1].evaluation_slice()
+                pr2 = zk_amd.ProductPoly.new(tabs[:2]).prod_reduce_device()
+                ok = np.array_equal(pr2.evaluation_slice(), orc.prod_reduce(field, n, [host0, host1]))
+                pr2.free()
+                del host1
+                pr3 = zk_amd.ProductPoly.new(tabs[:3]).prod_reduce_device()
+                got3 = pr3.evaluation_slice()
+                pr3.free()
+                rs = np.random.default_rng(0x9A7E)
+                for first in rs.integers(0, (1 << n) - 1024, 64):
+                    runs = [orc.fill_random(field, 0x5EED0F00 + f, 1024, first_index=int(first)) for f in range(3)]
+                    ok = ok and np.array_equal(got3[int(first):int(first) + 1024], orc.prod_reduce(field, 10, runs))
+                del got3
+                gate_set(result, "prod_reduce_2p24", ok)
+                okf = True
+                for v in (1, n // 2, n - 1):
+                    pe = tabs[0].partial_evaluate(v, asg)
+                    okf = okf and np.array_equal(pe.evaluation_slice(), orc.mle_partial_evaluate(field, n, host0, v, asg))
+                    pe.free()
+                gate_set(result, "partial_evaluate_2p24_general_positions", okf)
+                del host0
             for v in (1, n // 2, n - 1):
                 tabs[0].partial_evaluate(v, asg).free()
                 row(f"partial_evaluate_2p24_var{v}", timed(lambda: tabs[0].partial_evaluate(v, asg)), 48 << n,
@@ -791,6 +827,26 @@ def main():
             keys = rng_c.integers(0, 1 << n, 1 << 10, dtype=np.uint64)   # few terms: the binding's term handling stays out of the timing
             coeffs = zk_amd.fe_from_ints(field, [int(x) for x in rng_c.integers(1, 1 << 62, 1 << 10)])
             cf = zk_amd.CoeffMultilinearPolynomial.new_with_coefficient(field, n, {int(k_): c_ for k_, c_ in zip(keys, coeffs)})
+            def zeta_gate(cpoly, key):
+                """coefficient_form.rs:340-347 by its definition on 64 table entries: T[idx] = sum of the coefficients whose variable set is
+                contained in the point's (key bit v <-> variable v <-> index bit n-1-v), big-int arithmetic"""
+                tab_ = cpoly.to_evaluation_form(ctx)
+                hostt = tab_.evaluation_slice()
+                tab_.free()
+                p_ = zk_amd.modulus(field)
+                ks = np.array(sorted(cpoly.coefficients), dtype=np.uint64)
+                cs = [zk_amd.fe_to_int(field, cpoly.coefficients[int(k_)]) for k_ in ks]
+                rq = np.random.default_rng(0x2E7A)
+                good = True
+                for idx in [0, (1 << n) - 1] + [int(x) for x in rq.integers(0, 1 << n, 62)]:
+                    mask = int("{:0{w}b}".format(idx, w=n)[::-1], 2)          # variables set to one at this index
+                    sel = (ks & np.uint64(~mask & ((1 << n) - 1))) == 0
+                    want_ = sum(c_ for c_, s_ in zip(cs, sel) if s_) % p_
+                    good = good and zk_amd.fe_to_int(field, hostt[idx]) == want_
+                gate_set(result, key, good)
+
+            if not args.no_parity_gate:
+                zeta_gate(cf, "to_evaluation_form_2p24_1k_terms")
             cf.to_evaluation_form(ctx).free()
             ts = []
             for _ in range(3):
@@ -808,6 +864,8 @@ def main():
             keys16 = np.unique(rng_c.integers(0, 1 << n, 1 << 16, dtype=np.uint64))
             co16 = zk_amd.MultiLinearPolynomial.random(ctx, 16, 0xC0EF16, 0).evaluation_slice()[:len(keys16)]
             cf16 = zk_amd.CoeffMultilinearPolynomial.new_with_coefficient(field, n, {int(k_): c_ for k_, c_ in zip(keys16, co16)})
+            if not args.no_parity_gate:
+                zeta_gate(cf16, "to_evaluation_form_2p24_64k_terms")
             cf16.to_evaluation_form(ctx).free()
             ts = []
             for _ in range(5):
@@ -940,6 +998,23 @@ def main():
             # config[4]: 2^24-point NTT (3 LDS-staged passes), device resident
             x = zk_amd.MultiLinearPolynomial.random(ctx, 24, 0x5EED0005, 0)
             y = zk_amd.MultiLinearPolynomial.alloc(ctx, 24)
+            if not args.no_parity_gate:
+                # the timed transform: three forward and two inverse outputs against the definition X[k] = sum_j x[j] w^(jk) evaluated by the
+                # oracle (fft/src/lib.rs:39-45; ~2.5 s each on one host core), and ifft(fft(x)) == x on the device (fft/src/lib.rs:78-82)
+                from oracle import binding as orc
+                xs = x.evaluation_slice()
+                zk_amd.ntt(ctx, x, y, False)
+                Xs = y.evaluation_slice()
+                okn = all(np.array_equal(Xs[k_], orc.dft_point(field, xs, k_)) for k_ in (1, (1 << 23) + 12345, (1 << 24) - 1))
+                back = zk_amd.MultiLinearPolynomial.alloc(ctx, 24)
+                zk_amd.ntt(ctx, y, back, True)
+                okn = okn and back == x
+                zk_amd.ntt(ctx, x, back, True)
+                Ys = back.evaluation_slice()
+                okn = okn and all(np.array_equal(Ys[k_], orc.dft_point(field, xs, k_, inverse=True)) for k_ in (7, (1 << 22) + 99))
+                back.free()
+                del xs, Xs, Ys
+                gate_set(result, "ntt_2p24", okn)
             extra["ntt_2p24_ms"] = zk_amd.bench_ntt(ctx, x, y, False, 10)
             extra["intt_2p24_ms"] = zk_amd.bench_ntt(ctx, x, y, True, 10)
             x.free(); y.free()
@@ -1005,6 +1080,12 @@ def main():
             if isinstance(cpu_cache.get(ns), dict) and "faithful_absorbing_ms" in cpu_cache[ns]:
                 result["cpu_baseline"][f"sumcheck_prove_absorbing_ms_n{ns}_k2_d2"] = cpu_cache[ns]["faithful_absorbing_ms"]
 
+    # a row whose inputs failed their check is not a measurement: the line says so and the run ends non-zero
+    if rank == 0 and isinstance(result.get("parity_gate"), dict) and not all(result["parity_gate"].values()):
+        failed = sorted(k for k, v in result["parity_gate"].items() if not v)
+        result["error"] = f"parity gate failed for {failed}: the GPU path differs from the CPU oracle on those timed inputs"
+        result["value"] = None
+        exit_code = exit_code or 5
     if dist is not None:
         if exit_code == 0:
             dist.barrier()
