@@ -820,11 +820,20 @@ SKIP1_RUNS = {
     "round0_dot29_terms": dict(ZK_ROUND0_DOT29="2", ZK_LEAD_MIN_PAIRS="1", ZK_CHECK_SIZES="3,9,13,14"),
     # SKIP1 + LEAD everywhere with the claim evaluated by the TAILS (round 4's form; shipped: the round kernel's claim workgroup), with
     # and without the pipeline behind them (k_round_tail / the deferred tail of the first pipelined launch)
+    # the LDS-DMA round kernels (k_round0_glds, k_round_fused_glds<2 / 3>; cached half tables below 256 pairs, nontemporal above) wherever
+    # a round has a multiple of 64 pairs: classic tails behind them, then the pipeline entered right after them, then the three-table
+    # shape and the batched twins on bigger tables; and OFF at sizes where the defaults select them (the kernels they replaced)
+    "glds_classic_tails": dict(ZK_ROUND_GLDS_MIN_PAIRS="64", ZK_ROUND_GLDS_NT_MIN_PAIRS="256", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1",
+                               ZK_QUAD_MAX_PAIRS="0", ZK_PIPE_MAX_PAIRS="0", ZK_CHECK_SIZES="7,8,9,11,13,15"),
+    "glds_then_pipe": dict(ZK_ROUND_GLDS_MIN_PAIRS="64", ZK_ROUND_GLDS_NT_MIN_PAIRS="256", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1",
+                           ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="11,12,13,15"),
+    "glds_defaults_n18_to_20": dict(ZK_CHECK_SIZES="18,19,20", ZK_CHECK_FIELDS="2"),
+    "glds_off_n19_20": dict(ZK_ROUND_GLDS="0", ZK_CHECK_SIZES="19,20", ZK_CHECK_FIELDS="1"),
     "claim_in_tails": dict(ZK_CLAIM_IN_ROUND="0", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="3,7,11,13",
                            ZK_CHECK_FIELDS="2"),
 }
 _SWEEP_ENV_KEYS = ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES", "ZK_LEAD_MIN_PAIRS", "ZK_ROUND0_DOT29",
-                   "ZK_CHECK_FIELDS", "ZK_CLAIM_IN_ROUND")
+                   "ZK_CHECK_FIELDS", "ZK_CLAIM_IN_ROUND", "ZK_ROUND_GLDS", "ZK_ROUND_GLDS_MIN_PAIRS", "ZK_ROUND_GLDS_NT_MIN_PAIRS")
 
 
 @pytest.fixture(scope="module")

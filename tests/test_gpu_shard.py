@@ -63,6 +63,11 @@ SHARD_RUNS = {
     # round 4's behaviour: every sum formed by the round kernels
     "derivation_off": dict(ZK_SHARD_SKIP1="0", ZK_SKIP1_MIN_PAIRS="1", ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_FIELDS="1"),
     # the claim S_prev(r_prev) evaluated by k_lanes_transcript itself (no claim workgroup in the round kernels)
+    # the LDS-DMA round kernels (k_round0_glds, k_round_fused_glds) on every shard of at least 64 pairs, cached and nontemporal half tables
+    "glds_everywhere": dict(ZK_ROUND_GLDS_MIN_PAIRS="64", ZK_ROUND_GLDS_NT_MIN_PAIRS="256", ZK_SKIP1_MIN_PAIRS="1", ZK_LEAD_MIN_PAIRS="1",
+                            ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_CASES="2:2:2:10,2:3:3:10,4:2:2:11,1:2:2:9,1:3:3:9,4:3:3:12", ZK_CHECK_FIELDS="2"),
+    # ... and switched off on the big shards (k_round0_dot29 / k_round_kd where the defaults now select the LDS-DMA forms)
+    "glds_off_big_shards": dict(ZK_ROUND_GLDS="0", ZK_CHECK_CASES="2:2:2:20,2:3:3:20", ZK_CHECK_FIELDS="1"),
     "claim_in_lanes_transcript": dict(ZK_CLAIM_IN_ROUND="0", ZK_SKIP1_MIN_PAIRS="1", ZK_LEAD_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_FIELDS="1"),
 }
 
@@ -81,7 +86,7 @@ def shard_sweeps(tmp_path_factory):
     import shard_skip_check
 
     drop = ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_LEAD_MIN_PAIRS", "ZK_SHARD_SKIP1", "ZK_CHECK_CASES", "ZK_CHECK_FIELDS",
-            "ZK_CLAIM_IN_ROUND")
+            "ZK_CLAIM_IN_ROUND", "ZK_ROUND_GLDS", "ZK_ROUND_GLDS_MIN_PAIRS", "ZK_ROUND_GLDS_NT_MIN_PAIRS")
     cache = str(tmp_path_factory.mktemp("oracle_cache_shard"))
     base = {k: v for k, v in os.environ.items() if k not in drop}
     base["ZK_ORACLE_CACHE"] = cache

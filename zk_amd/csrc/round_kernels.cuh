@@ -509,6 +509,248 @@ __global__ __launch_bounds__(kBlock, 2) void k_round0_dot29_b(BatchOf<RoundSlot>
     round0_dot29_body<EXTRA>(fp, q, P, a.partials);
 }
 
+// ---- the big rounds with their rows arriving by LDS-DMA (round 6) ------------------------------------------------------------------
+// k_round_kd and k_round0_dot29 move 32 bytes per lane and access (fe_load / fe_store): every wave instruction touches half of
+// sixteen 128-byte lines, and the 0.65-0.70 of HBM they reach at 2^24 is that access shape, not their prefetch depth
+// (tools/mb/mb_round0_glds.hip, mb_fused_glds.hip: a ring of one unit does what a ring of four does, at two, three or four waves per
+// SIMD).  Here a wave's 64-pair-index RUN of a row (2 KiB) arrives as two global_load_lds_dwordx4 -- whole 1-KiB nontemporal pieces,
+// no VGPR destination, lane l's 16 bytes at LDS offset 16 l -- into a per-wave ring, lane l reads element pair_owned(l) back with two
+// ds_read_b128 right before it needs it, and the folded half tables leave through pair_scatter (one DPP half swap) as whole 1-KiB
+// stores: the fold kernel's data movement (kernels.cuh k_fold_msb) under the round kernels' arithmetic.  2^24, same box, bit-identical
+// outputs: round 0 190 -> 174 us, the largest fused round 322-349 -> 285-290 us (profiles/r06_mb_glds_rounds.log).
+// The DMA instructions live in asm statements, so the compiler does not count them: every wait is a counted s_waitcnt vmcnt(N) placed
+// by hand.  vmcnt retires in issue order and counts stores as well on this part; N is always "what was issued after the pieces I need".
+// q must be a multiple of 64 (the host sends other sizes to the kernels above); a wave's runs are r0, r0 + rs, ... (wave-uniform).
+extern __shared__ __attribute__((aligned(1024))) uint8_t glds_ring[];   // [4 waves][8 KiB]
+constexpr uint32_t kGldsRingBytes = 4 * 8192;
+template <int N>
+ZK_D void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+#define ZK_GLDS_PIECES(ADDR)                      \
+    "global_load_lds_dwordx4 %1, " ADDR " nt\n\t" \
+    "global_load_lds_dwordx4 %1, " ADDR " offset:1024 nt\n\t"
+#define ZK_GLDS_ROW(M0, ADDR) "s_mov_b32 m0, " M0 "\n\ts_nop 0\n\t" ZK_GLDS_PIECES(ADDR)
+// two rows (lo, hi) of one run: four 1-KiB pieces; voff = 16 * lane, LDS rows 2 KiB apart from lds_dst (a wave-uniform byte address)
+ZK_D void glds_rows2(uint64_t a0, uint64_t a1, uint32_t voff, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t" ZK_GLDS_ROW("%4", "%2") ZK_GLDS_ROW("%5", "%3") "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(a0), "s"(a1), "s"(lds_dst), "s"(lds_dst + 2048u)
+                 : "memory");
+}
+// four rows (j, j + q, j + 2q, j + 3q) of one run: eight pieces
+ZK_D void glds_rows4(uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3, uint32_t voff, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t" ZK_GLDS_ROW("%6", "%2") ZK_GLDS_ROW("%7", "%3") ZK_GLDS_ROW("%8", "%4") ZK_GLDS_ROW("%9", "%5") "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(lds_dst), "s"(lds_dst + 2048u), "s"(lds_dst + 4096u), "s"(lds_dst + 6144u)
+                 : "memory");
+}
+#undef ZK_GLDS_ROW
+#undef ZK_GLDS_PIECES
+ZK_D Fe glds_elem(const uint8_t *row, uint32_t elem) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(row + elem * 32);
+    const uint4 a = p[0], b = p[1];
+    Fe r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+    return r;
+}
+struct GldsWave {
+    uint8_t *my;         // this wave's 8 KiB of the ring
+    uint32_t my_lds;     // its LDS byte address (wave-uniform)
+    uint32_t lane, voff, own;
+    uint64_t r0, rs, K;  // first run, run stride, number of runs of this wave
+};
+ZK_D GldsWave glds_wave(uint64_t q, uint32_t nblk) {
+    GldsWave w;
+    w.lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    w.my = glds_ring + wave * 8192;
+    w.my_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)w.my);
+    w.voff = w.lane * 16;
+    w.own = pair_owned(w.lane);
+    const uint64_t runs = q >> 6;
+    w.r0 = (uint64_t)blockIdx.x * (kBlock / 64) + wave;
+    w.rs = (uint64_t)nblk * (kBlock / 64);
+    w.K = w.r0 < runs ? (runs - w.r0 + w.rs - 1) / w.rs : 0;
+    return w;
+}
+
+// Round 0 of the two-table degree-2 product (k_round0_dot29's sums: S(0), S(1), leading coefficient).  A unit = one factor's (lo, hi)
+// rows of a run = 4 KiB; the wave's ring holds two (factor 0, factor 1); the unit a lane has just copied to registers is re-issued for
+// the next run before its arithmetic starts.  Any number of runs per wave: the columns are reduced every kMaxLazy pair indices.
+ZK_D void round0_glds_body(const FactorPtrs &fp, uint64_t q, const FieldParams &P, uint64_t *__restrict__ partials) {
+    const GldsWave w = glds_wave(q, gridDim.x);
+    const uint64_t in0 = (uint64_t)(uintptr_t)fp.in[0], in1 = (uint64_t)(uintptr_t)fp.in[1], hi_off = q * 32;
+    uint64_t c0[17], c1[17], cL[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) c0[k] = c1[k] = cL[k] = 0;
+    Fe sum[3] = {fe_zero(), fe_zero(), fe_zero()};
+    if (w.K) {
+        glds_rows2(in0 + w.r0 * 2048, in0 + w.r0 * 2048 + hi_off, w.voff, w.my_lds);
+        glds_rows2(in1 + w.r0 * 2048, in1 + w.r0 * 2048 + hi_off, w.voff, w.my_lds + 4096);
+        int since = 0, lazy = 0;
+        for (uint64_t k = 0; k < w.K; ++k) {
+            const bool last = k + 1 == w.K;
+            const uint64_t next = (w.r0 + (k + 1) * w.rs) * 2048;
+            uint32_t la0[9], la1[9], ld0[9];
+            wait_vm<4>();   // factor 0 of this run is in LDS; factor 1's four pieces may still fly
+            {
+                const Fe lo = glds_elem(w.my, w.lane), hi = glds_elem(w.my + 2048, w.lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (!last) glds_rows2(in0 + next, in0 + next + hi_off, w.voff, w.my_lds);
+                split29(lo.v, la0);
+                split29(hi.v, la1);
+                const Fe d = fe_sub(hi, lo, P);
+                split29(d.v, ld0);
+            }
+            if (!last) wait_vm<4>();
+            else wait_vm<0>();
+            {
+                const Fe lo = glds_elem(w.my + 4096, w.lane), hi = glds_elem(w.my + 6144, w.lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (!last) glds_rows2(in1 + next, in1 + next + hi_off, w.voff, w.my_lds + 4096);
+                uint32_t b[9];
+                split29(lo.v, b);
+                dot29_mac(c0, la0, b);   // S(0): lo0 * lo1
+                split29(hi.v, b);
+                dot29_mac(c1, la1, b);   // S(1): hi0 * hi1
+                const Fe d = fe_sub(hi, lo, P);
+                split29(d.v, b);
+                dot29_mac(cL, ld0, b);   // leading coefficient: (hi0 - lo0)(hi1 - lo1)
+            }
+            ++lazy;
+            if (++since == 7 || lazy == kMaxLazy || last) {
+                dot29_normalise(c0);
+                dot29_normalise(c1);
+                dot29_normalise(cL);
+                since = 0;
+            }
+            if (lazy == kMaxLazy || last) {   // redc_wide takes the sum of at most kMaxLazy products
+                WideAcc wa;
+                dot29_to_wide(c0, wa);
+                sum[0] = fe_add(sum[0], redc_wide(wa, P), P);
+                dot29_to_wide(c1, wa);
+                sum[1] = fe_add(sum[1], redc_wide(wa, P), P);
+                dot29_to_wide(cL, wa);
+                sum[2] = fe_add(sum[2], redc_wide(wa, P), P);
+#pragma unroll
+                for (int i = 0; i < 17; ++i) c0[i] = c1[i] = cL[i] = 0;
+                lazy = 0;
+            }
+        }
+    }
+    block_reduce_store<3>(sum, partials, P);
+}
+__global__ __launch_bounds__(kBlock, 2) void k_round0_glds(FactorPtrs fp, uint64_t q, FieldParams P, uint64_t *__restrict__ partials) {
+    round0_glds_body(fp, q, P, partials);
+}
+__global__ __launch_bounds__(kBlock, 2) void k_round0_glds_b(BatchOf<RoundSlot> b, uint64_t q, FieldParams P) {
+    const RoundSlot &a = b.a[blockIdx.y];
+    const FactorPtrs fp = factor_ptrs_of(a.fp);
+    round0_glds_body(fp, q, P, a.partials);
+}
+
+// The big fused rounds of a K-table product of degree D = K with SKIP1 and LEAD (k_round_kd<K, K, true, 0, true, true>: same sums, same
+// claim workgroup, same half tables).  A unit = one factor's four rows of a run = 8 KiB = the wave's whole ring: the next unit's DMA is
+// issued the moment this unit's rows are in registers, and is waited for with vmcnt(4) -- its eight pieces are older than this unit's
+// four stores.  STORE_NT: the half tables bypass the caches (they are larger than what the next round could find there).
+template <int F, int K, bool STORE_NT>
+ZK_D void fused_glds_unit(const GldsWave &w, const FactorPtrs &fp, uint64_t q, uint64_t run, bool last, const Mul29 &r, const FieldParams &P,
+                          Fe (&prod)[K + 1], WideAcc (&acc)[K + 1]) {
+    constexpr int D = K;
+    const Fe c0 = glds_elem(w.my, w.own), c1 = glds_elem(w.my + 2048, w.own), c2 = glds_elem(w.my + 4096, w.own), c3 = glds_elem(w.my + 6144, w.own);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint64_t rowb = q * 32;
+    if (F + 1 < K) {
+        const uint64_t a = (uint64_t)(uintptr_t)fp.in[F + 1 < K ? F + 1 : 0] + run * 2048;
+        glds_rows4(a, a + rowb, a + 2 * rowb, a + 3 * rowb, w.voff, w.my_lds);
+    } else if (!last) {
+        const uint64_t a = (uint64_t)(uintptr_t)fp.in[0] + (run + w.rs) * 2048;
+        glds_rows4(a, a + rowb, a + 2 * rowb, a + 3 * rowb, w.voff, w.my_lds);
+    }
+    const Fe lo = fe_sub(c0, fe_mul29(fe_sub(c0, c2, P), r, P), P);   // prover.rs:64 on rows (0, 2) and (1, 3)
+    const Fe hi = fe_sub(c1, fe_mul29(fe_sub(c1, c3, P), r, P), P);
+    uint64_t *out = fp.out[F];
+    if (STORE_NT) {
+        run_store_nt(out + run * 256, w.lane, lo);
+        run_store_nt(out + (run * 64 + q) * 4, w.lane, hi);
+    } else {
+        run_store(out + run * 256, w.lane, lo);
+        run_store(out + (run * 64 + q) * 4, w.lane, hi);
+    }
+    const Fe diff = fe_sub(hi, lo, P);
+    Fe v = lo;
+#pragma unroll
+    for (int t = 0; t <= D; ++t) {
+        if (t == 1) {
+            v = hi;
+            continue;   // SKIP1: S(1) = claim - S(0), derived in the tail
+        }
+        if (t == D) v = diff;   // LEAD: slot D accumulates the leading coefficient
+        else if (t > 1) v = fe_add(v, diff, P);
+        if (F == 0) prod[t] = v;
+        else if (F < K - 1) prod[t] = ZK_KD_INNER_MUL(prod[t], v, P);
+        else wide_mac(acc[t], prod[t].v, v.v);
+    }
+    if (F + 1 < K || !last) wait_vm<4>();
+}
+template <int K, bool STORE_NT>
+ZK_D void fused_glds_body(const FactorPtrs &fp, uint64_t q, const FieldParams &P, const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials,
+                          const ClaimJob &cj) {
+    constexpr int NS = K + 1;
+    uint32_t nblk = gridDim.x;
+    if (cj.out) {   // the claim workgroup (k_round_kd, SKIP1)
+        nblk -= 1;
+        if (blockIdx.x == nblk) {
+            if (threadIdx.x < 64) {
+                const Fe claim = claim_eval(cj, P);
+                if (threadIdx.x == 0) fe_store(cj.out, 0, claim);
+            }
+            return;
+        }
+    }
+    const Mul29 r = load_challenge29(rptr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of the compiler's is in flight when the counting starts
+    const GldsWave w = glds_wave(q, nblk);
+    Fe prod[NS], sum[NS];
+    WideAcc acc[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        sum[t] = fe_zero();
+        wide_zero(acc[t]);
+    }
+    if (w.K) {
+        {
+            const uint64_t a = (uint64_t)(uintptr_t)fp.in[0] + w.r0 * 2048, rowb = q * 32;
+            glds_rows4(a, a + rowb, a + 2 * rowb, a + 3 * rowb, w.voff, w.my_lds);
+        }
+        wait_vm<0>();
+        for (uint64_t k = 0; k < w.K; ++k) {   // (the host sizes the grid for at most kMaxLazy runs per wave)
+            const uint64_t run = w.r0 + k * w.rs;
+            const bool last = k + 1 == w.K;
+            fused_glds_unit<0, K, STORE_NT>(w, fp, q, run, last, r, P, prod, acc);
+            fused_glds_unit<1, K, STORE_NT>(w, fp, q, run, last, r, P, prod, acc);
+            if constexpr (K > 2) fused_glds_unit<2, K, STORE_NT>(w, fp, q, run, last, r, P, prod, acc);
+        }
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+            if (t != 1) sum[t] = redc_wide(acc[t], P);
+    }
+    block_reduce_store<NS, true>(sum, partials, P);
+}
+template <int K, bool STORE_NT>
+__global__ __launch_bounds__(kBlock, 2) void k_round_fused_glds(FactorPtrs fp, uint64_t q, FieldParams P, const uint64_t *__restrict__ rptr,
+                                                                 uint64_t *__restrict__ partials, ClaimJob cj) {
+    fused_glds_body<K, STORE_NT>(fp, q, P, rptr, partials, cj);
+}
+template <int K, bool STORE_NT>
+__global__ __launch_bounds__(kBlock, 2) void k_round_fused_glds_b(BatchOf<RoundSlot> b, uint64_t q, FieldParams P) {
+    const RoundSlot &a = b.a[blockIdx.y];
+    const FactorPtrs fp = factor_ptrs_of(a.fp);
+    fused_glds_body<K, STORE_NT>(fp, q, P, a.rptr, a.partials, a.cj);
+}
+
 // ---- small fused rounds: one FACTOR per lane, one EVALUATION POINT per lane, four lanes per pair index -----------------
 // Between ~2^10 and ~2^15 pairs a round is pure latency: k_round_kd gives a lane the whole pair index (7 dependent-ish
 // multiplies for k = 2, 14 for k = 3: 4-8 us of a single wave's issue time) while most of the machine idles.  Here the four

@@ -27,6 +27,24 @@ static int round0_dot29_mode() {
 }
 static bool round0_dot29() { return round0_dot29_mode() != 0; }
 static bool round0_dot29_extra() { return round0_dot29_mode() == 2; }
+// ZK_ROUND_GLDS: 1 (default) = the big rounds take the LDS-DMA kernels (round_kernels.cuh: k_round0_glds for round 0 of the (2, 2) product,
+// k_round_fused_glds for the fused SKIP1 + LEAD rounds of the (2, 2) and (3, 3) products); 0 = k_round0_dot29 / k_round_kd at every size
+// (A/B).  Sizes: a multiple of 64 pairs and at least 2^17 (round 0), 2^19 (fused, two tables), 2^18 (fused, three tables) -- measured
+// cross-overs, profiles/r06_glds_rounds_ab.log; ZK_ROUND_GLDS_MIN_PAIRS replaces all three (the parity sweeps force 64).  The half
+// tables of a fused round bypass the caches from ZK_ROUND_GLDS_NT_MIN_PAIRS pairs up.
+static bool glds_rounds() {
+    static const bool v = env_u64("ZK_ROUND_GLDS", 1, 0, 1) != 0;
+    return v;
+}
+static uint64_t glds_min_pairs(uint64_t unset) {
+    static const uint64_t v = env_u64("ZK_ROUND_GLDS_MIN_PAIRS", 0, 0, (uint64_t)1 << 40);
+    return v ? v : unset;
+}
+static uint64_t glds_nt_min_pairs() {
+    static const uint64_t v = env_u64("ZK_ROUND_GLDS_NT_MIN_PAIRS", (uint64_t)1 << 20, 64, (uint64_t)1 << 40);
+    return v;
+}
+static bool glds_takes(uint64_t q, uint64_t min_pairs) { return glds_rounds() && (q & 63) == 0 && q >= 64 && q >= glds_min_pairs(min_pairs); }
 static uint64_t quad_max_pairs() {
     static const uint64_t v = env_u64("ZK_QUAD_MAX_PAIRS", (uint64_t)1 << 15, 0, (uint64_t)1 << 40);
     return v;
@@ -106,6 +124,36 @@ static void go_round0_dot29(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint
     (void)single();
 }
 
+// the LDS-DMA forms (round_kernels.cuh): shape bit 12 marks them in a batch record, bit 13 the nontemporal half tables
+constexpr uint32_t kShapeGlds = 1u << 12, kShapeGldsNt = 1u << 13;
+static void go_round0_glds(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, uint32_t grid) {
+    const FieldParams *P = lc.P;
+    hipStream_t st = lc.stream;
+    uint64_t *part = lc.d_partials;
+    auto single = [=]() {
+        k_round0_glds<<<grid, kBlock, kGldsRingBytes, st>>>(fp, q, *P, part);
+        return hipGetLastError();
+    };
+    if (batch_record(BK_ROUND0_DOT29, kShapeGlds, grid, kBlock, kGldsRingBytes, q, 0, 0, 0, RoundSlot{factor_ptrs4(fp), nullptr, part, ClaimJob{}}, single)) return;
+    (void)single();
+}
+template <int K>
+static void go_fused_glds(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, const uint64_t *d_r, uint32_t grid, const ClaimJob &cj) {
+    const FieldParams *P = lc.P;
+    hipStream_t st = lc.stream;
+    uint64_t *part = lc.d_partials;
+    const bool nt = q >= glds_nt_min_pairs();
+    auto single = [=]() {
+        if (nt) k_round_fused_glds<K, true><<<grid, kBlock, kGldsRingBytes, st>>>(fp, q, *P, d_r, part, cj);
+        else k_round_fused_glds<K, false><<<grid, kBlock, kGldsRingBytes, st>>>(fp, q, *P, d_r, part, cj);
+        return hipGetLastError();
+    };
+    if (batch_record(BK_ROUND_KD, kd_shape(K, K, true, 0, true, true) | kShapeGlds | (nt ? kShapeGldsNt : 0u), grid, kBlock, kGldsRingBytes, q, 0, 0, 0,
+                     RoundSlot{factor_ptrs4(fp), d_r, part, cj}, single))
+        return;
+    (void)single();
+}
+
 template <int K, int D>
 static void launch_kd(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, bool fused, const uint64_t *d_r, uint32_t g) {
     if (fused) go_kd<K, D, true>(lc, fp, q, d_r, g);
@@ -136,12 +184,18 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
         const int shl = k * 10 + (int)D;
         bool done = true;
         if (!fused) {
-            if (shl == 22 && round0_dot29()) go_round0_dot29<0>(lc, fp, q, g);
+            if (shl == 22 && round0_dot29() && glds_takes(q, (uint64_t)1 << 17)) {
+                if (g > 512) g = 512;   // two workgroups per CU; the kernel reduces its columns every kMaxLazy pair indices itself
+                go_round0_glds(lc, fp, q, g);
+            } else if (shl == 22 && round0_dot29()) go_round0_dot29<0>(lc, fp, q, g);
             else if (shl == 22) go_kd<2, 2, false, 0, false, true>(lc, fp, q, d_r, g);
             else go_kd<3, 3, false, 0, false, true>(lc, fp, q, d_r, g);
             if (skip1) *skip1 = false;
         } else if (skip1 && *skip1) {
-            if (shl == 22) go_kd<2, 2, true, 0, true, true>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
+            if (glds_takes(q, shl == 22 ? (uint64_t)1 << 19 : (uint64_t)1 << 18)) {
+                if (shl == 22) go_fused_glds<2>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
+                else go_fused_glds<3>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
+            } else if (shl == 22) go_kd<2, 2, true, 0, true, true>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
             else go_kd<3, 3, true, 0, true, true>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
         } else {
             done = false;
@@ -280,7 +334,19 @@ int batch_launch_rounds(const BatchRecorder &r, size_t idx) {
     case kd_shape(K, D, F, E, S, L):                                                               \
         k_round_kd_b<K, D, F, E, S, L><<<grid, kBlock, 0, r.stream>>>(slots, q, P);               \
         break;
-    if (r0.kernel == BK_ROUND_KD) {
+    if (r0.kernel == BK_ROUND_KD && (r0.shape & kShapeGlds)) {
+        const uint32_t base = r0.shape & ~(kShapeGlds | kShapeGldsNt);
+        const bool nt = (r0.shape & kShapeGldsNt) != 0;
+        if (base == kd_shape(2, 2, true, 0, true, true)) {
+            if (nt) k_round_fused_glds_b<2, true><<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
+            else k_round_fused_glds_b<2, false><<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
+        } else if (base == kd_shape(3, 3, true, 0, true, true)) {
+            if (nt) k_round_fused_glds_b<3, true><<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
+            else k_round_fused_glds_b<3, false><<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
+        } else {
+            return kLaunchUnsupported;
+        }
+    } else if (r0.kernel == BK_ROUND_KD) {
         switch (r0.shape) {
             ZK_KD_B(2, 2, true, 0, true, true)     // the big fused rounds (SKIP1 + LEAD)
             ZK_KD_B(3, 3, true, 0, true, true)
@@ -291,6 +357,8 @@ int batch_launch_rounds(const BatchRecorder &r, size_t idx) {
             ZK_KD_B(3, 3, false, 0, false, false)
             default: return kLaunchUnsupported;
         }
+    } else if (r0.kernel == BK_ROUND0_DOT29 && r0.shape == kShapeGlds) {
+        k_round0_glds_b<<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
     } else if (r0.kernel == BK_ROUND0_DOT29) {
         if (r0.shape != 0) return kLaunchUnsupported;
         k_round0_dot29_b<0><<<grid, kBlock, 0, r.stream>>>(slots, q, P);
