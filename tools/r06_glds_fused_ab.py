@@ -1,4 +1,4 @@
-"""k_round_fused_glds on (ZK_ROUND_GLDS=2) vs off (=1: round 0 only) vs everything off (=0): prove_partial at n = 20, 22, 24 for k = 2 and k = 3,
+"""the LDS-DMA round kernels on (ZK_ROUND_GLDS=1) vs off (=0): prove_partial at n = 20, 22, 24 for k = 2 and k = 3,
 each arm in its own process, interleaved three times"""
 import os
 import subprocess
@@ -28,7 +28,7 @@ for n, k, D in ((20, 2, 2), (22, 2, 2), (24, 2, 2), (20, 3, 3), (22, 3, 3), (24,
 print(" | ".join(out))
 ''' % ROOT
 for rep in range(3):
-    for arm in ("0", "1", "2"):
+    for arm in ("0", "1"):
         env = dict(os.environ, ZK_ROUND_GLDS=arm)
         r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
         print(f"[ZK_ROUND_GLDS={arm}] {r.stdout.strip() or r.stderr[-400:]}", flush=True)

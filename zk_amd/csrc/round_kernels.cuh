@@ -521,8 +521,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_round0_dot29_b(BatchOf<RoundSlot>
 // The DMA instructions live in asm statements, so the compiler does not count them: every wait is a counted s_waitcnt vmcnt(N) placed
 // by hand.  vmcnt retires in issue order and counts stores as well on this part; N is always "what was issued after the pieces I need".
 // q must be a multiple of 64 (the host sends other sizes to the kernels above); a wave's runs are r0, r0 + rs, ... (wave-uniform).
-extern __shared__ __attribute__((aligned(1024))) uint8_t glds_ring[];   // [4 waves][8 KiB]
-constexpr uint32_t kGldsRingBytes = 4 * 8192;
+extern __shared__ __attribute__((aligned(1024))) uint8_t glds_ring[];   // [4 waves][8 or 12 KiB]
+constexpr uint32_t kGldsRingBytes = 4 * 8192, kGldsRing3Bytes = 4 * 12288;   // per workgroup: two 4-KiB units or one 8-KiB unit per wave; three units
 template <int N>
 ZK_D void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -561,11 +561,11 @@ struct GldsWave {
     uint32_t lane, voff, own;
     uint64_t r0, rs, K;  // first run, run stride, number of runs of this wave
 };
-ZK_D GldsWave glds_wave(uint64_t q, uint32_t nblk) {
+ZK_D GldsWave glds_wave(uint64_t q, uint32_t nblk, uint32_t bytes_per_wave = 8192) {
     GldsWave w;
     w.lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    w.my = glds_ring + wave * 8192;
+    w.my = glds_ring + wave * bytes_per_wave;
     w.my_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)w.my);
     w.voff = w.lane * 16;
     w.own = pair_owned(w.lane);
@@ -576,40 +576,60 @@ ZK_D GldsWave glds_wave(uint64_t q, uint32_t nblk) {
     return w;
 }
 
-// Round 0 of the two-table degree-2 product (k_round0_dot29's sums: S(0), S(1), leading coefficient).  A unit = one factor's (lo, hi)
-// rows of a run = 4 KiB; the wave's ring holds two (factor 0, factor 1); the unit a lane has just copied to registers is re-issued for
-// the next run before its arithmetic starts.  Any number of runs per wave: the columns are reduced every kMaxLazy pair indices.
+// Round 0 of the two-table degree-2 product (k_round0_dot29's sums: S(0), S(1), leading coefficient), EXTRA = 1: plus a single-factor
+// term (the GKR layer polynomial's round 0, k_round_kd<2, 2, false, 1, false, true>).  A unit = one table's (lo, hi) rows of a run =
+// 4 KiB; the wave's ring holds one unit per table, each re-issued for the next run the moment a lane has copied it to registers.  Any
+// number of runs per wave: the columns are reduced every kMaxLazy pair indices.
+// waits: a unit's four pieces are followed by the other tables' units (this run's or the next one's): 4 (NU - 1) pieces, fewer in the
+// last run
+template <int NU, int F>
+ZK_D void round0_glds_wait(bool last) {
+    if (!last) wait_vm<4 * (NU - 1)>();
+    else wait_vm<4 * (NU - 1 - F)>();
+}
+ZK_D void dot29_flush(uint64_t (&c)[17], Fe &sum, const FieldParams &P) {   // sum += c (normalised) * R^-1; c = 0
+    WideAcc wa;
+    dot29_to_wide(c, wa);
+    sum = fe_add(sum, redc_wide(wa, P), P);
+#pragma unroll
+    for (int i = 0; i < 17; ++i) c[i] = 0;
+}
+template <int EXTRA>
 ZK_D void round0_glds_body(const FactorPtrs &fp, uint64_t q, const FieldParams &P, uint64_t *__restrict__ partials) {
-    const GldsWave w = glds_wave(q, gridDim.x);
-    const uint64_t in0 = (uint64_t)(uintptr_t)fp.in[0], in1 = (uint64_t)(uintptr_t)fp.in[1], hi_off = q * 32;
+    constexpr int NU = 2 + EXTRA;
+    const GldsWave w = glds_wave(q, gridDim.x, NU * 4096);
+    const uint64_t hi_off = q * 32;
     uint64_t c0[17], c1[17], cL[17];
 #pragma unroll
     for (int k = 0; k < 17; ++k) c0[k] = c1[k] = cL[k] = 0;
     Fe sum[3] = {fe_zero(), fe_zero(), fe_zero()};
+    Fe sb0 = fe_zero(), sb1 = fe_zero();   // the single-factor term: linear, so it only feeds S(0) and S(1)
     if (w.K) {
-        glds_rows2(in0 + w.r0 * 2048, in0 + w.r0 * 2048 + hi_off, w.voff, w.my_lds);
-        glds_rows2(in1 + w.r0 * 2048, in1 + w.r0 * 2048 + hi_off, w.voff, w.my_lds + 4096);
+#pragma unroll
+        for (int f = 0; f < NU; ++f) {
+            const uint64_t a = (uint64_t)(uintptr_t)fp.in[f] + w.r0 * 2048;
+            glds_rows2(a, a + hi_off, w.voff, w.my_lds + f * 4096);
+        }
         int since = 0, lazy = 0;
         for (uint64_t k = 0; k < w.K; ++k) {
             const bool last = k + 1 == w.K;
             const uint64_t next = (w.r0 + (k + 1) * w.rs) * 2048;
             uint32_t la0[9], la1[9], ld0[9];
-            wait_vm<4>();   // factor 0 of this run is in LDS; factor 1's four pieces may still fly
+            round0_glds_wait<NU, 0>(last);
             {
                 const Fe lo = glds_elem(w.my, w.lane), hi = glds_elem(w.my + 2048, w.lane);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (!last) glds_rows2(in0 + next, in0 + next + hi_off, w.voff, w.my_lds);
+                if (!last) glds_rows2((uint64_t)(uintptr_t)fp.in[0] + next, (uint64_t)(uintptr_t)fp.in[0] + next + hi_off, w.voff, w.my_lds);
                 split29(lo.v, la0);
                 split29(hi.v, la1);
                 const Fe d = fe_sub(hi, lo, P);
                 split29(d.v, ld0);
             }
-            if (!last) wait_vm<4>();
-            else wait_vm<0>();
+            round0_glds_wait<NU, 1>(last);
             {
                 const Fe lo = glds_elem(w.my + 4096, w.lane), hi = glds_elem(w.my + 6144, w.lane);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (!last) glds_rows2(in1 + next, in1 + next + hi_off, w.voff, w.my_lds + 4096);
+                if (!last) glds_rows2((uint64_t)(uintptr_t)fp.in[1] + next, (uint64_t)(uintptr_t)fp.in[1] + next + hi_off, w.voff, w.my_lds + 4096);
                 uint32_t b[9];
                 split29(lo.v, b);
                 dot29_mac(c0, la0, b);   // S(0): lo0 * lo1
@@ -619,6 +639,14 @@ ZK_D void round0_glds_body(const FactorPtrs &fp, uint64_t q, const FieldParams &
                 split29(d.v, b);
                 dot29_mac(cL, ld0, b);   // leading coefficient: (hi0 - lo0)(hi1 - lo1)
             }
+            if constexpr (EXTRA) {
+                round0_glds_wait<NU, 2>(last);
+                const Fe lo = glds_elem(w.my + 8192, w.lane), hi = glds_elem(w.my + 10240, w.lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (!last) glds_rows2((uint64_t)(uintptr_t)fp.in[2] + next, (uint64_t)(uintptr_t)fp.in[2] + next + hi_off, w.voff, w.my_lds + 8192);
+                sb0 = fe_add(sb0, lo, P);
+                sb1 = fe_add(sb1, hi, P);
+            }
             ++lazy;
             if (++since == 7 || lazy == kMaxLazy || last) {
                 dot29_normalise(c0);
@@ -627,43 +655,135 @@ ZK_D void round0_glds_body(const FactorPtrs &fp, uint64_t q, const FieldParams &
                 since = 0;
             }
             if (lazy == kMaxLazy || last) {   // redc_wide takes the sum of at most kMaxLazy products
-                WideAcc wa;
-                dot29_to_wide(c0, wa);
-                sum[0] = fe_add(sum[0], redc_wide(wa, P), P);
-                dot29_to_wide(c1, wa);
-                sum[1] = fe_add(sum[1], redc_wide(wa, P), P);
-                dot29_to_wide(cL, wa);
-                sum[2] = fe_add(sum[2], redc_wide(wa, P), P);
-#pragma unroll
-                for (int i = 0; i < 17; ++i) c0[i] = c1[i] = cL[i] = 0;
+                dot29_flush(c0, sum[0], P);
+                dot29_flush(c1, sum[1], P);
+                dot29_flush(cL, sum[2], P);
                 lazy = 0;
             }
         }
     }
+    if (EXTRA) {
+        sum[0] = fe_add(sum[0], sb0, P);
+        sum[1] = fe_add(sum[1], sb1, P);
+    }
     block_reduce_store<3>(sum, partials, P);
 }
+template <int EXTRA>
 __global__ __launch_bounds__(kBlock, 2) void k_round0_glds(FactorPtrs fp, uint64_t q, FieldParams P, uint64_t *__restrict__ partials) {
-    round0_glds_body(fp, q, P, partials);
+    round0_glds_body<EXTRA>(fp, q, P, partials);
 }
+template <int EXTRA>
 __global__ __launch_bounds__(kBlock, 2) void k_round0_glds_b(BatchOf<RoundSlot> b, uint64_t q, FieldParams P) {
     const RoundSlot &a = b.a[blockIdx.y];
     const FactorPtrs fp = factor_ptrs_of(a.fp);
-    round0_glds_body(fp, q, P, a.partials);
+    round0_glds_body<EXTRA>(fp, q, P, a.partials);
 }
 
-// The big fused rounds of a K-table product of degree D = K with SKIP1 and LEAD (k_round_kd<K, K, true, 0, true, true>: same sums, same
-// claim workgroup, same half tables).  A unit = one factor's four rows of a run = 8 KiB = the wave's whole ring: the next unit's DMA is
-// issued the moment this unit's rows are in registers, and is waited for with vmcnt(4) -- its eight pieces are older than this unit's
-// four stores.  STORE_NT: the half tables bypass the caches (they are larger than what the next round could find there).
-template <int F, int K, bool STORE_NT>
+// Round 0 of the three-table degree-3 product (k_round_kd<3, 3, false, 0, false, true>'s sums: S(0), S(1), S(2) and the leading
+// coefficient in slot 3).  That kernel is VALU-bound (four reduced table x table products and four wide ones per pair index); here
+//  * the pair products of the first two tables are A = lo0 lo1, B = hi0 hi1, C = d0 d1 (d = hi - lo), and the fourth,
+//    (lo0 + 2 d0)(lo1 + 2 d1) = 2 (B + C) - A, costs three modular additions instead of a multiplication (hi0 hi1 = A + cross + C);
+//  * the four products with the third table go into carry-free 29-bit columns (dot29_mac), reduced once per kMaxLazy pair indices;
+//  * the rows arrive by LDS-DMA (one 4-KiB unit per table in the wave's ring), so the 136 column registers fit beside the working set.
+// Exact in F_p, so the same canonical sums (tests: the forced-path sweeps, three fields).
+ZK_D void round0_glds3_body(const FactorPtrs &fp, uint64_t q, const FieldParams &P, uint64_t *__restrict__ partials) {
+    constexpr int NU = 3;
+    const GldsWave w = glds_wave(q, gridDim.x, NU * 4096);
+    const uint64_t hi_off = q * 32;
+    uint64_t c0[17], c1[17], c2[17], cL[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) c0[k] = c1[k] = c2[k] = cL[k] = 0;
+    Fe sum[4] = {fe_zero(), fe_zero(), fe_zero(), fe_zero()};
+    if (w.K) {
+#pragma unroll
+        for (int f = 0; f < NU; ++f) {
+            const uint64_t a = (uint64_t)(uintptr_t)fp.in[f] + w.r0 * 2048;
+            glds_rows2(a, a + hi_off, w.voff, w.my_lds + f * 4096);
+        }
+        int since = 0, lazy = 0;
+        for (uint64_t k = 0; k < w.K; ++k) {
+            const bool last = k + 1 == w.K;
+            const uint64_t next = (w.r0 + (k + 1) * w.rs) * 2048;
+            round0_glds_wait<NU, 0>(last);
+            const Fe lo0 = glds_elem(w.my, w.lane), hi0 = glds_elem(w.my + 2048, w.lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!last) glds_rows2((uint64_t)(uintptr_t)fp.in[0] + next, (uint64_t)(uintptr_t)fp.in[0] + next + hi_off, w.voff, w.my_lds);
+            const Fe d0 = fe_sub(hi0, lo0, P);
+            uint32_t lA[9], lB[9], lM[9], lC[9];
+            round0_glds_wait<NU, 1>(last);
+            {
+                const Fe lo1 = glds_elem(w.my + 4096, w.lane), hi1 = glds_elem(w.my + 6144, w.lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (!last) glds_rows2((uint64_t)(uintptr_t)fp.in[1] + next, (uint64_t)(uintptr_t)fp.in[1] + next + hi_off, w.voff, w.my_lds + 4096);
+                const Fe A = ZK_KD_INNER_MUL(lo0, lo1, P), B = ZK_KD_INNER_MUL(hi0, hi1, P), C = ZK_KD_INNER_MUL(d0, fe_sub(hi1, lo1, P), P);
+                const Fe bc = fe_add(B, C, P);
+                const Fe M = fe_sub(fe_add(bc, bc, P), A, P);   // (lo0 + 2 d0)(lo1 + 2 d1)
+                split29(A.v, lA);
+                split29(B.v, lB);
+                split29(M.v, lM);
+                split29(C.v, lC);
+            }
+            round0_glds_wait<NU, 2>(last);
+            {
+                const Fe lo2 = glds_elem(w.my + 8192, w.lane), hi2 = glds_elem(w.my + 10240, w.lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (!last) glds_rows2((uint64_t)(uintptr_t)fp.in[2] + next, (uint64_t)(uintptr_t)fp.in[2] + next + hi_off, w.voff, w.my_lds + 8192);
+                uint32_t b[9];
+                split29(lo2.v, b);
+                dot29_mac(c0, lA, b);   // S(0)
+                split29(hi2.v, b);
+                dot29_mac(c1, lB, b);   // S(1)
+                const Fe d2 = fe_sub(hi2, lo2, P);
+                split29(d2.v, b);
+                dot29_mac(cL, lC, b);   // leading coefficient
+                const Fe e2 = fe_add(hi2, d2, P);
+                split29(e2.v, b);
+                dot29_mac(c2, lM, b);   // S(2)
+            }
+            ++lazy;
+            if (++since == 7 || lazy == kMaxLazy || last) {
+                dot29_normalise(c0);
+                dot29_normalise(c1);
+                dot29_normalise(c2);
+                dot29_normalise(cL);
+                since = 0;
+            }
+            if (lazy == kMaxLazy || last) {
+                dot29_flush(c0, sum[0], P);
+                dot29_flush(c1, sum[1], P);
+                dot29_flush(c2, sum[2], P);
+                dot29_flush(cL, sum[3], P);
+                lazy = 0;
+            }
+        }
+    }
+    block_reduce_store<4>(sum, partials, P);
+}
+__global__ __launch_bounds__(kBlock, 2) void k_round0_glds3(FactorPtrs fp, uint64_t q, FieldParams P, uint64_t *__restrict__ partials) {
+    round0_glds3_body(fp, q, P, partials);
+}
+__global__ __launch_bounds__(kBlock, 2) void k_round0_glds3_b(BatchOf<RoundSlot> b, uint64_t q, FieldParams P) {
+    const RoundSlot &a = b.a[blockIdx.y];
+    const FactorPtrs fp = factor_ptrs_of(a.fp);
+    round0_glds3_body(fp, q, P, a.partials);
+}
+
+// The big fused rounds of a K-table product of degree D = K with SKIP1 and LEAD, EXTRA = 1: plus a single-factor term
+// (k_round_kd<K, K, true, EXTRA, true, true>: same sums, same claim workgroup, same half tables).  A unit = one table's four rows of a
+// run = 8 KiB = the wave's whole ring: the next unit's DMA is issued the moment this unit's rows are in registers, and is waited for
+// with vmcnt(4) -- its eight pieces are older than this unit's four stores.  STORE_NT: the half tables bypass the caches (they are
+// larger than what the next round could find there).  Three tables need no scratch here (198-210 registers; k_round_kd spills 12-184
+// bytes per lane at two waves per SIMD), which is where the gain comes from: 8-13 % from 2^16 pairs up for K = 3; two tables gain
+// nothing at any size and stay on k_round_kd (profiles/r06_glds_sizes.log).
+template <int F, int K, int EXTRA, bool STORE_NT>
 ZK_D void fused_glds_unit(const GldsWave &w, const FactorPtrs &fp, uint64_t q, uint64_t run, bool last, const Mul29 &r, const FieldParams &P,
-                          Fe (&prod)[K + 1], WideAcc (&acc)[K + 1]) {
-    constexpr int D = K;
+                          Fe (&prod)[K + 1], WideAcc (&acc)[K + 1], Fe (&sum_b)[K + 1]) {
+    constexpr int D = K, NT = K + EXTRA;
     const Fe c0 = glds_elem(w.my, w.own), c1 = glds_elem(w.my + 2048, w.own), c2 = glds_elem(w.my + 4096, w.own), c3 = glds_elem(w.my + 6144, w.own);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const uint64_t rowb = q * 32;
-    if (F + 1 < K) {
-        const uint64_t a = (uint64_t)(uintptr_t)fp.in[F + 1 < K ? F + 1 : 0] + run * 2048;
+    if (F + 1 < NT) {
+        const uint64_t a = (uint64_t)(uintptr_t)fp.in[F + 1 < NT ? F + 1 : 0] + run * 2048;
         glds_rows4(a, a + rowb, a + 2 * rowb, a + 3 * rowb, w.voff, w.my_lds);
     } else if (!last) {
         const uint64_t a = (uint64_t)(uintptr_t)fp.in[0] + (run + w.rs) * 2048;
@@ -689,13 +809,15 @@ ZK_D void fused_glds_unit(const GldsWave &w, const FactorPtrs &fp, uint64_t q, u
         }
         if (t == D) v = diff;   // LEAD: slot D accumulates the leading coefficient
         else if (t > 1) v = fe_add(v, diff, P);
-        if (F == 0) prod[t] = v;
+        if (F == K) {
+            if (t < D) sum_b[t] = fe_add(sum_b[t], v, P);   // the single-factor term: linear, nothing for the leading coefficient
+        } else if (F == 0) prod[t] = v;
         else if (F < K - 1) prod[t] = ZK_KD_INNER_MUL(prod[t], v, P);
         else wide_mac(acc[t], prod[t].v, v.v);
     }
-    if (F + 1 < K || !last) wait_vm<4>();
+    if (F + 1 < NT || !last) wait_vm<4>();
 }
-template <int K, bool STORE_NT>
+template <int K, int EXTRA, bool STORE_NT>
 ZK_D void fused_glds_body(const FactorPtrs &fp, uint64_t q, const FieldParams &P, const uint64_t *__restrict__ rptr, uint64_t *__restrict__ partials,
                           const ClaimJob &cj) {
     constexpr int NS = K + 1;
@@ -713,11 +835,12 @@ ZK_D void fused_glds_body(const FactorPtrs &fp, uint64_t q, const FieldParams &P
     const Mul29 r = load_challenge29(rptr);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of the compiler's is in flight when the counting starts
     const GldsWave w = glds_wave(q, nblk);
-    Fe prod[NS], sum[NS];
+    Fe prod[NS], sum[NS], sum_b[NS];
     WideAcc acc[NS];
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
         sum[t] = fe_zero();
+        sum_b[t] = fe_zero();
         wide_zero(acc[t]);
     }
     if (w.K) {
@@ -729,26 +852,32 @@ ZK_D void fused_glds_body(const FactorPtrs &fp, uint64_t q, const FieldParams &P
         for (uint64_t k = 0; k < w.K; ++k) {   // (the host sizes the grid for at most kMaxLazy runs per wave)
             const uint64_t run = w.r0 + k * w.rs;
             const bool last = k + 1 == w.K;
-            fused_glds_unit<0, K, STORE_NT>(w, fp, q, run, last, r, P, prod, acc);
-            fused_glds_unit<1, K, STORE_NT>(w, fp, q, run, last, r, P, prod, acc);
-            if constexpr (K > 2) fused_glds_unit<2, K, STORE_NT>(w, fp, q, run, last, r, P, prod, acc);
+            fused_glds_unit<0, K, EXTRA, STORE_NT>(w, fp, q, run, last, r, P, prod, acc, sum_b);
+            fused_glds_unit<1, K, EXTRA, STORE_NT>(w, fp, q, run, last, r, P, prod, acc, sum_b);
+            if constexpr (K + EXTRA > 2) fused_glds_unit<2, K, EXTRA, STORE_NT>(w, fp, q, run, last, r, P, prod, acc, sum_b);
+            if constexpr (K + EXTRA > 3) fused_glds_unit<3, K, EXTRA, STORE_NT>(w, fp, q, run, last, r, P, prod, acc, sum_b);
         }
 #pragma unroll
         for (int t = 0; t < NS; ++t)
             if (t != 1) sum[t] = redc_wide(acc[t], P);
+        if (EXTRA) {
+#pragma unroll
+            for (int t = 0; t < K; ++t)
+                if (t != 1) sum[t] = fe_add(sum[t], sum_b[t], P);
+        }
     }
     block_reduce_store<NS, true>(sum, partials, P);
 }
-template <int K, bool STORE_NT>
+template <int K, int EXTRA, bool STORE_NT>
 __global__ __launch_bounds__(kBlock, 2) void k_round_fused_glds(FactorPtrs fp, uint64_t q, FieldParams P, const uint64_t *__restrict__ rptr,
                                                                  uint64_t *__restrict__ partials, ClaimJob cj) {
-    fused_glds_body<K, STORE_NT>(fp, q, P, rptr, partials, cj);
+    fused_glds_body<K, EXTRA, STORE_NT>(fp, q, P, rptr, partials, cj);
 }
-template <int K, bool STORE_NT>
+template <int K, int EXTRA, bool STORE_NT>
 __global__ __launch_bounds__(kBlock, 2) void k_round_fused_glds_b(BatchOf<RoundSlot> b, uint64_t q, FieldParams P) {
     const RoundSlot &a = b.a[blockIdx.y];
     const FactorPtrs fp = factor_ptrs_of(a.fp);
-    fused_glds_body<K, STORE_NT>(fp, q, P, a.rptr, a.partials, a.cj);
+    fused_glds_body<K, EXTRA, STORE_NT>(fp, q, P, a.rptr, a.partials, a.cj);
 }
 
 // ---- small fused rounds: one FACTOR per lane, one EVALUATION POINT per lane, four lanes per pair index -----------------

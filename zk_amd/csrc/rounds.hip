@@ -27,11 +27,12 @@ static int round0_dot29_mode() {
 }
 static bool round0_dot29() { return round0_dot29_mode() != 0; }
 static bool round0_dot29_extra() { return round0_dot29_mode() == 2; }
-// ZK_ROUND_GLDS: 1 (default) = the big rounds take the LDS-DMA kernels (round_kernels.cuh: k_round0_glds for round 0 of the (2, 2) product,
-// k_round_fused_glds for the fused SKIP1 + LEAD rounds of the (2, 2) and (3, 3) products); 0 = k_round0_dot29 / k_round_kd at every size
-// (A/B).  Sizes: a multiple of 64 pairs and at least 2^17 (round 0), 2^19 (fused, two tables), 2^18 (fused, three tables) -- measured
-// cross-overs, profiles/r06_glds_rounds_ab.log; ZK_ROUND_GLDS_MIN_PAIRS replaces all three (the parity sweeps force 64).  The half
-// tables of a fused round bypass the caches from ZK_ROUND_GLDS_NT_MIN_PAIRS pairs up.
+// ZK_ROUND_GLDS: 1 (default) = the big rounds take the LDS-DMA kernels (round_kernels.cuh: k_round0_glds<0 / 1> and k_round0_glds3 for
+// round 0, k_round_fused_glds<3, 0> and <2, 1> for the fused SKIP1 + LEAD rounds over three tables); 0 = k_round0_dot29 / k_round_kd at
+// every size (A/B).  Sizes: a multiple of 64 pairs and at least 2^21 (round 0, two tables), 2^20 (round 0, three tables or product plus term), 2^16 /
+// 2^19 (fused rounds of the (3, 3) product / of the product-plus-term shape; the fused rounds of the two-table product gain nothing at
+// any size and stay on k_round_kd) -- measured cross-overs, profiles/r06_glds_sizes.log; ZK_ROUND_GLDS_MIN_PAIRS replaces
+// all of them (the parity sweeps force 64).  The half tables of a fused round bypass the caches from ZK_ROUND_GLDS_NT_MIN_PAIRS pairs up.
 static bool glds_rounds() {
     static const bool v = env_u64("ZK_ROUND_GLDS", 1, 0, 1) != 0;
     return v;
@@ -126,29 +127,44 @@ static void go_round0_dot29(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint
 
 // the LDS-DMA forms (round_kernels.cuh): shape bit 12 marks them in a batch record, bit 13 the nontemporal half tables
 constexpr uint32_t kShapeGlds = 1u << 12, kShapeGldsNt = 1u << 13;
+template <int EXTRA>
 static void go_round0_glds(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, uint32_t grid) {
     const FieldParams *P = lc.P;
     hipStream_t st = lc.stream;
     uint64_t *part = lc.d_partials;
+    constexpr uint32_t lds = EXTRA ? kGldsRing3Bytes : kGldsRingBytes;
     auto single = [=]() {
-        k_round0_glds<<<grid, kBlock, kGldsRingBytes, st>>>(fp, q, *P, part);
+        k_round0_glds<EXTRA><<<grid, kBlock, lds, st>>>(fp, q, *P, part);
         return hipGetLastError();
     };
-    if (batch_record(BK_ROUND0_DOT29, kShapeGlds, grid, kBlock, kGldsRingBytes, q, 0, 0, 0, RoundSlot{factor_ptrs4(fp), nullptr, part, ClaimJob{}}, single)) return;
+    if (batch_record(BK_ROUND0_DOT29, kShapeGlds | (uint32_t)EXTRA, grid, kBlock, lds, q, 0, 0, 0, RoundSlot{factor_ptrs4(fp), nullptr, part, ClaimJob{}}, single)) return;
     (void)single();
 }
-template <int K>
+static void go_round0_glds3(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, uint32_t grid) {
+    const FieldParams *P = lc.P;
+    hipStream_t st = lc.stream;
+    uint64_t *part = lc.d_partials;
+    auto single = [=]() {
+        k_round0_glds3<<<grid, kBlock, kGldsRing3Bytes, st>>>(fp, q, *P, part);
+        return hipGetLastError();
+    };
+    if (batch_record(BK_ROUND_KD, kd_shape(3, 3, false, 0, false, true) | kShapeGlds, grid, kBlock, kGldsRing3Bytes, q, 0, 0, 0,
+                     RoundSlot{factor_ptrs4(fp), nullptr, part, ClaimJob{}}, single))
+        return;
+    (void)single();
+}
+template <int K, int EXTRA>
 static void go_fused_glds(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, const uint64_t *d_r, uint32_t grid, const ClaimJob &cj) {
     const FieldParams *P = lc.P;
     hipStream_t st = lc.stream;
     uint64_t *part = lc.d_partials;
     const bool nt = q >= glds_nt_min_pairs();
     auto single = [=]() {
-        if (nt) k_round_fused_glds<K, true><<<grid, kBlock, kGldsRingBytes, st>>>(fp, q, *P, d_r, part, cj);
-        else k_round_fused_glds<K, false><<<grid, kBlock, kGldsRingBytes, st>>>(fp, q, *P, d_r, part, cj);
+        if (nt) k_round_fused_glds<K, EXTRA, true><<<grid, kBlock, kGldsRingBytes, st>>>(fp, q, *P, d_r, part, cj);
+        else k_round_fused_glds<K, EXTRA, false><<<grid, kBlock, kGldsRingBytes, st>>>(fp, q, *P, d_r, part, cj);
         return hipGetLastError();
     };
-    if (batch_record(BK_ROUND_KD, kd_shape(K, K, true, 0, true, true) | kShapeGlds | (nt ? kShapeGldsNt : 0u), grid, kBlock, kGldsRingBytes, q, 0, 0, 0,
+    if (batch_record(BK_ROUND_KD, kd_shape(K, K, true, EXTRA, true, true) | kShapeGlds | (nt ? kShapeGldsNt : 0u), grid, kBlock, kGldsRingBytes, q, 0, 0, 0,
                      RoundSlot{factor_ptrs4(fp), d_r, part, cj}, single))
         return;
     (void)single();
@@ -184,18 +200,19 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
         const int shl = k * 10 + (int)D;
         bool done = true;
         if (!fused) {
-            if (shl == 22 && round0_dot29() && glds_takes(q, (uint64_t)1 << 17)) {
+            if (shl == 22 && round0_dot29() && glds_takes(q, (uint64_t)1 << 21)) {
                 if (g > 512) g = 512;   // two workgroups per CU; the kernel reduces its columns every kMaxLazy pair indices itself
-                go_round0_glds(lc, fp, q, g);
+                go_round0_glds<0>(lc, fp, q, g);
             } else if (shl == 22 && round0_dot29()) go_round0_dot29<0>(lc, fp, q, g);
             else if (shl == 22) go_kd<2, 2, false, 0, false, true>(lc, fp, q, d_r, g);
-            else go_kd<3, 3, false, 0, false, true>(lc, fp, q, d_r, g);
+            else if (glds_takes(q, (uint64_t)1 << 20)) {
+                if (g > 512) g = 512;
+                go_round0_glds3(lc, fp, q, g);
+            } else go_kd<3, 3, false, 0, false, true>(lc, fp, q, d_r, g);
             if (skip1) *skip1 = false;
         } else if (skip1 && *skip1) {
-            if (glds_takes(q, shl == 22 ? (uint64_t)1 << 19 : (uint64_t)1 << 18)) {
-                if (shl == 22) go_fused_glds<2>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
-                else go_fused_glds<3>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
-            } else if (shl == 22) go_kd<2, 2, true, 0, true, true>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
+            if (shl == 33 && glds_takes(q, (uint64_t)1 << 16)) go_fused_glds<3, 0>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
+            else if (shl == 22) go_kd<2, 2, true, 0, true, true>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
             else go_kd<3, 3, true, 0, true, true>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
         } else {
             done = false;
@@ -260,7 +277,7 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
 // Terms {k, 1}: the k-factor product plus one single-factor term in one pass (fp lists the k factors, then the extra one).
 int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t q, uint32_t D, bool fused,
                        const uint64_t *d_r, uint32_t *out_grid, bool *skip1, bool *lead) {
-    const uint32_t g = round_grid(q, min_blocks_plus1());
+    uint32_t g = round_grid(q, min_blocks_plus1());
     if ((uint64_t)g * (D + 1) > lc.capacity_elems) return kLaunchUnsupported;
     const int shape = k * 10 + (int)D;
     bool no_lead = false;
@@ -270,10 +287,14 @@ int launch_round_plus1(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, ui
             // (the carry-free round-0 kernel with a third table has no registers left for the second prefetch buffer and measures
             // 0.1-0.4 % SLOWER on the GKR driver: profiles/r04_round0_dot29_ab.log; ZK_ROUND0_DOT29=2 selects it for A/B runs)
             if (round0_dot29_extra()) go_round0_dot29<1>(lc, fp, q, g);
-            else go_kd<2, 2, false, 1, false, true>(lc, fp, q, d_r, g);
+            else if (round0_dot29() && glds_takes(q, (uint64_t)1 << 20)) {
+                if (g > 512) g = 512;
+                go_round0_glds<1>(lc, fp, q, g);
+            } else go_kd<2, 2, false, 1, false, true>(lc, fp, q, d_r, g);
             if (skip1) *skip1 = false;
         } else {
-            go_kd<2, 2, true, 1, true, true>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
+            if (glds_takes(q, (uint64_t)1 << 19)) go_fused_glds<2, 1>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
+            else go_kd<2, 2, true, 1, true, true>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
         }
         if (hipGetLastError() != hipSuccess) return kLaunchHipError;
         *out_grid = g;
@@ -337,12 +358,11 @@ int batch_launch_rounds(const BatchRecorder &r, size_t idx) {
     if (r0.kernel == BK_ROUND_KD && (r0.shape & kShapeGlds)) {
         const uint32_t base = r0.shape & ~(kShapeGlds | kShapeGldsNt);
         const bool nt = (r0.shape & kShapeGldsNt) != 0;
-        if (base == kd_shape(2, 2, true, 0, true, true)) {
-            if (nt) k_round_fused_glds_b<2, true><<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
-            else k_round_fused_glds_b<2, false><<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
-        } else if (base == kd_shape(3, 3, true, 0, true, true)) {
-            if (nt) k_round_fused_glds_b<3, true><<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
-            else k_round_fused_glds_b<3, false><<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
+        if (base == kd_shape(3, 3, true, 0, true, true)) {
+            if (nt) k_round_fused_glds_b<3, 0, true><<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
+            else k_round_fused_glds_b<3, 0, false><<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
+        } else if (base == kd_shape(3, 3, false, 0, false, true)) {
+            k_round0_glds3_b<<<grid, kBlock, kGldsRing3Bytes, r.stream>>>(slots, q, P);
         } else {
             return kLaunchUnsupported;
         }
@@ -358,7 +378,9 @@ int batch_launch_rounds(const BatchRecorder &r, size_t idx) {
             default: return kLaunchUnsupported;
         }
     } else if (r0.kernel == BK_ROUND0_DOT29 && r0.shape == kShapeGlds) {
-        k_round0_glds_b<<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
+        k_round0_glds_b<0><<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
+    } else if (r0.kernel == BK_ROUND0_DOT29 && r0.shape == (kShapeGlds | 1u)) {
+        k_round0_glds_b<1><<<grid, kBlock, kGldsRing3Bytes, r.stream>>>(slots, q, P);
     } else if (r0.kernel == BK_ROUND0_DOT29) {
         if (r0.shape != 0) return kLaunchUnsupported;
         k_round0_dot29_b<0><<<grid, kBlock, 0, r.stream>>>(slots, q, P);
