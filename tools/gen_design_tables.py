@@ -183,11 +183,15 @@ def build():
                 fr = f"{frac(nbytes, t):.2f}" + (" (largest launch)" if pick == "max" else "") if nbytes else "—"
                 L.append(f"| `{kern}` ({what}) | {c} | {a:.1f} ({mn:.1f}; max {mx:.1f}) | {pct:.1f} % | {fr} |")
         row("sumcheck_n24", "k_round0_dot29<0>", "n = 24 round 0: 2 × 2^24 elements read", 2 * 32 * 2 ** 24)
+        row("sumcheck_n24", "k_round0_glds<0>", "n = 24 round 0 on the LDS-DMA kernel: 2 × 2^24 elements read", 2 * 32 * 2 ** 24)
         row("sumcheck_n24", "k_round_kd<2, 2, true, 0, true, true>", "n = 24 fused rounds; largest: 2 × (2^24 read + 2^23 written)", 2 * 48 * 2 ** 24, "max")
         row("sumcheck_n24", "k_round_tail", "n = 24: second-stage reduction + transcript step of the classic rounds")
         row("sumcheck_n20", "k_round_pipe<2, 2, 0, true>", "n = 20: pipelined rounds, ≤ 2^12 pairs")
         row("sumcheck_n20", "k_round_tail", "n = 20: classic tails")
         row("sumcheck_n20", "k_finish_pipe<2, 2, 0>", "n = 20: the last 8 rounds in one launch")
+        row("sumcheck_k3_n20", "k_round_fused_glds<3, 0, false>", "k = 3, n = 20: fused rounds of three tables on the LDS-DMA kernel, 2^18 .. 2^16 pairs")
+        row("sumcheck_k3_n20", "k_round_kd<3, 3, false, 0, false, true>", "k = 3, n = 20 round 0: 3 × 2^20 elements read", 3 * 32 * 2 ** 20)
+        row("batch8_k3_n20", "k_round_fused_glds_b<3, 0, false>", "batched fused rounds of B = 2 / 4 / 8 proofs, k = 3, n = 20, LDS-DMA kernel: grid (x, B)")
         row("batch8_k3_n20", "k_round_kd_b<3, 3, true, 0, true, true>", "batched fused rounds of B = 2 / 4 / 8 proofs, k = 3, n = 20: grid (x, B)")
         row("batch8_k3_n20", "k_round_pipe_b<3, 3, 0, true>", "batched pipelined rounds: B transcript blocks + B sets of work blocks per launch")
         row("batch8_k3_n20", "k_finish_pipe_b<3, 3, 0>", "batched finisher: B workgroups, the last rounds of all proofs")
