@@ -144,6 +144,8 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, u
                        const Mul29 &r, const FieldParams &P, uint64_t jnn = 0, bool more2 = false) {
     static_assert(!LEAD || (K == D && D >= 1), "the leading-coefficient slot needs deg = K = D");
     constexpr int NS = D + 1, NL = FUSED ? 4 : 2;
+    // the second factor of a three-table degree-3 product with all four slots live (round 0, LEAD): see the end of this function
+    constexpr bool PAIR3 = K == 3 && D == 3 && F == 1 && LEAD && !SKIP1;
     Fe lo, hi;
     if (FUSED) {
         lo = fe_sub(R.cur[F][0], fe_mul29(fe_sub(R.cur[F][0], R.cur[F][2], P), r, P), P);
@@ -182,8 +184,15 @@ ZK_D void round_factor(RoundRegs<K, D, FUSED, EXTRA> &R, const FactorPtrs &fp, u
         if (F == K) R.sum_b[t] = fe_add(R.sum_b[t], v, P);            // the extra single-factor term
         else if (K == 1) R.sum[t] = fe_add(R.sum[t], v, P);
         else if (F == 0) R.prod[t] = v;
+        else if (PAIR3 && t == 2) continue;                             // (formed below from the other three pair products)
         else if (F < K - 1) R.prod[t] = ZK_KD_INNER_MUL(R.prod[t], v, P);   // (K >= 3: the products in front of the last, unreduced one)
         else wide_mac(R.acc[t], R.prod[t].v, v.v);
+    }
+    if (PAIR3) {
+        // slots 0, 1, 3 hold A = lo0 lo1, B = hi0 hi1, C = d0 d1 (d = hi - lo); hi0 hi1 = A + (lo0 d1 + d0 lo1) + C, so the pair product at
+        // t = 2, (lo0 + 2 d0)(lo1 + 2 d1) = A + 2 (B - A - C) + 4 C = 2 (B + C) - A: three modular additions instead of a multiplication
+        const Fe bc = fe_add(R.prod[1], R.prod[3], P);
+        R.prod[2] = fe_sub(fe_add(bc, bc, P), R.prod[0], P);
     }
 }
 // K <= 2 fits 2 waves per SIMD (<= 256 VGPRs); K >= 3 (or an extra term) keeps >= 12 elements in flight and gets the whole
@@ -511,13 +520,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_round0_dot29_b(BatchOf<RoundSlot>
 
 // ---- the big rounds with their rows arriving by LDS-DMA (round 6) ------------------------------------------------------------------
 // k_round_kd and k_round0_dot29 move 32 bytes per lane and access (fe_load / fe_store): every wave instruction touches half of
-// sixteen 128-byte lines, and the 0.65-0.70 of HBM they reach at 2^24 is that access shape, not their prefetch depth
-// (tools/mb/mb_round0_glds.hip, mb_fused_glds.hip: a ring of one unit does what a ring of four does, at two, three or four waves per
-// SIMD).  Here a wave's 64-pair-index RUN of a row (2 KiB) arrives as two global_load_lds_dwordx4 -- whole 1-KiB nontemporal pieces,
-// no VGPR destination, lane l's 16 bytes at LDS offset 16 l -- into a per-wave ring, lane l reads element pair_owned(l) back with two
-// ds_read_b128 right before it needs it, and the folded half tables leave through pair_scatter (one DPP half swap) as whole 1-KiB
-// stores: the fold kernel's data movement (kernels.cuh k_fold_msb) under the round kernels' arithmetic.  2^24, same box, bit-identical
-// outputs: round 0 190 -> 174 us, the largest fused round 322-349 -> 285-290 us (profiles/r06_mb_glds_rounds.log).
+// sixteen 128-byte lines.  Here a wave's 64-pair-index RUN of a row (2 KiB) arrives as two global_load_lds_dwordx4 -- whole 1-KiB
+// nontemporal pieces, no VGPR destination, lane l's 16 bytes at LDS offset 16 l -- into a per-wave ring, a lane reads its element back
+// with two ds_read_b128 right before it needs it, and the folded half tables leave through pair_scatter (one DPP half swap) as whole
+// 1-KiB stores: the fold kernel's data movement (kernels.cuh k_fold_msb) under the round kernels' arithmetic.  What that buys
+// (tools/mb/mb_round0_glds.hip, mb_fused_glds.hip, mb_rows_pattern.hip; in the prover: profiles/r06_glds_sizes.log):
+//  * the sums-only round of two tables was held at 0.63 of HBM by its access SHAPE, not by its prefetch depth (a ring of one unit does
+//    what a ring of four does, at two, three or four waves per SIMD): 212 -> 168 us at 2^24 per table;
+//  * the three-table kernels keep their prefetch in LDS instead of 48-96 registers and stop spilling: 8-17 % from the sizes in rounds.hip;
+//  * the fused round of TWO tables gains nothing in any form (eight read + four written streams reach 0.69-0.72 of HBM with every
+//    multiplication removed) and has no instantiation here.
 // The DMA instructions live in asm statements, so the compiler does not count them: every wait is a counted s_waitcnt vmcnt(N) placed
 // by hand.  vmcnt retires in issue order and counts stores as well on this part; N is always "what was issued after the pieces I need".
 // q must be a multiple of 64 (the host sends other sizes to the kernels above); a wave's runs are r0, r0 + rs, ... (wave-uniform).
