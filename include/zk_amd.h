@@ -379,7 +379,7 @@ int32_t zk_bench_copy(zk_ctx *ctx, uint64_t bytes, int32_t reps, double *out_gbp
    ZK_FINISH_PIPE          1         0 .. 1       0: the classic single-workgroup finisher instead of the pipelined one
    ZK_ROUND0_DOT29         1         0 .. 2       0: round 0 of the two-table degree-2 shapes on the wide accumulator; 2: force dot29
    ZK_ROUND_GLDS           1         0 .. 1       0: the big rounds on k_round0_dot29 / k_round_kd instead of the LDS-DMA kernels (k_round0_glds, k_round_fused_glds)
-   ZK_ROUND_GLDS_MIN_PAIRS per kernel 64 .. 2^40  smallest round (pairs, a multiple of 64) on the LDS-DMA kernels; unset: 2^21 / 2^20 (round 0, 2 / 3 tables), 2^16 / 2^19 (fused, 3 tables / 2 + term)
+   ZK_ROUND_GLDS_MIN_PAIRS per kernel 64 .. 2^40  smallest round (pairs, a multiple of 64) on the LDS-DMA kernels; unset: 2^21 / 2^20 (round 0: 2 tables / 2 + term), 2^16 / 2^19 (fused: 3 tables / 2 + term)
    ZK_ROUND_GLDS_NT_MIN_PAIRS 2^20   64 .. 2^40   fused LDS-DMA rounds at least this big store their half tables nontemporal
    ZK_EVAL_FOLDS           off       flag         variable-by-variable evaluate (one fold launch per variable)
    ZK_EVAL_STREAM_MIN      21        0 .. 1000    smallest table (variables) that takes the streaming evaluate kernel

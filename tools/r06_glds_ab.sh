@@ -1,5 +1,5 @@
 #!/bin/bash
-# the big rounds on the LDS-DMA kernels (ZK_ROUND_GLDS=1: k_round0_glds<0/1>, k_round0_glds3, k_round_fused_glds<2/3>) vs k_round0_dot29 /
+# the big rounds on the LDS-DMA kernels (ZK_ROUND_GLDS=1: k_round0_glds<0/1>, k_round_fused_glds<3,0> / <2,1>) vs k_round0_dot29 /
 # k_round_kd (=0): forced-path parity at small sizes, then the wall-clock A/B (each arm in its own process, interleaved)
 set -u
 mkdir -p gpurun_out

@@ -527,14 +527,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_round0_dot29_b(BatchOf<RoundSlot>
 // (tools/mb/mb_round0_glds.hip, mb_fused_glds.hip, mb_rows_pattern.hip; in the prover: profiles/r06_glds_sizes.log):
 //  * the sums-only round of two tables was held at 0.63 of HBM by its access SHAPE, not by its prefetch depth (a ring of one unit does
 //    what a ring of four does, at two, three or four waves per SIMD): 212 -> 168 us at 2^24 per table;
-//  * the three-table kernels keep their prefetch in LDS instead of 48-96 registers and stop spilling: 8-17 % from the sizes in rounds.hip;
+//  * the three-table FUSED kernels keep their prefetch in LDS instead of 48-96 registers and stop spilling: 8-13 % from the sizes in
+//    rounds.hip (round 0 of three tables was built too -- carry-free columns, shared pair products -- and lost its lead when the shared
+//    pair products went into k_round_kd as well: PAIR3 in round_factor; HISTORY.md);
 //  * the fused round of TWO tables gains nothing in any form (eight read + four written streams reach 0.69-0.72 of HBM with every
 //    multiplication removed) and has no instantiation here.
 // The DMA instructions live in asm statements, so the compiler does not count them: every wait is a counted s_waitcnt vmcnt(N) placed
 // by hand.  vmcnt retires in issue order and counts stores as well on this part; N is always "what was issued after the pieces I need".
 // q must be a multiple of 64 (the host sends other sizes to the kernels above); a wave's runs are r0, r0 + rs, ... (wave-uniform).
 extern __shared__ __attribute__((aligned(1024))) uint8_t glds_ring[];   // [4 waves][8 or 12 KiB]
-constexpr uint32_t kGldsRingBytes = 4 * 8192, kGldsRing3Bytes = 4 * 12288;   // per workgroup: two 4-KiB units or one 8-KiB unit per wave; three units
+constexpr uint32_t kGldsRingBytes = 4 * 8192, kGldsRing3Bytes = 4 * 12288;   // per workgroup: two 4-KiB units or one 8-KiB unit per wave; three 4-KiB units
 template <int N>
 ZK_D void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -689,95 +691,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_round0_glds_b(BatchOf<RoundSlot> 
     const RoundSlot &a = b.a[blockIdx.y];
     const FactorPtrs fp = factor_ptrs_of(a.fp);
     round0_glds_body<EXTRA>(fp, q, P, a.partials);
-}
-
-// Round 0 of the three-table degree-3 product (k_round_kd<3, 3, false, 0, false, true>'s sums: S(0), S(1), S(2) and the leading
-// coefficient in slot 3).  That kernel is VALU-bound (four reduced table x table products and four wide ones per pair index); here
-//  * the pair products of the first two tables are A = lo0 lo1, B = hi0 hi1, C = d0 d1 (d = hi - lo), and the fourth,
-//    (lo0 + 2 d0)(lo1 + 2 d1) = 2 (B + C) - A, costs three modular additions instead of a multiplication (hi0 hi1 = A + cross + C);
-//  * the four products with the third table go into carry-free 29-bit columns (dot29_mac), reduced once per kMaxLazy pair indices;
-//  * the rows arrive by LDS-DMA (one 4-KiB unit per table in the wave's ring), so the 136 column registers fit beside the working set.
-// Exact in F_p, so the same canonical sums (tests: the forced-path sweeps, three fields).
-ZK_D void round0_glds3_body(const FactorPtrs &fp, uint64_t q, const FieldParams &P, uint64_t *__restrict__ partials) {
-    constexpr int NU = 3;
-    const GldsWave w = glds_wave(q, gridDim.x, NU * 4096);
-    const uint64_t hi_off = q * 32;
-    uint64_t c0[17], c1[17], c2[17], cL[17];
-#pragma unroll
-    for (int k = 0; k < 17; ++k) c0[k] = c1[k] = c2[k] = cL[k] = 0;
-    Fe sum[4] = {fe_zero(), fe_zero(), fe_zero(), fe_zero()};
-    if (w.K) {
-#pragma unroll
-        for (int f = 0; f < NU; ++f) {
-            const uint64_t a = (uint64_t)(uintptr_t)fp.in[f] + w.r0 * 2048;
-            glds_rows2(a, a + hi_off, w.voff, w.my_lds + f * 4096);
-        }
-        int since = 0, lazy = 0;
-        for (uint64_t k = 0; k < w.K; ++k) {
-            const bool last = k + 1 == w.K;
-            const uint64_t next = (w.r0 + (k + 1) * w.rs) * 2048;
-            round0_glds_wait<NU, 0>(last);
-            const Fe lo0 = glds_elem(w.my, w.lane), hi0 = glds_elem(w.my + 2048, w.lane);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (!last) glds_rows2((uint64_t)(uintptr_t)fp.in[0] + next, (uint64_t)(uintptr_t)fp.in[0] + next + hi_off, w.voff, w.my_lds);
-            const Fe d0 = fe_sub(hi0, lo0, P);
-            uint32_t lA[9], lB[9], lM[9], lC[9];
-            round0_glds_wait<NU, 1>(last);
-            {
-                const Fe lo1 = glds_elem(w.my + 4096, w.lane), hi1 = glds_elem(w.my + 6144, w.lane);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (!last) glds_rows2((uint64_t)(uintptr_t)fp.in[1] + next, (uint64_t)(uintptr_t)fp.in[1] + next + hi_off, w.voff, w.my_lds + 4096);
-                const Fe A = ZK_KD_INNER_MUL(lo0, lo1, P), B = ZK_KD_INNER_MUL(hi0, hi1, P), C = ZK_KD_INNER_MUL(d0, fe_sub(hi1, lo1, P), P);
-                const Fe bc = fe_add(B, C, P);
-                const Fe M = fe_sub(fe_add(bc, bc, P), A, P);   // (lo0 + 2 d0)(lo1 + 2 d1)
-                split29(A.v, lA);
-                split29(B.v, lB);
-                split29(M.v, lM);
-                split29(C.v, lC);
-            }
-            round0_glds_wait<NU, 2>(last);
-            {
-                const Fe lo2 = glds_elem(w.my + 8192, w.lane), hi2 = glds_elem(w.my + 10240, w.lane);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (!last) glds_rows2((uint64_t)(uintptr_t)fp.in[2] + next, (uint64_t)(uintptr_t)fp.in[2] + next + hi_off, w.voff, w.my_lds + 8192);
-                uint32_t b[9];
-                split29(lo2.v, b);
-                dot29_mac(c0, lA, b);   // S(0)
-                split29(hi2.v, b);
-                dot29_mac(c1, lB, b);   // S(1)
-                const Fe d2 = fe_sub(hi2, lo2, P);
-                split29(d2.v, b);
-                dot29_mac(cL, lC, b);   // leading coefficient
-                const Fe e2 = fe_add(hi2, d2, P);
-                split29(e2.v, b);
-                dot29_mac(c2, lM, b);   // S(2)
-            }
-            ++lazy;
-            if (++since == 7 || lazy == kMaxLazy || last) {
-                dot29_normalise(c0);
-                dot29_normalise(c1);
-                dot29_normalise(c2);
-                dot29_normalise(cL);
-                since = 0;
-            }
-            if (lazy == kMaxLazy || last) {
-                dot29_flush(c0, sum[0], P);
-                dot29_flush(c1, sum[1], P);
-                dot29_flush(c2, sum[2], P);
-                dot29_flush(cL, sum[3], P);
-                lazy = 0;
-            }
-        }
-    }
-    block_reduce_store<4>(sum, partials, P);
-}
-__global__ __launch_bounds__(kBlock, 2) void k_round0_glds3(FactorPtrs fp, uint64_t q, FieldParams P, uint64_t *__restrict__ partials) {
-    round0_glds3_body(fp, q, P, partials);
-}
-__global__ __launch_bounds__(kBlock, 2) void k_round0_glds3_b(BatchOf<RoundSlot> b, uint64_t q, FieldParams P) {
-    const RoundSlot &a = b.a[blockIdx.y];
-    const FactorPtrs fp = factor_ptrs_of(a.fp);
-    round0_glds3_body(fp, q, P, a.partials);
 }
 
 // The big fused rounds of a K-table product of degree D = K with SKIP1 and LEAD, EXTRA = 1: plus a single-factor term

@@ -27,9 +27,9 @@ static int round0_dot29_mode() {
 }
 static bool round0_dot29() { return round0_dot29_mode() != 0; }
 static bool round0_dot29_extra() { return round0_dot29_mode() == 2; }
-// ZK_ROUND_GLDS: 1 (default) = the big rounds take the LDS-DMA kernels (round_kernels.cuh: k_round0_glds<0 / 1> and k_round0_glds3 for
-// round 0, k_round_fused_glds<3, 0> and <2, 1> for the fused SKIP1 + LEAD rounds over three tables); 0 = k_round0_dot29 / k_round_kd at
-// every size (A/B).  Sizes: a multiple of 64 pairs and at least 2^21 (round 0, two tables), 2^20 (round 0, three tables or product plus term), 2^16 /
+// ZK_ROUND_GLDS: 1 (default) = the big rounds take the LDS-DMA kernels (round_kernels.cuh: k_round0_glds<0 / 1> for round 0 over two
+// tables (+ a term), k_round_fused_glds<3, 0> and <2, 1> for the fused SKIP1 + LEAD rounds over three tables); 0 = k_round0_dot29 / k_round_kd at
+// every size (A/B).  Sizes: a multiple of 64 pairs and at least 2^21 (round 0, two tables), 2^20 (round 0, product plus term), 2^16 /
 // 2^19 (fused rounds of the (3, 3) product / of the product-plus-term shape; the fused rounds of the two-table product gain nothing at
 // any size and stay on k_round_kd) -- measured cross-overs, profiles/r06_glds_sizes.log; ZK_ROUND_GLDS_MIN_PAIRS replaces
 // all of them (the parity sweeps force 64).  The half tables of a fused round bypass the caches from ZK_ROUND_GLDS_NT_MIN_PAIRS pairs up.
@@ -140,19 +140,6 @@ static void go_round0_glds(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint6
     if (batch_record(BK_ROUND0_DOT29, kShapeGlds | (uint32_t)EXTRA, grid, kBlock, lds, q, 0, 0, 0, RoundSlot{factor_ptrs4(fp), nullptr, part, ClaimJob{}}, single)) return;
     (void)single();
 }
-static void go_round0_glds3(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, uint32_t grid) {
-    const FieldParams *P = lc.P;
-    hipStream_t st = lc.stream;
-    uint64_t *part = lc.d_partials;
-    auto single = [=]() {
-        k_round0_glds3<<<grid, kBlock, kGldsRing3Bytes, st>>>(fp, q, *P, part);
-        return hipGetLastError();
-    };
-    if (batch_record(BK_ROUND_KD, kd_shape(3, 3, false, 0, false, true) | kShapeGlds, grid, kBlock, kGldsRing3Bytes, q, 0, 0, 0,
-                     RoundSlot{factor_ptrs4(fp), nullptr, part, ClaimJob{}}, single))
-        return;
-    (void)single();
-}
 template <int K, int EXTRA>
 static void go_fused_glds(const RoundLaunchCtx &lc, const FactorPtrs &fp, uint64_t q, const uint64_t *d_r, uint32_t grid, const ClaimJob &cj) {
     const FieldParams *P = lc.P;
@@ -205,10 +192,7 @@ int launch_round(const RoundLaunchCtx &lc, const FactorPtrs &fp, int k, uint64_t
                 go_round0_glds<0>(lc, fp, q, g);
             } else if (shl == 22 && round0_dot29()) go_round0_dot29<0>(lc, fp, q, g);
             else if (shl == 22) go_kd<2, 2, false, 0, false, true>(lc, fp, q, d_r, g);
-            else if (glds_takes(q, (uint64_t)1 << 20)) {
-                if (g > 512) g = 512;
-                go_round0_glds3(lc, fp, q, g);
-            } else go_kd<3, 3, false, 0, false, true>(lc, fp, q, d_r, g);
+            else go_kd<3, 3, false, 0, false, true>(lc, fp, q, d_r, g);
             if (skip1) *skip1 = false;
         } else if (skip1 && *skip1) {
             if (shl == 33 && glds_takes(q, (uint64_t)1 << 16)) go_fused_glds<3, 0>(lc, fp, q, d_r, g + claim_blocks(lc), lc.claim);
@@ -361,8 +345,6 @@ int batch_launch_rounds(const BatchRecorder &r, size_t idx) {
         if (base == kd_shape(3, 3, true, 0, true, true)) {
             if (nt) k_round_fused_glds_b<3, 0, true><<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
             else k_round_fused_glds_b<3, 0, false><<<grid, kBlock, kGldsRingBytes, r.stream>>>(slots, q, P);
-        } else if (base == kd_shape(3, 3, false, 0, false, true)) {
-            k_round0_glds3_b<<<grid, kBlock, kGldsRing3Bytes, r.stream>>>(slots, q, P);
         } else {
             return kLaunchUnsupported;
         }
