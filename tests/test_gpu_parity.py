@@ -828,6 +828,8 @@ SKIP1_RUNS = {
     "glds_then_pipe": dict(ZK_ROUND_GLDS_MIN_PAIRS="64", ZK_ROUND_GLDS_NT_MIN_PAIRS="256", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1",
                            ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="11,12,13,15"),
     "glds_defaults_n18_to_20": dict(ZK_CHECK_SIZES="18,19,20", ZK_CHECK_FIELDS="2"),
+    # the shipped thresholds where round 0 of two tables (2^21 pairs) and the product-plus-term kernels (2^20 / 2^19) reach them
+    "glds_defaults_n21_22": dict(ZK_CHECK_SIZES="21,22", ZK_CHECK_FIELDS="1"),
     "glds_off_n19_20": dict(ZK_ROUND_GLDS="0", ZK_CHECK_SIZES="19,20", ZK_CHECK_FIELDS="1"),
     "claim_in_tails": dict(ZK_CLAIM_IN_ROUND="0", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="3,7,11,13",
                            ZK_CHECK_FIELDS="2"),
