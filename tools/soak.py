@@ -23,7 +23,7 @@ while time.time() < t_end:
     c = ctxs[f]
     p = zk_amd.modulus(f)
     kind = rng.choice(["prove", "prove", "terms", "evaluate", "fold", "gkr", "gkr_wide", "evaluate_big", "prod_reduce", "to_bytes", "coeff", "shard",
-                       "batch", "batch", "prove_absorb"])
+                       "batch", "batch", "prove_absorb", "prove_big"])
     if kind == "batch":   # zk_sumcheck_prove_batch: B independent proofs side by side (round 6), each against the oracle's own proof
         k, D = rng.choice([(2, 2), (2, 2), (3, 3), (3, 3), (1, 1), (2, 3), (4, 4)])
         n = rng.choice([1, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17] if k <= 3 else [1, 4, 9, 11])
@@ -37,6 +37,15 @@ while time.time() < t_end:
         got = SumcheckProver(D).prove_partial_batch(polys, np.stack([s for _, s, _ in cases]), consume=rng.random() < 0.5)
         for (proof, ch), (_, _, (want_rp, want_ch)) in zip(got, cases):
             assert np.array_equal(proof.round_polys, want_rp) and np.array_equal(ch, want_ch), ("batch", f, k, D, n, B)
+    elif kind == "prove_big":   # sizes where the shipped thresholds pick the LDS-DMA round kernels (round 0 of two tables from 2^21 pairs)
+        k, D = rng.choice([(2, 2), (2, 2), (3, 3)])
+        n = rng.choice([22, 23] if k == 2 else [21, 22])
+        tabs = [orc.fill_random(f, rng.randrange(1 << 30), 1 << n) for _ in range(k)]
+        s = orc.fill_random(f, rng.randrange(1 << 30), 1)[0]
+        want_rp, want_ch = orc.sumcheck_prove(f, n, tabs, D, s, False)
+        pp = ProductPoly.new([MLE.new(c, n, t) for t in tabs])
+        proof, ch = SumcheckProver(D).prove_partial(pp, s, consume=True)
+        assert np.array_equal(proof.round_polys, want_rp) and np.array_equal(ch, want_ch), ("prove_big", f, k, D, n)
     elif kind == "prove_absorb":   # prove (tables absorbed, prover.rs:15-20) where the chunked serialiser runs: 1, 2 and 4 chunks per table
         k, D = rng.choice([(1, 1), (2, 2), (2, 2), (3, 3)])
         n = rng.choice([18, 19, 20, 21])
