@@ -946,6 +946,20 @@ def main():
             for pp in layers:
                 for q in pp.polynomials:
                     q.free()
+            # one BIG three-table proof (k = 3, D = 3, n = 22): the size where the fused rounds of three tables run on the LDS-DMA kernels
+            # from the first fold on.  Gated like every row: the timed proof against the faithful oracle's on the same tables.
+            t3 = [zk_amd.MultiLinearPolynomial.random(ctx, 22, 0x7000 + f, 0) for f in range(3)]
+            pp3 = zk_amd.ProductPoly.new(t3)
+            got3 = p3.prove_partial(pp3, claimed)
+            if not args.no_parity_gate:
+                from oracle import binding as orc
+                w_rp, w_ch = orc.sumcheck_prove(field, 22, [q.evaluation_slice() for q in t3], 3, claimed, False)
+                gate_set(result, "prove_k3_n22", np.array_equal(got3[0].round_polys, w_rp) and np.array_equal(got3[1], w_ch))
+            ms3 = sorted(zk_amd.bench_prove_partial(pp3, 3, claimed, 11))
+            extra["sumcheck_prove_partial_ms_n22_k3_d3"] = ms3[len(ms3) // 2]
+            extra["sumcheck_prove_partial_ms_n22_k3_d3_min"] = ms3[0]
+            for q in t3:
+                q.free()
             # config[3] as an actual layered circuit: depth 8, width 2^20, random add/mul gates with random wiring, proved by
             # the GKR-shaped driver (zk_gkr_prove: circuit evaluation + per layer two sum-of-products prove_partial calls)
             try:

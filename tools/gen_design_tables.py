@@ -85,6 +85,10 @@ def build():
     if "sumcheck_prove_absorbing_ms_n24_k2_d2" in ex:
         L.append(f"| `prove` (tables absorbed first, `prover.rs:15-20`: a serial host Keccak over k·2^n·32 B) | n = 20: {ex['sumcheck_prove_absorbing_ms_n20_k2_d2']:.0f} ms; "
                  f"n = 24: {ex['sumcheck_prove_absorbing_ms_n24_k2_d2']:.0f} ms | host-bound |")
+    if ex.get("sumcheck_prove_partial_ms_n22_k3_d3"):
+        L.append(f"| `prove_partial` k = 3, D = 3, n = 22 (fused rounds of three tables on the LDS-DMA kernels; gated against the oracle's proof) | "
+                 f"**{ex['sumcheck_prove_partial_ms_n22_k3_d3']:.3f}** / {ex['sumcheck_prove_partial_ms_n22_k3_d3_min']:.3f} ms | "
+                 f"{frac(3 * 96 * 2 ** 22, ex['sumcheck_prove_partial_ms_n22_k3_d3'] * 1e3):.3f} (k·96·2^n B) |")
     L.append(f"| eight layers of `prove_partial` on 3 factors of 2^20, D = 3 / GKR driver depth 8 × 2^20 (random add/mul wiring) | "
              f"{ex['gkr_shaped_depth8_width2p20_k3_d3_ms']:.2f} ms / prove **{ex['gkr_depth8_width2p20_addmul_prove_ms']:.2f} ms**, verify "
              f"{ex['gkr_depth8_width2p20_addmul_verify_ms']:.2f} ms, proof {ex['gkr_proof_bytes']} B | latency-bound |")
