@@ -124,7 +124,8 @@ def build():
         if "to_bytes_2p24" in rows:
             z = rows["to_bytes_2p24"]
             tail += f"; `to_bytes`: {z['ms_fresh_destination']:.1f} ms into a fresh destination, {z['ms_mapped_destination']:.1f} ms into a mapped one"
-        L.append("| other (a)-rows at 2^24 through the allocating calls | `prod_reduce` k = 2 / 3: " + rr("prod_reduce_k2_2p24") + " / " + rr("prod_reduce_k3_2p24") +
+        settled = " (single calls; 0.8 s of untimed folds first -- right after idle seconds the same call measures up to 40 % longer, `profiles/r06_a_rows_probe.log`)" if ex.get("rows_2p24_note") else ""
+        L.append("| other (a)-rows at 2^24 through the allocating calls" + settled + " | `prod_reduce` k = 2 / 3: " + rr("prod_reduce_k2_2p24") + " / " + rr("prod_reduce_k3_2p24") +
                  "; `partial_evaluate` at " + ", ".join(f"{k.split('_')[-1]}: {rr(k)}" for k in pe) + tail + " | (of 8 TB/s) |")
     L.append(f"| multiplier cores, register resident (`zk_bench_modmul`) | `fe_mul` {ex['modmul_per_s_register_resident']:.3e} /s, `fe_mul29` "
              f"{ex['modmul29_per_s_register_resident']:.3e} /s; 1-GiB streaming copy {ex['copy_gbps_1GiB']:.0f} GB/s | the integer roof; the copy ceiling |")
