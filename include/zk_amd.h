@@ -377,6 +377,7 @@ int32_t zk_bench_copy(zk_ctx *ctx, uint64_t bytes, int32_t reps, double *out_gbp
    ZK_PIPE_MAX_PAIRS       4096      0 .. 2^40    rounds up to this size are prepared before their challenge exists; 0 = never
    ZK_ROUND_MIN_BLOCKS     512 / 256 1 .. 2048    smallest grid of the fused round kernels (256 for the GKR shape)
    ZK_FINISH_PIPE          1         0 .. 1       0: the classic single-workgroup finisher instead of the pipelined one
+   ZK_SPONGE_IN_TAIL       1         0 .. 1       0: the initial sponge state goes to the device with a launch of its own instead of as an argument of round 0's tail
    ZK_ROUND0_DOT29         1         0 .. 2       0: round 0 of the two-table degree-2 shapes on the wide accumulator; 2: force dot29
    ZK_ROUND_GLDS           1         0 .. 1       0: the big rounds on k_round0_dot29 / k_round_kd instead of the LDS-DMA kernels (k_round0_glds, k_round_fused_glds)
    ZK_ROUND_GLDS_MIN_PAIRS per kernel 64 .. 2^40  smallest round (pairs, a multiple of 64) on the LDS-DMA kernels; unset: 2^21 / 2^20 (round 0: 2 tables / 2 + term), 2^16 / 2^19 (fused: 3 tables / 2 + term)

@@ -831,11 +831,14 @@ SKIP1_RUNS = {
     # the shipped thresholds where round 0 of two tables (2^21 pairs) and the product-plus-term kernels (2^20 / 2^19) reach them
     "glds_defaults_n21_22": dict(ZK_CHECK_SIZES="21,22", ZK_CHECK_FIELDS="1"),
     "glds_off_n19_20": dict(ZK_ROUND_GLDS="0", ZK_CHECK_SIZES="19,20", ZK_CHECK_FIELDS="1"),
+    # the initial sponge stored by a launch of its own in front of round 0 (until round 6; shipped: an argument of round 0's tail)
+    "sponge_by_its_own_launch": dict(ZK_SPONGE_IN_TAIL="0", ZK_CHECK_SIZES="2,9,13,14,17", ZK_CHECK_FIELDS="2"),
     "claim_in_tails": dict(ZK_CLAIM_IN_ROUND="0", ZK_LEAD_MIN_PAIRS="1", ZK_SKIP1_MIN_PAIRS="1", ZK_QUAD_MAX_PAIRS="0", ZK_CHECK_SIZES="3,7,11,13",
                            ZK_CHECK_FIELDS="2"),
 }
 _SWEEP_ENV_KEYS = ("ZK_SKIP1_MIN_PAIRS", "ZK_QUAD_MAX_PAIRS", "ZK_PIPE_MAX_PAIRS", "ZK_CHECK_SIZES", "ZK_LEAD_MIN_PAIRS", "ZK_ROUND0_DOT29",
-                   "ZK_CHECK_FIELDS", "ZK_CLAIM_IN_ROUND", "ZK_ROUND_GLDS", "ZK_ROUND_GLDS_MIN_PAIRS", "ZK_ROUND_GLDS_NT_MIN_PAIRS")
+                   "ZK_CHECK_FIELDS", "ZK_CLAIM_IN_ROUND", "ZK_ROUND_GLDS", "ZK_ROUND_GLDS_MIN_PAIRS", "ZK_ROUND_GLDS_NT_MIN_PAIRS",
+                   "ZK_SPONGE_IN_TAIL")
 
 
 @pytest.fixture(scope="module")

@@ -1243,11 +1243,28 @@ static inline RoundLaunchCtx launch_ctx(zk_ctx *c) {
     return lc;
 }
 // k_round_tail on the current proof's partials: launched, or recorded for the batch's merged launch (one transcript block per proof)
+// the initial sponge of a single proof, not stored yet: the first classic tail takes it as an argument (k_round_tail_init); any other
+// first consumer stores it first (flush_pending_sponge)
+struct PendingSponge {
+    WordSponge w;
+    WordSponge *dst;
+    uint64_t *zero2;
+    bool valid;
+};
 static int32_t launch_tail(zk_ctx *c, uint32_t nblocks, uint32_t ns, WordSponge *sponge, uint64_t *out_rp, uint64_t *out_ch, uint64_t *d_challenge,
-                           uint64_t *lanes, const TailDerive &dv) {
+                           uint64_t *lanes, const TailDerive &dv, const PendingSponge *init = nullptr) {
     const uint64_t *part = partials_of(c);
     hipStream_t st = c->stream;
     const FieldParams *P = &c->fi->P;
+    if (init && init->valid && sponge == init->dst && !lanes && !g_batch) {
+        k_round_tail_init<<<1, kBlock, 0, st>>>(part, nblocks, ns, sponge, out_rp, out_ch, d_challenge, *P, dv, init->w, init->zero2);
+        HIPCHK(hipGetLastError());
+        return ZK_OK;
+    }
+    if (init && init->valid) {   // (cannot happen with the callers as they are: the state must reach the device before anything reads it)
+        k_store_sponge<<<1, 64, 0, st>>>(init->w, init->dst, init->zero2);
+        HIPCHK(hipGetLastError());
+    }
     auto single = [=]() {
         k_round_tail<<<1, kBlock, 0, st>>>(part, nblocks, ns, sponge, out_rp, out_ch, d_challenge, lanes, *P, dv);
         return hipGetLastError();
@@ -1270,6 +1287,7 @@ struct TailTargets {
     uint64_t *out_ch;       // challenge record (device), may be null
     uint64_t *d_challenge;  // challenge for the next fused fold
     uint64_t *lanes;        // 32-bit digit lanes for the cross-GPU all-reduce, may be null
+    const PendingSponge *init;   // non-null: the proof's initial sponge has not been stored -- this round's tail takes it as an argument
     uint64_t *claim_park;   // one element owned by the prover (ProverScratch::d_claim); null: no SKIP1 round is possible (no previous round)
     TailDerive *lanes_dv;   // with lanes (host memory, may be null): out -- what k_lanes_transcript has to derive after the all-reduce
                             // (S(1) from the claim, S(D) from the leading coefficient); null: the round kernels compute every sum
@@ -1352,7 +1370,7 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
                     defer->lead = lead;
                     return ZK_OK;
                 }
-                return launch_tail(c, g, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge, tt.lanes, tail_dv());
+                return launch_tail(c, g, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge, tt.lanes, tail_dv(), tt.init);
             }
         }
         if (ts.n_terms != 1) {
@@ -1385,7 +1403,7 @@ static int32_t launch_sums(zk_ctx *c, const FactorPtrs &fp, const TermSpec &ts, 
             defer->lead = lead;
             return ZK_OK;
         }
-        return launch_tail(c, total, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge, tt.lanes, tail_dv());
+        return launch_tail(c, total, D + 1, tt.sponge, tt.out_rp, tt.out_ch, tt.d_challenge, tt.lanes, tail_dv(), tt.init);
     }
     if (ts.n_terms != 1) return ZK_ERR_UNSUPPORTED;
     const int k = ts.term_k[0];
@@ -1554,6 +1572,7 @@ struct RoundState {
     uint32_t pipe_blocks;             // work blocks that wrote them
     bool pipe_total;                  // slot 0 of their buffer holds the total (k_round_pipe: the block that finishes last adds them up);
                                       // false: the next launch's transcript block (or the finisher) adds the pipe_blocks partials up
+    PendingSponge init;               // valid: the initial sponge is still on the host side of the launch queue (prove_core)
     FinishPublish pub;                // flag != null: the pipelined finisher, being the call's last launch, publishes the proof block itself
     bool published;                   // ... and has been enqueued with that job
 };
@@ -1592,6 +1611,7 @@ static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uin
     st.pipe_total = true;
     st.pub = {};
     st.published = false;
+    st.init.valid = false;
     for (uint64_t i = 0; i < (uint64_t)kMaxFactors; ++i) {
         st.cur[i] = i < k ? f[i]->d : nullptr;
         st.scratch[i] = nullptr;
@@ -1625,6 +1645,15 @@ static int32_t round_state_init(RoundState &st, zk_ctx *c, zk_mle *const *f, uin
 }
 // Enqueue the next round: apply the pending fold (prover.rs:64 of the previous round, fused) and compute this round's
 // sums (prover.rs:49-56).  `lanes` selects the sharded form (sums -> digit lanes, transcript deferred).
+// store the proof's initial sponge with a launch of its own (what every proof did until round 6): for first transcript steps that are
+// not a classic tail (a pipelined launch, a finisher) and for the batch / sharded provers
+static int32_t flush_pending_sponge(RoundState &st) {
+    if (!st.init.valid) return ZK_OK;
+    st.init.valid = false;
+    k_store_sponge<<<1, 64, 0, st.c->stream>>>(st.init.w, st.init.dst, st.init.zero2);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
 static int32_t round_enqueue(RoundState &st, uint64_t *lanes, DeferredTail *defer = nullptr, TailDerive *lanes_dv = nullptr) {
     zk_ctx *c = st.c;
     if (st.pending_fold) st.vars_left -= 1;           // tables shrink by the fold fused into this launch
@@ -1644,6 +1673,13 @@ static int32_t round_enqueue(RoundState &st, uint64_t *lanes, DeferredTail *defe
     tt.lanes = lanes;
     tt.claim_park = st.ps.d_claim;
     tt.lanes_dv = lanes_dv;
+    // the initial sponge, if it has not been stored yet: this round's tail takes it as an argument when it is a classic tail launched right
+    // here (launch_sums on a supported degree, not deferred into a pipelined launch, not sharded); else it is stored now
+    tt.init = nullptr;
+    if (st.init.valid) {
+        if (!lanes && !defer && fast_degree(st.D) && !st.pending_fold) tt.init = &st.init;
+        else ZKCHK(flush_pending_sponge(st));
+    }
     int32_t rc;
     if (st.pending_fold && !fast_degree(st.D)) {
         // generic degree: fold as separate launches, then the per-point passes
@@ -1661,6 +1697,7 @@ static int32_t round_enqueue(RoundState &st, uint64_t *lanes, DeferredTail *defe
         st.dv.prev_rp = st.round ? tt.out_rp - (size_t)(st.D + 1) * 4 : nullptr;
         st.dv.prev_chal = chal_prev(st);
         rc = launch_sums(c, fp, st.terms, q, st.D, st.pending_fold, chal_prev(st), tt, &st.dv, defer);
+        if (tt.init) st.init.valid = false;   // (consumed by the tail; on an error the proof is abandoned anyway)
     }
     if (st.pending_fold) {
         for (uint64_t i = 0; i < st.k; ++i) st.cur[i] = fp.out[i];
@@ -1965,6 +2002,7 @@ static inline bool finish_applies(const RoundState &st) {
 }
 
 static int32_t prover_step(RoundState &st, bool *finished_in_kernel) {
+    if (st.init.valid && (finish_pipe_applies(st) || st.pipe_active || finish_applies(st))) ZKCHK(flush_pending_sponge(st));
     if (finish_pipe_applies(st)) {                                       // (covers the pipelined state as well)
         *finished_in_kernel = true;
         return finish_pipe_enqueue(st);
@@ -2064,7 +2102,18 @@ static int32_t prove_core(zk_ctx *c, zk_mle *const *f, uint64_t k, const TermSpe
     st.terms = ts;
     int32_t rc = ZK_OK;
     if (out_final) st.d_final = st.ps.d_final;
-    if (rc == ZK_OK) rc = sponge_to_device(c, sp, st.ps.d_sponge, st.ps.d_epart);
+    // ZK_SPONGE_IN_TAIL=0: the initial sponge goes to the device with a launch of its own in front of round 0 (until round 6; A/B)
+    static const bool sponge_in_tail = env_u64("ZK_SPONGE_IN_TAIL", 1, 0, 1) != 0;
+    if (rc == ZK_OK) {
+        if (sponge_in_tail && !g_batch) {
+            if (!st.init.w.from_byte_sponge(sp)) rc = ZK_ERR_BAD_ARG;
+            st.init.dst = st.ps.d_sponge;
+            st.init.zero2 = st.ps.d_epart ? epart_counters(st.ps.d_epart) : nullptr;
+            st.init.valid = rc == ZK_OK;
+        } else {
+            rc = sponge_to_device(c, sp, st.ps.d_sponge, st.ps.d_epart);
+        }
+    }
     // one copy of [round polys | challenges | finals] into pinned memory behind a completion word: by the pipelined finisher itself
     // when it is the call's last launch (ZK_PUBLISH_IN_FINISHER=0: always by k_publish_host), else by k_publish_host below
     uint8_t *stage = nullptr;

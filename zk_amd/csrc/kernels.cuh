@@ -391,9 +391,23 @@ __global__ __launch_bounds__(kBlock) void k_prod_reduce(FactorPtrs fp, int k, ui
 //   lanes    != null : store them as 8 zero-extended 32-bit digits per element (uint64 lanes) for the cross-GPU
 //                      all-reduce (RCCL has no mod-p sum; integer lane sums cannot overflow);
 //   sponge   != null : run the transcript step and publish the challenge.
+// init (optional, a kernel ARGUMENT): the proof's initial sponge state.  The tail that closes round 0 then takes the state from its own
+// arguments instead of from *sponge, and clears the two counters at zero2 -- the launch that used to do both in front of round 0
+// (k_store_sponge) disappears from the single proof's serial chain.  25 selects on SGPR operands: a dynamic index into a by-value
+// argument would send it through scratch.
+ZK_D LaneSponge lane_sponge_from_arg(const WordSponge &w, const LaneKeccak &L) {
+    LaneSponge sp;
+    sp.a = 0;
+#pragma unroll
+    for (int i = 0; i < 25; ++i)
+        if (L.index == i) sp.a = w.s[i];
+    sp.pos = w.pos;
+    return sp;
+}
 ZK_D void round_tail_body(const uint64_t *__restrict__ partials, uint32_t nblocks, uint32_t ns, WordSponge *__restrict__ sponge,
                           uint64_t *__restrict__ out_rp, uint64_t *__restrict__ out_ch, uint64_t *__restrict__ d_challenge,
-                          uint64_t *__restrict__ lanes, const FieldParams &P, const TailDerive &dv) {
+                          uint64_t *__restrict__ lanes, const FieldParams &P, const TailDerive &dv, const WordSponge *init = nullptr,
+                          uint64_t *__restrict__ zero2 = nullptr) {
     __shared__ Fe fin[256];
     __shared__ Fe claim;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -402,7 +416,8 @@ ZK_D void round_tail_body(const uint64_t *__restrict__ partials, uint32_t nblock
     // wave 0 fetches the sponge first, so that load is in flight while the partials are reduced
     const LaneKeccak L = lane_keccak_init();
     LaneSponge sp = {0, 0};
-    if (sponge && wave0) sp = lane_sponge_load(sponge, L);
+    if (sponge && wave0) sp = init ? lane_sponge_from_arg(*init, L) : lane_sponge_load(sponge, L);
+    if (init && zero2 && threadIdx.x >= 64 && threadIdx.x < 66) zero2[threadIdx.x - 64] = 0;
     // wave w owns the sums t = w, w+4, ...: lanes stride over the blocks' partials, one VALU wave reduction, one barrier
     for (uint32_t t = wave; t < ns; t += kBlock / 64) {
         if (derive1 && t == 1 && (dv.claim || dv.local_only)) {
@@ -475,6 +490,13 @@ __global__ __launch_bounds__(kBlock) void k_round_tail(const uint64_t *__restric
                                                        uint64_t *__restrict__ out_ch, uint64_t *__restrict__ d_challenge,
                                                        uint64_t *__restrict__ lanes, FieldParams P, TailDerive dv = {}) {
     round_tail_body(partials, nblocks, ns, sponge, out_rp, out_ch, d_challenge, lanes, P, dv);
+}
+// the tail of round 0 of a single proof: the initial sponge state arrives as an argument (round_tail_body)
+__global__ __launch_bounds__(kBlock) void k_round_tail_init(const uint64_t *__restrict__ partials, uint32_t nblocks, uint32_t ns,
+                                                            WordSponge *__restrict__ sponge, uint64_t *__restrict__ out_rp,
+                                                            uint64_t *__restrict__ out_ch, uint64_t *__restrict__ d_challenge, FieldParams P,
+                                                            TailDerive dv, WordSponge init, uint64_t *__restrict__ zero2) {
+    round_tail_body(partials, nblocks, ns, sponge, out_rp, out_ch, d_challenge, nullptr, P, dv, &init, zero2);
 }
 // batched form (zk_sumcheck_prove_batch): grid (1, proofs), the B transcript steps of a round side by side
 struct TailSlot {
